@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by importing the REFERENCE itself.
+
+Run in the build container only (needs /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py [--full]      # --full adds the 768x1152 step (minutes of CPU)
+
+Nothing else in the repository reads /root/reference.  Outputs are data only (inputs are
+regenerated from seeds by the tests; expected outputs are stored here):
+
+  state_keys.json      G6  reference state-dict keys / shapes / dtypes, parameter order, Adam state layout
+  init_seed333.json    G4  per-tensor (sum, abs-sum, first 4 values) of the seed-333 initialisation
+  loss_kat.npz         G1  fp_loss / argmax / compute_score known-answer cases
+  block_kat.npz        G3  reference Block forward/backward at small channel counts (in-place ReLU quirk)
+  model_small.json     G4  64x96 B=2: logits samples, loss, IoU, grad checksums, 3 steps Adam and AdamW, eval B=1
+  model_full.json      G4  768x1152 B=2 (only with --full)
+  lr_schedule.json     G5  MultiStepLR sequences through the reference's get_lr_schedule
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REF = "/root/reference/src/deepCam"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+
+from architecture import deeplab_xception as ref_arch      # noqa: E402
+from utils import losses as ref_losses                      # noqa: E402
+from utils import utils as ref_utils                        # noqa: E402
+from utils import parsing_helpers as ref_ph                 # noqa: E402
+
+CLASS_W = [0.986267818390377 ** -0.125, 0.0004578708870701058 ** -0.125, 0.01327431072255291 ** -0.125]
+FPW = (2.61461122397522257612, 1.71641974795896018744)
+
+
+def tensor_digest(t):
+    f = t.detach().double().flatten()
+    return {"sum": float(f.sum()), "abs": float(f.abs().sum()), "head": [float(x) for x in f[:4]]}
+
+
+def make_inputs(B, H, W, seed=1234):
+    """Synthetic batch recipe shared with the tests (tests/util_inputs.py restates it)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 16, H, W, generator=g)
+    y = torch.randint(0, 3, (B, H, W), generator=g)
+    return x, y
+
+
+def sample_index(n, count=64, seed=99):
+    rs = np.random.RandomState(seed)
+    return rs.randint(0, n, size=count).astype(np.int64)
+
+
+def build_ref_model():
+    torch.manual_seed(333)
+    return ref_arch.DeepLabv3_plus(n_input=16, n_classes=3, os=16, pretrained=False, rank=1)
+
+
+def g6_state_keys(net):
+    sd = net.state_dict()
+    out = {"state_dict": [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()],
+           "parameters": [k for k, _ in net.named_parameters()]}
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    osd = opt.state_dict()
+    out["adam_state_keys"] = sorted(osd["state"][0].keys())
+    out["adam_param_group_keys"] = sorted(osd["param_groups"][0].keys())
+    out["adam_num_state"] = len(osd["state"])
+    json.dump(out, open(os.path.join(HERE, "state_keys.json"), "w"), indent=0)
+
+
+def g4_init(net):
+    out = {k: tensor_digest(v) for k, v in net.state_dict().items()}
+    json.dump(out, open(os.path.join(HERE, "init_seed333.json"), "w"), indent=0)
+
+
+def g1_loss():
+    cases = {}
+    g = torch.Generator().manual_seed(7)
+
+    def run(name, logit, target):
+        logit = logit.clone().requires_grad_(True)
+        loss = ref_losses.fp_loss(logit, target, CLASS_W, fpw_1=FPW[0], fpw_2=FPW[1])
+        loss.backward()
+        crit = torch.nn.CrossEntropyLoss(weight=torch.from_numpy(np.array(CLASS_W)).float(), reduction="none")
+        lmap = crit(logit.detach(), target.long())
+        pred = torch.max(logit.detach(), 1)[1]
+        iou = ref_utils.compute_score(pred, target, num_classes=3, device_id=0)
+        gt = target.long()
+        eq, ne = pred == gt, pred != gt
+        tp = [int(torch.sum(eq[gt == j])) for j in range(3)]
+        fp = [int(torch.sum(ne[pred == j])) for j in range(3)]
+        fn = [int(torch.sum(ne[gt == j])) for j in range(3)]
+        cases[name + "_logit"] = logit.detach().numpy()
+        cases[name + "_target"] = target.numpy()
+        cases[name + "_loss"] = np.float32(loss.item())
+        cases[name + "_map"] = lmap.numpy()
+        cases[name + "_grad"] = logit.grad.numpy()
+        cases[name + "_pred"] = pred.numpy()
+        cases[name + "_tp"] = np.array(tp, np.int64)
+        cases[name + "_fp"] = np.array(fp, np.int64)
+        cases[name + "_fn"] = np.array(fn, np.int64)
+        cases[name + "_iou"] = np.float32(float(iou))
+
+    # generic
+    run("rand", torch.randn(2, 3, 32, 48, generator=g) * 3, torch.randint(0, 3, (2, 32, 48), generator=g))
+    # class 1 absent from both prediction and labels -> IoU_1 == 1
+    lg = torch.randn(2, 3, 32, 48, generator=g)
+    lg[:, 1] = -50.0
+    tg = torch.randint(0, 2, (2, 32, 48), generator=g) * 2
+    run("absent", lg, tg)
+    # exact ties (quantised logits) -> first-index argmax; uint8 labels
+    lg = torch.round(torch.randn(2, 3, 32, 48, generator=g))
+    run("ties", lg, torch.randint(0, 3, (2, 32, 48), generator=g).to(torch.uint8))
+    # int32 labels, all-equal logits
+    run("flat", torch.zeros(1, 3, 8, 8), torch.randint(0, 3, (1, 8, 8), generator=g).to(torch.int32))
+    np.savez_compressed(os.path.join(HERE, "loss_kat.npz"), **cases)
+
+
+def g3_blocks():
+    """Reference Block at small widths; covers block1 / block2,3 / middle / block20 shapes of rep lists."""
+    cfgs = {
+        "b1": dict(inplanes=8, planes=16, reps=2, stride=2, start_with_relu=False),
+        "b2": dict(inplanes=16, planes=24, reps=2, stride=2, start_with_relu=True, grow_first=True),
+        "b3": dict(inplanes=16, planes=24, reps=2, stride=2, start_with_relu=True, grow_first=True, is_last=True),
+        "mid": dict(inplanes=24, planes=24, reps=3, stride=1),
+        "b20": dict(inplanes=24, planes=32, reps=2, stride=1, dilation=1, start_with_relu=True, grow_first=False, is_last=True),
+    }
+    out = {}
+    for name, kw in cfgs.items():
+        torch.manual_seed(11)
+        blk = ref_arch.Block(**kw)
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                with torch.no_grad():
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.uniform_(-0.5, 0.5)
+        blk.train()
+        g = torch.Generator().manual_seed(5)
+        x0 = torch.randn(2, kw["inplanes"], 12, 16, generator=g)
+        x = x0.clone().requires_grad_(True)
+        # feed through an identity op so that the in-place ReLU acts on a non-leaf, as in the real model
+        xin = x * 1.0
+        y = blk(xin)
+        go = torch.randn(y.shape, generator=g)
+        y.backward(go)
+        out[name + "_x"] = x0.numpy()
+        out[name + "_xin_after"] = xin.detach().numpy()          # the in-place mutated block input
+        out[name + "_y"] = y.detach().numpy()
+        out[name + "_go"] = go.numpy()
+        out[name + "_gx"] = x.grad.numpy()
+        for k, v in blk.state_dict().items():
+            out[f"{name}_sd_{k}"] = v.numpy()
+        for k, p in blk.named_parameters():
+            out[f"{name}_grad_{k}"] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "block_kat.npz"), **out)
+
+
+def run_model_steps(H, W, optimizer_name, nsteps, wd):
+    net = build_ref_model()
+    net.train()
+    if optimizer_name == "Adam":
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-8, weight_decay=wd)
+    else:
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-3, eps=1e-8, weight_decay=wd)
+    x, y = make_inputs(2, H, W)
+    idx = None
+    steps = []
+    for s in range(nsteps):
+        t0 = time.time()
+        out = net.forward(x)
+        loss = ref_losses.fp_loss(out, y, CLASS_W, fpw_1=FPW[0], fpw_2=FPW[1])
+        opt.zero_grad()
+        loss.backward()
+        rec = {"loss": float(loss.item())}
+        pred = torch.max(out, 1)[1]
+        rec["iou"] = float(ref_utils.compute_score(pred, y, num_classes=3, device_id=0))
+        flat = out.detach().flatten()
+        if idx is None:
+            idx = sample_index(flat.numel())
+        rec["logit_samples"] = [float(v) for v in flat[idx]]
+        rec["logit_digest"] = tensor_digest(out)
+        rec["pred_hist"] = [int((pred == j).sum()) for j in range(3)]
+        if s == 0:
+            named = dict(net.named_parameters())
+            rec["grad_digest"] = {k: tensor_digest(named[k].grad) for k in (
+                "xception_features.conv1.weight", "xception_features.block1.skip.weight",
+                "xception_features.block1.rep.0.conv1.weight", "xception_features.block4.rep.1.pointwise.weight",
+                "xception_features.block4.rep.2.weight", "xception_features.block4.rep.2.bias",
+                "xception_features.block20.rep.6.pointwise.weight", "xception_features.conv5.conv1.weight",
+                "aspp1.atrous_convolution.weight", "aspp4.atrous_convolution.weight", "global_avg_pool.1.weight",
+                "global_avg_pool.2.weight", "conv1.weight", "conv2.weight", "upsample.deconv1.0.weight",
+                "upsample.conv1.0.weight", "upsample.conv1.6.weight", "upsample.conv1.6.bias",
+                "upsample.deconv3.0.weight", "upsample.last_deconv.0.weight")}
+            rec["grad_total_abs"] = float(sum(p.grad.double().abs().sum() for p in net.parameters()))
+        opt.step()
+        rec["seconds"] = time.time() - t0
+        steps.append(rec)
+        print(f"  [{optimizer_name} {H}x{W}] step {s}: loss {rec['loss']:.8f} iou {rec['iou']:.8f} ({rec['seconds']:.1f}s)", flush=True)
+    sd = net.state_dict()
+    final = {k: tensor_digest(sd[k]) for k in (
+        "xception_features.conv1.weight", "xception_features.bn1.running_mean", "xception_features.bn1.running_var",
+        "xception_features.bn1.num_batches_tracked", "xception_features.block4.rep.1.pointwise.weight",
+        "global_avg_pool.2.running_var", "upsample.last_deconv.0.weight", "upsample.conv1.6.bias")}
+    return {"steps": steps, "sample_index": [int(i) for i in idx], "final_state_digest": final}, net
+
+
+def g4_model_small():
+    out = {"recipe": "x=torch.rand(2,16,H,W,G(1234)); y=torch.randint(0,3,(2,H,W),same G); model seed 333; lr 1e-3 eps 1e-8",
+           "H": 64, "W": 96}
+    out["adam_wd1e-6"], net = run_model_steps(64, 96, "Adam", 3, 1e-6)
+    out["adamw_wd1e-2"], _ = run_model_steps(64, 96, "AdamW", 3, 1e-2)
+    # eval-mode forward at B=1 with the fresh seed-333 model (running stats = init values)
+    net = build_ref_model()
+    net.eval()
+    x, y = make_inputs(1, 64, 96, seed=4321)
+    with torch.no_grad():
+        o = net(x)
+        loss = ref_losses.fp_loss(o, y, CLASS_W, fpw_1=FPW[0], fpw_2=FPW[1])
+    idx = sample_index(o.numel())
+    out["eval_b1"] = {"seed": 4321, "loss": float(loss), "logit_samples": [float(v) for v in o.flatten()[idx]],
+                      "logit_digest": tensor_digest(o),
+                      "iou": float(ref_utils.compute_score(torch.max(o, 1)[1], y, num_classes=3, device_id=0))}
+    # B=1 in train mode must raise
+    net.train()
+    try:
+        net(x)
+        out["train_b1_raises"] = False
+    except ValueError as e:
+        out["train_b1_raises"] = True
+        out["train_b1_message"] = str(e)
+    json.dump(out, open(os.path.join(HERE, "model_small.json"), "w"), indent=0)
+
+
+def g4_model_full():
+    out = {"recipe": "as model_small.json", "H": 768, "W": 1152}
+    out["adam_wd1e-6"], _ = run_model_steps(768, 1152, "Adam", 2, 1e-6)
+    json.dump(out, open(os.path.join(HERE, "model_full.json"), "w"), indent=0)
+
+
+def g5_lr():
+    out = {}
+    arg = {"type": "multistep", "milestones": "3 6", "decay_rate": "0.1"}
+    for start in (0, 4):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=1e-3)
+        sched = ref_ph.get_lr_schedule(1e-3, arg, opt, last_step=start)
+        seq = []
+        for _ in range(8):
+            seq.append(sched.get_last_lr()[0])       # read before step, train_hdf5_ddp.py:370-371
+            opt.step()
+            sched.step()
+        out[f"start{start}"] = seq
+    try:
+        ref_ph.get_lr_schedule(1e-3, {"type": "cosine"}, opt)
+        out["bad_type_raises"] = False
+    except ValueError as e:
+        out["bad_type_raises"] = True
+        out["bad_type_message"] = str(e)
+    out["arg"] = arg
+    json.dump(out, open(os.path.join(HERE, "lr_schedule.json"), "w"), indent=0)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    if a.only in (None, "keys"):
+        net = build_ref_model()
+        g4_init(net)
+        g6_state_keys(net)
+    if a.only in (None, "loss"):
+        g1_loss()
+    if a.only in (None, "blocks"):
+        g3_blocks()
+    if a.only in (None, "lr"):
+        g5_lr()
+    if a.only in (None, "small"):
+        g4_model_small()
+    if a.full or a.only == "full":
+        g4_model_full()
+    print("golden fixtures written to", HERE)

@@ -1,0 +1,231 @@
+"""Pin the CPU oracle against golden vectors captured from the reference (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_metric as olm
+from oracle import model as omodel
+from oracle import optim as ooptim
+from util_inputs import digest, make_inputs, sample_index
+
+CLASS_W = olm.class_weights(-0.125)
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def _close_digest(d, ref, rtol=1e-6):
+    assert d["sum"] == pytest.approx(ref["sum"], rel=rtol, abs=1e-6 * max(1.0, ref["abs"]))
+    assert d["abs"] == pytest.approx(ref["abs"], rel=rtol, abs=1e-9)
+
+
+# ---------------------------------------------------------------- G6: checkpoint key layout
+def test_state_dict_keys_match_reference(golden_dir):
+    g = _load(golden_dir, "state_keys.json")
+    sd = omodel.init_state(333)
+    mine = [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()]
+    assert mine == g["state_dict"]
+    assert omodel.param_keys(sd) == g["parameters"]
+    assert len(g["parameters"]) == 301 and len(g["state_dict"]) == 532
+    assert sum(sd[k].numel() for k in g["parameters"]) == 56454720
+
+
+# ---------------------------------------------------------------- G4: seed-333 initialisation, bit for bit
+def test_init_seed333_bit_exact(golden_dir):
+    g = _load(golden_dir, "init_seed333.json")
+    sd = omodel.init_state(333)
+    for k, ref in g.items():
+        d = digest(sd[k])
+        assert d["head"] == ref["head"], k
+        assert d["sum"] == ref["sum"] and d["abs"] == ref["abs"], k
+
+
+# ---------------------------------------------------------------- G1: loss / argmax / IoU
+@pytest.mark.parametrize("case", ["rand", "absent", "ties", "flat"])
+def test_loss_metric_kat(golden_dir, case):
+    z = np.load(os.path.join(golden_dir, "loss_kat.npz"))
+    logit = torch.from_numpy(z[case + "_logit"])
+    target = torch.from_numpy(z[case + "_target"])
+    lmap = olm.weighted_ce_map(logit, target, CLASS_W)
+    np.testing.assert_allclose(lmap.numpy(), z[case + "_map"], rtol=2e-6, atol=1e-6)
+    loss = olm.fp_loss(logit, target, CLASS_W, 2.6, 1.7)
+    assert float(loss) == pytest.approx(float(z[case + "_loss"]), rel=2e-6)
+    np.testing.assert_allclose(olm.fp_loss_grad(logit, target, CLASS_W).numpy(), z[case + "_grad"], rtol=1e-5, atol=1e-9)
+    pred = olm.argmax_first(logit)
+    assert pred.dtype == np.int64
+    np.testing.assert_array_equal(pred, z[case + "_pred"])                      # bit exact, incl. ties
+    tp, fp, fn = olm.confusion_counts(pred, z[case + "_target"])
+    np.testing.assert_array_equal(tp, z[case + "_tp"])
+    np.testing.assert_array_equal(fp, z[case + "_fp"])
+    np.testing.assert_array_equal(fn, z[case + "_fn"])
+    assert olm.iou_from_counts(tp, fp, fn) == pytest.approx(float(z[case + "_iou"]), rel=1e-6)
+
+
+def test_iou_absent_class_counts_as_one(golden_dir):
+    z = np.load(os.path.join(golden_dir, "loss_kat.npz"))
+    tp, fp, fn = z["absent_tp"], z["absent_fp"], z["absent_fn"]
+    assert tp[1] + fp[1] + fn[1] == 0
+    assert olm.iou_from_counts(tp, fp, fn) >= 1.0 / 3.0
+
+
+# ---------------------------------------------------------------- G3: residual block semantics
+BLOCK_CFG = {
+    "b1": omodel.BlockSpec("b1", 8, 16, 2, stride=2, start_with_relu=False),
+    "b2": omodel.BlockSpec("b2", 16, 24, 2, stride=2),
+    "b3": omodel.BlockSpec("b3", 16, 24, 2, stride=2, is_last=True),
+    "mid": omodel.BlockSpec("mid", 24, 24, 3),
+    "b20": omodel.BlockSpec("b20", 24, 32, 2, stride=1, grow_first=False, is_last=True),
+}
+
+
+@pytest.mark.parametrize("name", list(BLOCK_CFG))
+def test_block_matches_reference(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, "block_kat.npz"))
+    blk = BLOCK_CFG[name]
+    sd = {}
+    for k in z.files:
+        if k.startswith(name + "_sd_"):
+            sd["p." + k[len(name) + 4:]] = torch.from_numpy(z[k]).clone()
+    for k in list(sd):
+        if not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            sd[k].requires_grad_(True)
+    x = torch.from_numpy(z[name + "_x"]).clone().requires_grad_(True)
+    ctx = omodel._Ctx(sd, training=True, update_stats=False)
+    y = ctx.block(blk, x, "p")
+    np.testing.assert_allclose(y.detach().numpy(), z[name + "_y"], rtol=1e-4, atol=2e-5)
+    y.backward(torch.from_numpy(z[name + "_go"]))
+    np.testing.assert_allclose(x.grad.numpy(), z[name + "_gx"], rtol=1e-4, atol=2e-5)
+    for k in z.files:
+        if k.startswith(name + "_grad_"):
+            pk = "p." + k[len(name) + 6:]
+            np.testing.assert_allclose(sd[pk].grad.numpy(), z[k], rtol=2e-4, atol=5e-5, err_msg=pk)
+    # the reference mutates the block input in place when the rep list starts with ReLU
+    expect = np.maximum(z[name + "_x"], 0) if blk.start_with_relu else z[name + "_x"]
+    np.testing.assert_array_equal(z[name + "_xin_after"], expect)
+
+
+# ---------------------------------------------------------------- G4: whole model, 64x96, three optimizer steps
+def _run_steps(kind, wd, nsteps, H, W):
+    sd = omodel.init_state(333)
+    keys = omodel.param_keys(sd)
+    params = [sd[k].requires_grad_(True) for k in keys]
+    opt = ooptim.OracleOptimizer([p.detach() for p in params], kind, lr=1e-3, eps=1e-8, weight_decay=wd)
+    # optimizer works on detached aliases of the same storage
+    x, y = make_inputs(2, H, W)
+    recs = []
+    for s in range(nsteps):
+        for p in params:
+            p.grad = None
+        out = omodel.forward(sd, x, training=True)
+        loss = olm.fp_loss(out, y, CLASS_W)
+        loss.backward()
+        pred = olm.argmax_first(out)
+        recs.append({"loss": float(loss.detach()), "iou": olm.compute_score(pred, y), "out": out.detach(),
+                     "grads": {k: p.grad.clone() for k, p in zip(keys, params)} if s == 0 else None})
+        opt.step([p.grad for p in params])
+    return recs, sd
+
+
+@pytest.mark.parametrize("tag,kind,wd", [("adam_wd1e-6", "Adam", 1e-6), ("adamw_wd1e-2", "AdamW", 1e-2)])
+def test_model_small_three_steps(golden_dir, tag, kind, wd):
+    g = _load(golden_dir, "model_small.json")
+    recs, sd = _run_steps(kind, wd, 3, g["H"], g["W"])
+    idx = np.array(g[tag]["sample_index"])
+    for s, (rec, ref) in enumerate(zip(recs, g[tag]["steps"])):
+        # step 0 is pure forward of identical weights: tight.  Later steps pass through Adam's
+        # 1/sqrt(v) amplification of fp32 rounding differences, hence looser.
+        tol = (2e-6, 2e-4, 1e-3)[s]
+        assert rec["loss"] == pytest.approx(ref["loss"], rel=tol), f"step {s}"
+        # IoU moves by ~1e-4 when a handful of near-tie pixels flip under fp32 re-association: north_star's 1e-3
+        # (steps >= 1 follow an Adam update, whose first step is lr*sign(g): rounding noise in tiny gradients
+        # becomes O(lr) weight changes, and at 12k pixels that moves IoU by a few 1e-3 even reference-vs-reference
+        # (compare the Adam and AdamW goldens); the loss stays within 2e-4.)
+        assert rec["iou"] == pytest.approx(ref["iou"], rel=(1e-3, 5e-3, 1e-2)[s]), f"step {s}"
+        if s == 0:
+            samples = rec["out"].flatten()[idx].numpy()
+            # fp32 re-association through 77 train-mode BNs moves single logits by ~2e-4 even CPU vs CPU;
+            # after an Adam step single logits are chaotic (O(0.1)) and only the loss is compared.
+            np.testing.assert_allclose(samples, np.array(ref["logit_samples"]), rtol=1e-3, atol=1e-3)
+    for k, ref in g[tag]["steps"][0]["grad_digest"].items():
+        d = digest(recs[0]["grads"][k])
+        assert d["abs"] == pytest.approx(ref["abs"], rel=2e-3), k
+    total = float(sum(v.double().abs().sum() for v in recs[0]["grads"].values()))
+    assert total == pytest.approx(g[tag]["steps"][0]["grad_total_abs"], rel=1e-3)
+    fin = g[tag]["final_state_digest"]
+    assert int(sd["xception_features.bn1.num_batches_tracked"]) == int(fin["xception_features.bn1.num_batches_tracked"]["sum"]) == 3
+    for k in ("xception_features.bn1.running_mean", "xception_features.bn1.running_var", "global_avg_pool.2.running_var"):
+        assert digest(sd[k])["abs"] == pytest.approx(fin[k]["abs"], rel=1e-2), k   # after 3 chaotic Adam steps
+
+
+def test_model_eval_b1_and_train_b1_raises(golden_dir):
+    g = _load(golden_dir, "model_small.json")
+    sd = omodel.init_state(333)
+    x, y = make_inputs(1, g["H"], g["W"], seed=g["eval_b1"]["seed"])
+    with torch.no_grad():
+        out = omodel.forward(sd, x, training=False)
+    idx = sample_index(out.numel())
+    np.testing.assert_allclose(out.flatten()[idx].numpy(), np.array(g["eval_b1"]["logit_samples"]), rtol=1e-4, atol=1e-5)
+    assert float(olm.fp_loss(out, y, CLASS_W)) == pytest.approx(g["eval_b1"]["loss"], rel=1e-5)
+    assert olm.compute_score(olm.argmax_first(out), y) == pytest.approx(g["eval_b1"]["iou"], rel=1e-5)
+    assert g["train_b1_raises"] is True
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        omodel.forward(sd, x, training=True)
+
+
+# ---------------------------------------------------------------- G5: LR schedule
+def test_multistep_lr(golden_dir):
+    g = _load(golden_dir, "lr_schedule.json")
+    ms, gamma = ooptim.parse_lr_schedule(g["arg"])
+    assert (ms, gamma) == ([3, 6], 0.1)
+    for start in (0, 4):
+        sched = ooptim.MultiStepSchedule(1e-3, ms, gamma, last_step=start)
+        seq = []
+        for _ in range(8):
+            seq.append(sched.get_last_lr())
+            sched.step()
+        np.testing.assert_allclose(seq, g[f"start{start}"], rtol=1e-12)
+    assert g["bad_type_raises"]
+    with pytest.raises(ValueError, match="not supported"):
+        ooptim.parse_lr_schedule({"type": "cosine"})
+
+
+@pytest.mark.parametrize("kind,wd", [("Adam", 1e-6), ("AdamW", 1e-2)])
+def test_adam_restatement_matches_torch_optim(kind, wd):
+    """The reference's optimizer IS torch.optim.Adam/AdamW (train_hdf5_ddp.py:213-216): same grads in, same weights out."""
+    torch.manual_seed(1)
+    shapes = [(33, 7, 3, 3), (128,), (5, 9)]
+    p_ref = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    p_mine = [p.detach().clone() for p in p_ref]
+    cls = torch.optim.Adam if kind == "Adam" else torch.optim.AdamW
+    ref = cls(p_ref, lr=1e-3, eps=1e-8, weight_decay=wd)
+    mine = ooptim.OracleOptimizer(p_mine, kind, lr=1e-3, eps=1e-8, weight_decay=wd)
+    for step in range(5):
+        grads = [torch.randn(s) * (10.0 ** (step - 2)) for s in shapes]
+        for p, g in zip(p_ref, grads):
+            p.grad = g.clone()
+        ref.step()
+        mine.step(grads)
+        for a, b in zip(p_ref, p_mine):
+            np.testing.assert_allclose(b.numpy(), a.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_lamb_is_self_consistent():
+    """LAMB is parity-unpinned (apex absent): check the defining properties only."""
+    torch.manual_seed(0)
+    p = [torch.randn(64, 32), torch.zeros(16)]
+    g = [torch.randn(64, 32) * 10, torch.randn(16)]
+    before = [t.clone() for t in p]
+    opt = ooptim.OracleOptimizer(p, "LAMB", lr=1e-2, weight_decay=1e-2)
+    opt.step(g)
+    # trust ratio: ||delta|| == lr * ||w|| for a tensor with non-zero weight norm
+    delta = (p[0] - before[0]).norm()
+    assert float(delta) == pytest.approx(1e-2 * float(before[0].norm()), rel=1e-4)
+    # zero-norm weights fall back to ratio 1
+    assert float((p[1] - before[1]).abs().max()) > 0
+    with pytest.raises(NotImplementedError):
+        ooptim.OracleOptimizer(p, "SGD", lr=1e-2)
