@@ -1,0 +1,197 @@
+/* deepcam_hip.h -- C ABI of libdeepcam_hip.so: the MI355X (gfx950) kernels of the DeepCAM train step.
+ *
+ * The reference (azrael417/mlperf-deepcam) has no native code and no FFI: its hot path is the chain of
+ * PyTorch/cuDNN/apex operator calls made by src/deepCam/train_hdf5_ddp.py:345-371.  Each entry point below
+ * replaces one such operator call site (cited per function, paths relative to src/deepCam/), with plain
+ * pointers and sizes only.  The Python host (mlperf-deepcam_amd/) binds them with ctypes; INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers unless a parameter says "host".  `stream` is a hipStream_t.
+ *   - Activations are channels-last: element (n,h,w,c) of a view lives at ptr[((n*H+h)*W+w)*ld + c];
+ *     `ld` >= C lets a view be a channel slice of a wider buffer (this is how torch.cat disappears).
+ *     ptr and ld*sizeof(elem) must be 16-byte aligned; C must be a multiple of 8 (true for every layer).
+ *   - `dtype` selects the storage type of activations, activation gradients and packed GEMM weights:
+ *     DC_BF16 (MFMA v_mfma_f32_16x16x32_bf16, fp32 accumulate) or DC_F32 (v_mfma_f32_16x16x4_f32, exact fp32).
+ *     Master weights, gradients of weights, BN statistics, the loss and the optimizer state are always fp32.
+ *   - Every function returns 0 on success.  On failure it returns non-zero and dc_last_error() describes it
+ *     (bad shape/alignment => nothing was launched).  No function synchronises, allocates or frees.
+ */
+#ifndef DEEPCAM_HIP_H_
+#define DEEPCAM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DC_F32 = 0, DC_BF16 = 1 };
+enum { DC_ADAM = 0, DC_ADAMW = 1, DC_LAMB = 2 };
+
+const char* dc_last_error(void);
+int dc_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense convolution family: nn.Conv2d (k=1 or 3, stride 1|2, dilation, zero padding) and
+ * nn.ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1), all lowered to one gather-form
+ * implicit GEMM on MFMA.  Reference call sites: architecture/deeplab_xception.py:60,65 (pointwise),
+ * :74 (skip), :149 (conv2), :291-292 (ASPP, atrous), :426,430,434 (1x1), :352-374 (decoder convs and
+ * transposed convs).  Backward entry points replace what autograd dispatches at train_hdf5_ddp.py:363.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int dtype;      /* DC_F32 | DC_BF16 */
+  int k;          /* 1 or 3 */
+  int stride;     /* 1 or 2 */
+  int pad;
+  int dil;
+  int transposed; /* 1: ConvTranspose2d k3 s2 p1 op1 (stride/pad/dil fields ignored) */
+  int cin;
+  int cout;
+} dc_conv_desc;
+
+/* Output extent of the forward op for an Hi x Wi input. */
+int dc_conv_out_hw(const dc_conv_desc* d, int Hi, int Wi, int* Ho, int* Wo);
+
+/* Pack the fp32 master weight (PyTorch layout: [cout][cin][k][k], or [cin][cout][k][k] when transposed)
+ * into the two GEMM operand layouts, both in `dtype`:  wf[tap][cout][cin] (forward) and
+ * wb[tap][cin][cout] (data gradient).  Either output may be NULL. */
+int dc_conv_pack_weights(const dc_conv_desc* d, const float* master, void* wf, void* wb, void* stream);
+
+/* Rows of the per-tile BatchNorm partial-statistics slab that dc_conv_fwd writes when stat_slab != NULL:
+ * slab is float[2][rows][cout] (sum, sum of squares of the STORED outputs). */
+int dc_conv_stat_rows(const dc_conv_desc* d, int N, int Hi, int Wi);
+
+/* y = conv(x, w) [+ bias];  accumulate != 0 adds into the existing y instead of overwriting. */
+int dc_conv_fwd(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,
+                const float* bias, void* y, int ldy, float* stat_slab, int accumulate, void* stream);
+
+/* dx = conv_backward_data(dy, w).  Hi, Wi are the FORWARD input extents (= extents of dx). */
+int dc_conv_dgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb,
+                  void* dx, int lddx, int accumulate, void* stream);
+
+/* grad_w (fp32, PyTorch master layout) = conv_backward_weight(x, dy).  Split over the pixel axis into fp32
+ * partial slabs in `workspace` (dc_conv_wgrad_workspace bytes), then reduced deterministically. */
+size_t dc_conv_wgrad_workspace(const dc_conv_desc* d, int N, int Hi, int Wi);
+int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* dy,
+                  int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream);
+
+/* grad_bias[c] = sum over M rows of dy (the one biased conv, deeplab_xception.py:366). */
+int dc_colsum(int dtype, long M, int C, const void* dy, int lddy, float* out, void* workspace, void* stream);
+size_t dc_colsum_workspace(long M, int C);
+
+/* ------------------------------------------------------------------------------------------------
+ * Depthwise 3x3 ("SeparableConv2d_same.conv1" after fixed_padding): deeplab_xception.py:45-51,58-59,63-64.
+ * Zero padding of `dil` on every side is implicit.  Weights: fp32 master [C][1][3][3] used directly.
+ * ------------------------------------------------------------------------------------------------ */
+int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
+                  const float* w, void* y, int ldy, void* stream);
+/* dx = dw_backward_data(dy) [+ addend]  (addend: same shape as dx, e.g. the residual branch's gradient) */
+int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                    const float* w, const void* addend, int ldadd, void* dx, int lddx, void* stream);
+size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int stride);
+int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
+                    const void* dy, int lddy, void* workspace, float* grad_w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d (train and eval) fused with ReLU and the residual add: deeplab_xception.py:86,92,97,
+ * 146-147,150,180-186,293-302,353-371,427,431,435 and the `x += skip` at :120.
+ * Statistics are fp32 per-tile partials combined in fp64.
+ * ------------------------------------------------------------------------------------------------ */
+int dc_bn_stat_rows(long M);
+int dc_bn_stats(int dtype, long M, int C, const void* x, int ldx, float* slab, void* stream);
+/* slab[2][rows][C] -> batch mean / biased var -> scale = gamma*rsqrt(var+eps), shift = beta - mean*scale;
+ * running_mean/var (momentum, unbiased var) and num_batches_tracked (int64) are updated when non-NULL. */
+int dc_bn_finalize(int C, long count, const float* slab, int rows, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                   float eps, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+/* eval mode: scale/shift from the running statistics */
+int dc_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* out = act(y*scale + shift [+ residual]),  act = ReLU when relu != 0 */
+int dc_bn_apply(int dtype, long M, int C, const void* y, int ldy, const float* scale, const float* shift,
+                const void* residual, int ldr, int relu, void* out, int ldo, void* stream);
+/* backward, step 1: g = dout * (out > 0 if relu), partial sums of g and g*xhat -> slab[2][rows][C] */
+int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int lddo, const void* y, int ldy,
+                     const void* out, int ldout, int relu, const float* save_mean, const float* save_invstd,
+                     float* slab, void* stream);
+/* step 2: dgamma, dbeta (fp32, written to the gradient arena) */
+int dc_bn_bwd_finalize(int C, const float* slab, int rows, float* dgamma, float* dbeta, void* stream);
+/* step 3: dy = gamma*invstd*(g - dbeta/count - xhat*dgamma/count);  g is also stored when g_out != NULL */
+int dc_bn_bwd_apply(int dtype, long M, int C, long count, const void* dout, int lddo, const void* y, int ldy,
+                    const void* out, int ldout, int relu, const float* gamma, const float* save_mean,
+                    const float* save_invstd, const float* dgamma, const float* dbeta, void* dy, int lddy,
+                    void* g_out, int ldg, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Entry stem: Conv2d(16->32, k3, s2, p1) reading the caller's NCHW fp32 batch directly
+ * (deeplab_xception.py:145,197).  Output NHWC `dtype`.  Also writes the BN partial-statistics slab.
+ * ------------------------------------------------------------------------------------------------ */
+int dc_stem_stat_rows(int N, int H, int W);
+int dc_stem_fwd(int dtype, int N, int Cin, int H, int W, const float* x_nchw, const float* w /*[32][Cin][3][3]*/,
+                void* y, int ldy, float* stat_slab, void* stream);
+size_t dc_stem_wgrad_workspace(int N, int Cin, int H, int W);
+int dc_stem_wgrad(int dtype, int N, int Cin, int H, int W, const float* x_nchw, const void* dy, int lddy,
+                  void* workspace, float* grad_w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Classifier head: ConvTranspose2d(256->n_classes=3, k3, s2, p1, op1), deeplab_xception.py:374,382.
+ * Reads NHWC `dtype`, writes the NCHW fp32 logits the reference API returns.
+ * ------------------------------------------------------------------------------------------------ */
+int dc_head_fwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx,
+                const float* w /*[Cin][3][3][3]*/, float* logits_nchw, void* stream);
+int dc_head_dgrad(int dtype, int N, int Cin, int Hi, int Wi, const float* dlogits_nchw, const float* w,
+                  void* dx, int lddx, void* stream);
+size_t dc_head_wgrad_workspace(int N, int Cin, int Hi, int Wi);
+int dc_head_wgrad(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
+                  void* workspace, float* grad_w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss and metric: utils/losses.py:28-52 (fp_loss == plain mean of weighted CE), torch.max(.,1)[1]
+ * (train_hdf5_ddp.py:406,458) and utils/utils.py:32-60 (compute_score) in one pass over the logits.
+ *   loss_sum   double[1]   += sum over pixels of w[y]*(lse - logit[y])          (caller zeroes, divides)
+ *   dlogits    fp32 NCHW   = w[y]*(softmax - onehot)*grad_scale                 (NULL to skip)
+ *   pred       int64 [B,H,W] first-max argmax                                   (NULL to skip)
+ *   counts     int64[9]    += tp[3], fp[3], fn[3]                               (NULL to skip)
+ * label_dtype_bytes: 1 (uint8), 4 (int32) or 8 (int64) labels.
+ * ------------------------------------------------------------------------------------------------ */
+int dc_wce_fused(int B, int H, int W, const float* logits_nchw, const void* labels, int label_dtype_bytes,
+                 const float* class_weights /*device float[3]*/, float grad_scale, double* loss_sum,
+                 float* dlogits, int64_t* pred, int64_t* counts, void* stream);
+/* compute_score on existing prediction / label maps (int64), counts int64[9] += */
+int dc_confusion_counts(long n, const int64_t* pred, const void* labels, int label_dtype_bytes, int64_t* counts,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Image-pool branch helpers (deeplab_xception.py:425,449-450): AdaptiveAvgPool2d((1,1)), the 1x1 ->
+ * HxW "bilinear" broadcast and their backward passes.
+ * ------------------------------------------------------------------------------------------------ */
+int dc_avgpool_fwd(int dtype, int N, int HW, int C, const void* x, int ldx, void* out /*[N][C]*/, void* stream);
+/* dx[n,p,c] += g[n,c] / HW */
+int dc_avgpool_bwd_add(int dtype, int N, int HW, int C, const void* g, void* dx, int lddx, void* stream);
+/* out[n,p,c] = v[n,c] */
+int dc_broadcast_hw(int dtype, int N, int HW, int C, const void* v, void* out, int ldo, void* stream);
+/* g[n,c] = sum_p dout[n,p,c] */
+int dc_sum_hw(int dtype, int N, int HW, int C, const void* dout, int lddo, void* g, void* stream);
+/* dst = src (NHWC view copy, e.g. gradient slices) */
+int dc_copy_view(int dtype, long M, int C, const void* src, int lds, void* dst, int ldd, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizers over one flat fp32 arena: torch.optim.Adam / AdamW (train_hdf5_ddp.py:213-216) and LAMB
+ * (apex FusedLAMB, :218; this project's own definition).  `step` is the 1-based step count.
+ * `lr` is read from a device float so that a captured hipGraph follows the LR schedule.
+ * ------------------------------------------------------------------------------------------------ */
+int dc_adam_step(int kind, long n, float* p, const float* g, float* m, float* v, const float* lr_dev,
+                 float beta1, float beta2, float eps, float weight_decay, const int* step_dev, float grad_scale,
+                 void* stream);
+/* LAMB: tensor t occupies [offsets[t], offsets[t+1]) of the arena (device int64[ntensors+1]).
+ * workspace: float[2*ntensors + 2] */
+int dc_lamb_step(int ntensors, const int64_t* offsets_dev, long n, float* p, const float* g, float* m, float* v,
+                 const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                 const int* step_dev, float max_grad_norm, float grad_scale, float* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPCAM_HIP_H_ */

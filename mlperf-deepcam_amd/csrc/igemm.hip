@@ -1,0 +1,389 @@
+// Gather-form implicit GEMM on MFMA for every dense convolution of DeepLabV3+/Xception (see conv_geom.h).
+//
+//   tile      128 output pixels x 128 output channels per 256-thread workgroup (4 waves, 2x2, 64x64 each)
+//   K loop    taps (outer) x input-channel chunks of 128 bytes (64 bf16 / 32 f32), register-staged and
+//             double-buffered in LDS, one barrier per step
+//   LDS       rows of 128 B, 16-B slots XOR-swizzled by (row>>1)&7 -> conflict-free ds_read_b128 fragments
+//   MFMA      A operand = weight rows (output channel), B operand = pixel rows, so each lane ends up with
+//             4 consecutive output channels of one pixel -> 8/16-byte LDS writes in the epilogue
+//   epilogue  accumulators -> LDS C tile -> fully coalesced 16-B NHWC stores; optional bias, optional
+//             read-modify-write accumulate, optional per-channel sum / sum-of-squares partials of the STORED
+//             values for the following train-mode BatchNorm (deterministic slab, no atomics)
+#include "conv_geom.h"
+
+namespace dc {
+
+struct IgemmParams {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* bias;
+  float* slab;
+  GatherGeom g;
+  int N, ldx, ldy;
+  int M;       // pixels per phase = N*Qh*Qw
+  int mtiles;  // tiles per phase
+  int accumulate;
+};
+
+constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per LDS row
+constexpr int OPER_BYTES = BM * ROWB;          // 16 KiB per operand tile
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<bf16> {
+  __device__ static inline void run(const vec16& a, const vec16& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<float> {
+  // a 16-byte fragment holds k = 4g..4g+3 of lane group g; MFMA j consumes element j of every lane,
+  // i.e. the k-set {4g+j}: the same permutation on both operands, so the sum over k is unchanged.
+  __device__ static inline void run(const vec16& a, const vec16& b, f32x4& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w[j]), __uint_as_float(b.w[j]), c, 0, 0, 0);
+  }
+};
+
+__device__ inline int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+  constexpr int KPV = Elem<T>::kPerVec;      // elements per 16 B
+  constexpr int BK = ROWB / (int)sizeof(T);  // K elements per step
+  constexpr int CROW = BN * (int)sizeof(T) + 16;  // padded C-tile row
+  // all LDS lives in the one dynamic array (keeps its base 16-byte aligned); the tap list sits behind the tiles
+  constexpr int MAIN_BYTES = (4 * OPER_BYTES) > (BM * CROW) ? (4 * OPER_BYTES) : (BM * CROW);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_tap = reinterpret_cast<int*>(smem + MAIN_BYTES);
+  int& s_ntap = s_tap[27];
+
+  const GatherGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+  const int phase = blockIdx.z;
+  const int py = phase / g.os, px = phase % g.os;
+
+  if (tid == 0) {
+    int c = 0;
+    for (int t = 0; t < g.ntaps; ++t)
+      if (g.taps[t].phase == phase) {
+        s_tap[3 * c] = g.taps[t].dy;
+        s_tap[3 * c + 1] = g.taps[t].dx;
+        s_tap[3 * c + 2] = g.taps[t].widx;
+        ++c;
+      }
+    s_ntap = c;
+  }
+  __syncthreads();
+  const int ntap = s_ntap;
+  const int kchunks = (g.Cin + BK - 1) / BK;
+  const int steps = ntap * kchunks;
+  if (steps == 0 && p.accumulate) return;  // a phase without taps contributes zeros
+
+  // ---- per-thread load bookkeeping: 4 rows of each operand, one 16-byte slot -------------------------
+  const int slot = tid & 7;
+  int rowbase[4];   // ((n*Hin + iy0)*Win + ix0) is not enough (taps move iy/ix): keep n, iy0, ix0
+  int riy[4], rix[4];
+  bool rok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (tid >> 3) + 32 * i;
+    const int m = m0 + r;
+    rok[i] = m < p.M;
+    const int mm = rok[i] ? m : 0;
+    const int n = mm / (g.Qh * g.Qw);
+    const int rem = mm - n * (g.Qh * g.Qw);
+    const int qy = rem / g.Qw, qx = rem - qy * g.Qw;
+    rowbase[i] = n * g.Hin;
+    riy[i] = qy * g.is;
+    rix[i] = qx * g.is;
+  }
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+
+  vec16 ra[4], rb[4];
+  auto load_step = [&](int tapi, int kc) {
+    const int dy = s_tap[3 * tapi], dx = s_tap[3 * tapi + 1], widx = s_tap[3 * tapi + 2];
+    const int kofs = kc * BK + slot * KPV;
+    const bool kok = kofs < g.Cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int iy = riy[i] + dy, ix = rix[i] + dx;
+      const bool ok = kok && rok[i] && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+      if (ok) {
+        const size_t off = ((size_t)(rowbase[i] + iy) * g.Win + ix) * p.ldx + kofs;
+        rb[i] = ldg16(xg + off);
+      } else {
+        rb[i] = zero16();
+      }
+      const int ch = n0 + (tid >> 3) + 32 * i;
+      if (kok && ch < g.Cout) {
+        const size_t off = ((size_t)widx * g.Cout + ch) * g.Cin + kofs;
+        ra[i] = ldg16(wg + off);
+      } else {
+        ra[i] = zero16();
+      }
+    }
+  };
+  auto store_step = [&](int buf) {
+    char* wa = smem + buf * (2 * OPER_BYTES);
+    char* xb = wa + OPER_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (tid >> 3) + 32 * i;
+      const int o = swz(r, slot);
+      *reinterpret_cast<vec16*>(wa + o) = ra[i];
+      *reinterpret_cast<vec16*>(xb + o) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];  // [channel rep][pixel rep]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wn = wave & 1, wm = wave >> 1;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  if (steps > 0) {
+    load_step(0, 0);
+    store_step(0);
+  }
+  __syncthreads();
+  int tapi = 0, kc = 0;
+  for (int s = 0; s < steps; ++s) {
+    int ntapi = tapi, nkc = kc + 1;
+    if (nkc == kchunks) {
+      nkc = 0;
+      ++ntapi;
+    }
+    const bool more = (s + 1) < steps;
+    if (more) load_step(ntapi, nkc);
+    const char* wa = smem + (s & 1) * (2 * OPER_BYTES);
+    const char* xb = wa + OPER_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      vec16 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra_ = wn * 64 + i * 16 + fr;
+        fa[i] = *reinterpret_cast<const vec16*>(wa + swz(ra_, kk * 4 + fg));
+        const int rb_ = wm * 64 + i * 16 + fr;
+        fb[i] = *reinterpret_cast<const vec16*>(xb + swz(rb_, kk * 4 + fg));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+    if (more) store_step((s + 1) & 1);
+    __syncthreads();
+    tapi = ntapi;
+    kc = nkc;
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------
+  char* ct = smem;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int chl = wn * 64 + i * 16 + fg * 4;  // first of this lane's 4 channels, tile-local
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n0 + chl + r < g.Cout) b4[r] = p.bias[n0 + chl + r];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int prow = wm * 64 + j * 16 + fr;
+      T* dst = reinterpret_cast<T*>(ct + prow * CROW) + chl;
+      if constexpr (sizeof(T) == 4) {
+        f32x4 v = acc[i][j];
+        v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+        uint2 v;
+        v.x = pack2_bf16(acc[i][j][0] + b4[0], acc[i][j][1] + b4[1]);
+        v.y = pack2_bf16(acc[i][j][2] + b4[2], acc[i][j][3] + b4[3]);
+        *reinterpret_cast<uint2*>(dst) = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  constexpr int GPR = BN * (int)sizeof(T) / 16;  // 16-byte groups per C row: 16 (bf16) / 32 (f32)
+  constexpr int RPP = 256 / GPR;                 // rows covered per pass: 16 / 8
+  constexpr int PASSES = BM / RPP;               // 8 / 16
+  const int grp = tid % GPR, rsub = tid / GPR;
+  const int ch0 = n0 + grp * KPV;
+  const bool chok = ch0 < g.Cout;
+  float ssum[KPV], ssq[KPV];
+#pragma unroll
+  for (int e = 0; e < KPV; ++e) ssum[e] = ssq[e] = 0.f;
+  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+#pragma unroll 2
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int row = rsub + ps * RPP;
+    const int m = m0 + row;
+    if (m < p.M && chok) {
+      const int n = m / (g.Qh * g.Qw);
+      const int rem = m - n * (g.Qh * g.Qw);
+      const int qy = rem / g.Qw, qx = rem - qy * g.Qw;
+      const int oy = qy * g.os + py, ox = qx * g.os + px;
+      T* dst = yg + ((size_t)(n * g.Hout + oy) * g.Wout + ox) * p.ldy + ch0;
+      vec16 v = *reinterpret_cast<const vec16*>(ct + row * CROW + grp * 16);
+      float f[KPV];
+      unpack(v, f, T());
+      if (p.accumulate) {
+        float o[KPV];
+        unpack(ldg16(dst), o, T());
+#pragma unroll
+        for (int e = 0; e < KPV; ++e) f[e] += o[e];
+        pack(v, f, T());
+        unpack(v, f, T());
+      }
+      stg16(dst, v);
+#pragma unroll
+      for (int e = 0; e < KPV; ++e) {
+        ssum[e] += f[e];
+        ssq[e] += f[e] * f[e];
+      }
+    }
+  }
+  if (p.slab != nullptr) {
+    __syncthreads();  // everyone is done reading the C tile
+    float* red = reinterpret_cast<float*>(smem);  // [2][RPP][BN]
+#pragma unroll
+    for (int e = 0; e < KPV; ++e) {
+      red[(0 * RPP + rsub) * BN + grp * KPV + e] = ssum[e];
+      red[(1 * RPP + rsub) * BN + grp * KPV + e] = ssq[e];
+    }
+    __syncthreads();
+    const int which = tid >> 7, c = tid & 127;
+    if (n0 + c < g.Cout) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < RPP; ++r) a += red[(which * RPP + r) * BN + c];
+      const int rows = p.mtiles * g.os * g.os;
+      const int srow = phase * p.mtiles + blockIdx.y;
+      p.slab[((size_t)which * rows + srow) * g.Cout + n0 + c] = a;
+    }
+  }
+}
+
+template <typename T>
+static int launch_igemm(const IgemmParams& p, hipStream_t st) {
+  constexpr int CROW = BN * (int)sizeof(T) + 16;
+  const size_t lds = ((size_t)(4 * OPER_BYTES) > (size_t)BM * CROW ? (size_t)(4 * OPER_BYTES) : (size_t)BM * CROW) + 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(p.g.Cout, BN), p.mtiles, p.g.os * p.g.os);
+  hipLaunchKernelGGL(igemm_kernel<T>, grid, dim3(256), lds, st, p);
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+static int check_view(const void* ptr, int ld, int c, int dtype, const char* what) {
+  return dc_check_view(ptr, ld, c, dtype, what);
+}
+
+static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int Wi, const void* in, int ldin,
+                      const void* w, const float* bias, void* out, int ldout, float* slab, int accumulate,
+                      void* stream) {
+  DC_REQUIRE(d != nullptr, "dc_conv: null descriptor");
+  DC_REQUIRE(d->dtype == DC_F32 || d->dtype == DC_BF16, "dc_conv: bad dtype");
+  DC_REQUIRE(d->transposed || d->k == 1 || d->k == 3, "dc_conv: kernel size must be 1 or 3");
+  DC_REQUIRE(d->transposed || d->stride == 1 || d->stride == 2, "dc_conv: stride must be 1 or 2");
+  DC_REQUIRE(N > 0 && Hi > 0 && Wi > 0, "dc_conv: empty input");
+  IgemmParams p;
+  if (!build_geom(*d, Hi, Wi, mode, &p.g)) return dc_fail("dc_conv: odd extent under a stride-2 phase split", __FILE__, __LINE__);
+  if (int e = check_view(in, ldin, p.g.Cin, d->dtype, "dc_conv input")) return e;
+  if (int e = check_view(out, ldout, p.g.Cout, d->dtype, "dc_conv output")) return e;
+  DC_REQUIRE(w != nullptr && ((uintptr_t)w & 15) == 0, "dc_conv: weights null or unaligned");
+  DC_REQUIRE(!(slab != nullptr && accumulate), "dc_conv: statistics and accumulate are exclusive");
+  p.x = in; p.w = w; p.y = out; p.bias = bias; p.slab = slab;
+  p.N = N; p.ldx = ldin; p.ldy = ldout;
+  const long M = (long)N * p.g.Qh * p.g.Qw;
+  DC_REQUIRE(M < (1L << 31) - BM, "dc_conv: too many pixels for 32-bit indexing");
+  p.M = (int)M;
+  p.mtiles = cdiv(M, BM);
+  p.accumulate = accumulate;
+  hipStream_t st = (hipStream_t)stream;
+  return d->dtype == DC_BF16 ? launch_igemm<bf16>(p, st) : launch_igemm<float>(p, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight packing: fp32 master (PyTorch layout) -> wf[tap][cout][cin], wb[tap][cin][cout] in T
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ master, T* __restrict__ wf, T* __restrict__ wb,
+                                    int cin, int cout, int taps, int transposed) {
+  const long total = (long)cin * cout * taps;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // i enumerates the master layout
+    const int t = (int)(i % taps);
+    const long r = i / taps;
+    int co, ci;
+    if (transposed) {  // [cin][cout][t]
+      co = (int)(r % cout);
+      ci = (int)(r / cout);
+    } else {           // [cout][cin][t]
+      ci = (int)(r % cin);
+      co = (int)(r / cin);
+    }
+    const float v = master[i];
+    if (wf) Elem<T>::store(wf + ((size_t)t * cout + co) * cin + ci, v);
+    if (wb) Elem<T>::store(wb + ((size_t)t * cin + ci) * cout + co, v);
+  }
+}
+
+}  // namespace dc
+
+using namespace dc;
+
+extern "C" int dc_conv_out_hw(const dc_conv_desc* d, int Hi, int Wi, int* Ho, int* Wo) {
+  DC_REQUIRE(d != nullptr, "dc_conv_out_hw: null descriptor");
+  GatherGeom g;
+  if (!build_geom(*d, Hi, Wi, kFwd, &g)) return dc_fail("dc_conv_out_hw: unsupported geometry", __FILE__, __LINE__);
+  if (Ho) *Ho = g.Hout;
+  if (Wo) *Wo = g.Wout;
+  return 0;
+}
+
+extern "C" int dc_conv_stat_rows(const dc_conv_desc* d, int N, int Hi, int Wi) {
+  GatherGeom g;
+  if (d == nullptr || !build_geom(*d, Hi, Wi, kFwd, &g)) return -1;
+  return cdiv((long)N * g.Qh * g.Qw, BM) * g.os * g.os;
+}
+
+extern "C" int dc_conv_fwd(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,
+                           const float* bias, void* y, int ldy, float* stat_slab, int accumulate, void* stream) {
+  return run_gather(d, kFwd, N, Hi, Wi, x, ldx, wf, bias, y, ldy, stat_slab, accumulate, stream);
+}
+
+extern "C" int dc_conv_dgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy,
+                             const void* wb, void* dx, int lddx, int accumulate, void* stream) {
+  return run_gather(d, kDgrad, N, Hi, Wi, dy, lddy, wb, nullptr, dx, lddx, nullptr, accumulate, stream);
+}
+
+extern "C" int dc_conv_pack_weights(const dc_conv_desc* d, const float* master, void* wf, void* wb, void* stream) {
+  DC_REQUIRE(d != nullptr && master != nullptr, "dc_conv_pack_weights: null argument");
+  const int k = d->transposed ? 3 : d->k;
+  const long total = (long)d->cin * d->cout * k * k;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == DC_BF16)
+    hipLaunchKernelGGL(pack_weights_kernel<bf16>, dim3(blocks), dim3(256), 0, st, master, (bf16*)wf, (bf16*)wb, d->cin, d->cout, k * k, d->transposed);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, master, (float*)wf, (float*)wb, d->cin, d->cout, k * k, d->transposed);
+  DC_CHECK_LAUNCH();
+  return 0;
+}

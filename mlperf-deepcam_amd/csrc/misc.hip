@@ -1,0 +1,292 @@
+// Image-pool branch helpers and the optimizers: all HBM-bound streaming kernels.
+#include "common.h"
+
+namespace dc {
+
+// out[n][c] = scale * sum_p x[n,p,c]     (AdaptiveAvgPool2d((1,1)) with scale = 1/HW; its transpose with scale = 1)
+template <typename T>
+__global__ __launch_bounds__(256) void hw_reduce_kernel(int HW, int C, const T* __restrict__ x, int ldx, float scale,
+                                                        T* __restrict__ out) {
+  constexpr int KPV = Elem<T>::kPerVec;
+  __shared__ float red[16][16 * KPV];
+  const int cgl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c0 = (blockIdx.x * 16 + cgl) * KPV;
+  const int n = blockIdx.y;
+  float a[KPV];
+#pragma unroll
+  for (int e = 0; e < KPV; ++e) a[e] = 0.f;
+  if (c0 < C)
+    for (int p = rl; p < HW; p += 16) {
+      float f[KPV];
+      unpack(ldg16(x + ((size_t)n * HW + p) * ldx + c0), f, T());
+#pragma unroll
+      for (int e = 0; e < KPV; ++e) a[e] += f[e];
+    }
+#pragma unroll
+  for (int e = 0; e < KPV; ++e) red[rl][cgl * KPV + e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < 16 * KPV) {
+    const int c = blockIdx.x * 16 * KPV + threadIdx.x;
+    if (c < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += red[r][threadIdx.x];
+      Elem<T>::store(out + (size_t)n * C + c, s * scale);
+    }
+  }
+}
+
+// MODE 0: out[n,p,c]  = v[n,c]           (broadcast)
+// MODE 1: out[n,p,c] += v[n,c] * scale   (avg-pool backward, accumulating)
+// MODE 2: out[r,c]    = src[r,c]         (view copy; v is the source, HW rows per "n")
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void hw_ew_kernel(long rows, int HW, int C, const T* __restrict__ v, int ldv,
+                                                    float scale, T* __restrict__ out, int ldo) {
+  constexpr int KPV = Elem<T>::kPerVec;
+  const int ngroups = C / KPV;
+  const long total = rows * ngroups;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % ngroups);
+    const long r = i / ngroups;
+    const int c0 = cg * KPV;
+    if (MODE == 2) {
+      stg16(out + (size_t)r * ldo + c0, ldg16(v + (size_t)r * ldv + c0));
+    } else {
+      const long n = r / HW;
+      vec16 src = ldg16(v + (size_t)n * C + c0);
+      if (MODE == 1) {
+        float a[KPV], b[KPV];
+        unpack(src, a, T());
+        unpack(ldg16(out + (size_t)r * ldo + c0), b, T());
+#pragma unroll
+        for (int e = 0; e < KPV; ++e) b[e] = fmaf(a[e], scale, b[e]);
+        pack(src, b, T());
+      }
+      stg16(out + (size_t)r * ldo + c0, src);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ optimizers
+// torch.optim.Adam / AdamW single-tensor algorithm over the flat arena.
+__global__ __launch_bounds__(256) void adam_kernel(int kind, long n, float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, const float* lr_dev,
+                                                   float beta1, float beta2, float eps, float wd, const int* step_dev,
+                                                   float grad_scale) {
+  const float lr = *lr_dev;
+  const int step = *step_dev;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pa = &pp.x;
+    const float* ga = &gg.x;
+    float* ma = &mm.x;
+    float* va = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gr = ga[e] * grad_scale;
+      if (kind == DC_ADAM) gr = fmaf(wd, pa[e], gr);           // L2 penalty folded into the gradient
+      else pa[e] *= (1.f - lr * wd);                            // decoupled decay
+      ma[e] = ma[e] + (gr - ma[e]) * (1.f - beta1);             // lerp_
+      va[e] = va[e] * beta2 + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(va[e]) * inv_sqrt_bc2 + eps;
+      pa[e] = pa[e] - step_size * (ma[e] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  // tail (n not a multiple of 4)
+  const long tail0 = n4 << 2;
+  const long ti = tail0 + blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (ti < n) {
+    float gr = g[ti] * grad_scale;
+    float pv = p[ti];
+    if (kind == DC_ADAM) gr = fmaf(wd, pv, gr);
+    else pv *= (1.f - lr * wd);
+    const float mv = m[ti] + (gr - m[ti]) * (1.f - beta1);
+    const float vv = v[ti] * beta2 + (1.f - beta2) * gr * gr;
+    m[ti] = mv;
+    v[ti] = vv;
+    p[ti] = pv - step_size * (mv / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* __restrict__ g, float scale, float* out) {
+  __shared__ float s[4];
+  float a = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float x = g[i] * scale;
+    a = fmaf(x, x, a);
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, s[0] + s[1] + s[2] + s[3]);
+}
+
+constexpr int LAMB_SLICES = 32;
+
+// stage 1: moments, update direction u (written over g), per-tensor ||w||^2 and ||u||^2
+__global__ __launch_bounds__(256) void lamb_stage1_kernel(const int64_t* __restrict__ offs, float* __restrict__ p,
+                                                          float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, float beta1, float beta2, float eps,
+                                                          float wd, const int* step_dev, float max_grad_norm,
+                                                          float grad_scale, float* ws) {
+  __shared__ float s[2][4];
+  const int t = blockIdx.x;
+  const long beg = offs[t], end = offs[t + 1];
+  const int step = *step_dev;
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  const float gnorm = sqrtf(ws[0]);
+  const float clip = gnorm > max_grad_norm ? gnorm / max_grad_norm : 1.f;
+  const float gs = grad_scale / clip;
+  float wn = 0.f, un = 0.f;
+  for (long i = beg + blockIdx.y * 256L + threadIdx.x; i < end; i += 256L * LAMB_SLICES) {
+    const float gr = g[i] * gs;
+    const float pv = p[i];
+    const float mv = m[i] + (gr - m[i]) * (1.f - beta1);
+    const float vv = v[i] * beta2 + (1.f - beta2) * gr * gr;
+    m[i] = mv;
+    v[i] = vv;
+    const float u = (mv / bc1) / (sqrtf(vv / bc2) + eps) + wd * pv;
+    g[i] = u;
+    wn = fmaf(pv, pv, wn);
+    un = fmaf(u, u, un);
+  }
+  wn = wave_sum(wn);
+  un = wave_sum(un);
+  if ((threadIdx.x & 63) == 0) {
+    s[0][threadIdx.x >> 6] = wn;
+    s[1][threadIdx.x >> 6] = un;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&ws[2 + 2 * t], s[0][0] + s[0][1] + s[0][2] + s[0][3]);
+    atomicAdd(&ws[3 + 2 * t], s[1][0] + s[1][1] + s[1][2] + s[1][3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void lamb_stage2_kernel(const int64_t* __restrict__ offs, float* __restrict__ p,
+                                                          const float* __restrict__ u, const float* lr_dev,
+                                                          const float* __restrict__ ws) {
+  const int t = blockIdx.x;
+  const long beg = offs[t], end = offs[t + 1];
+  const float wn = sqrtf(ws[2 + 2 * t]), un = sqrtf(ws[3 + 2 * t]);
+  const float ratio = (wn > 0.f && un > 0.f) ? wn / un : 1.f;
+  const float a = *lr_dev * ratio;
+  for (long i = beg + blockIdx.y * 256L + threadIdx.x; i < end; i += 256L * LAMB_SLICES) p[i] = fmaf(-a, u[i], p[i]);
+}
+
+static int ew_blocks2(long total) {
+  long b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace dc
+
+using namespace dc;
+
+#define DISPATCH_T(dtype, ...)                      \
+  do {                                              \
+    if ((dtype) == DC_BF16) { typedef bf16 T; __VA_ARGS__; } \
+    else { typedef float T; __VA_ARGS__; }          \
+  } while (0)
+
+extern "C" int dc_avgpool_fwd(int dtype, int N, int HW, int C, const void* x, int ldx, void* out, void* stream) {
+  if (int e = dc_check_view(x, ldx, C, dtype, "dc_avgpool_fwd x")) return e;
+  DC_REQUIRE(out && N > 0 && HW > 0, "dc_avgpool_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int kpv = dtype == DC_BF16 ? 8 : 4;
+  dim3 grid(cdiv(C / kpv, 16), N);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(hw_reduce_kernel<T>, grid, dim3(256), 0, st, HW, C, (const T*)x, ldx, 1.0f / (float)HW, (T*)out));
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dc_sum_hw(int dtype, int N, int HW, int C, const void* dout, int lddo, void* g, void* stream) {
+  if (int e = dc_check_view(dout, lddo, C, dtype, "dc_sum_hw dout")) return e;
+  DC_REQUIRE(g && N > 0 && HW > 0, "dc_sum_hw: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int kpv = dtype == DC_BF16 ? 8 : 4;
+  dim3 grid(cdiv(C / kpv, 16), N);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(hw_reduce_kernel<T>, grid, dim3(256), 0, st, HW, C, (const T*)dout, lddo, 1.0f, (T*)g));
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dc_broadcast_hw(int dtype, int N, int HW, int C, const void* v, void* out, int ldo, void* stream) {
+  if (int e = dc_check_view(out, ldo, C, dtype, "dc_broadcast_hw out")) return e;
+  DC_REQUIRE(v && N > 0 && HW > 0, "dc_broadcast_hw: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const long rows = (long)N * HW;
+  const int kpv = dtype == DC_BF16 ? 8 : 4;
+  const int blocks = ew_blocks2(rows * (C / kpv));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((hw_ew_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, rows, HW, C, (const T*)v, C, 1.f, (T*)out, ldo));
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dc_avgpool_bwd_add(int dtype, int N, int HW, int C, const void* g, void* dx, int lddx, void* stream) {
+  if (int e = dc_check_view(dx, lddx, C, dtype, "dc_avgpool_bwd_add dx")) return e;
+  DC_REQUIRE(g && N > 0 && HW > 0, "dc_avgpool_bwd_add: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const long rows = (long)N * HW;
+  const int kpv = dtype == DC_BF16 ? 8 : 4;
+  const int blocks = ew_blocks2(rows * (C / kpv));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((hw_ew_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, rows, HW, C, (const T*)g, C, 1.0f / (float)HW, (T*)dx, lddx));
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dc_copy_view(int dtype, long M, int C, const void* src, int lds, void* dst, int ldd, void* stream) {
+  if (int e = dc_check_view(src, lds, C, dtype, "dc_copy_view src")) return e;
+  if (int e = dc_check_view(dst, ldd, C, dtype, "dc_copy_view dst")) return e;
+  hipStream_t st = (hipStream_t)stream;
+  const int kpv = dtype == DC_BF16 ? 8 : 4;
+  const int blocks = ew_blocks2(M * (C / kpv));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((hw_ew_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, M, 1, C, (const T*)src, lds, 1.f, (T*)dst, ldd));
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dc_adam_step(int kind, long n, float* p, const float* g, float* m, float* v, const float* lr_dev,
+                            float beta1, float beta2, float eps, float weight_decay, const int* step_dev,
+                            float grad_scale, void* stream) {
+  DC_REQUIRE(kind == DC_ADAM || kind == DC_ADAMW, "dc_adam_step: kind must be DC_ADAM or DC_ADAMW");
+  DC_REQUIRE(p && g && m && v && lr_dev && step_dev && n > 0, "dc_adam_step: bad argument");
+  DC_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "dc_adam_step: arenas must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks2(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, kind, n, p, g, m, v, lr_dev,
+                     beta1, beta2, eps, weight_decay, step_dev, grad_scale);
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dc_lamb_step(int ntensors, const int64_t* offsets_dev, long n, float* p, const float* g, float* m,
+                            float* v, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                            const int* step_dev, float max_grad_norm, float grad_scale, float* workspace, void* stream) {
+  DC_REQUIRE(ntensors > 0 && offsets_dev && p && g && m && v && lr_dev && step_dev && workspace && n > 0, "dc_lamb_step: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(float) * (2 * (size_t)ntensors + 2), st);
+  if (e != hipSuccess) return dc_set_error(e, __FILE__, __LINE__);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, st, n, g, grad_scale, workspace);
+  DC_CHECK_LAUNCH();
+  // the update direction is staged in the gradient arena (it is dead after this step)
+  float* gw = const_cast<float*>(g);
+  hipLaunchKernelGGL(lamb_stage1_kernel, dim3(ntensors, LAMB_SLICES), dim3(256), 0, st, offsets_dev, p, gw, m, v, beta1, beta2,
+                     eps, weight_decay, step_dev, max_grad_norm, grad_scale, workspace);
+  DC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lamb_stage2_kernel, dim3(ntensors, LAMB_SLICES), dim3(256), 0, st, offsets_dev, p, gw, lr_dev, workspace);
+  DC_CHECK_LAUNCH();
+  return 0;
+}

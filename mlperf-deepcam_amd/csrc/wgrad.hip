@@ -1,0 +1,255 @@
+// Weight gradient of every dense convolution:  dW_t[co][ci] = sum over output pixels m of dy[m][co] * x[gather(m,t)][ci].
+//
+// A GEMM whose reduction axis is the PIXEL axis, i.e. the slow axis of both NHWC operands.  The bf16 MFMA wants
+// 8 consecutive reduction elements per lane, so the LDS tiles stay [pixel][channel] (coalesced global loads) and
+// fragments are fetched with the gfx950 transposed LDS read ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane
+// group, delivered channel-per-lane).  The f32 MFMA (16x16x4) takes ONE element per lane, so it reads the same
+// image with plain ds_read_b32.  The pixel axis is split across workgroups (split-K); partial 128x128 fp32 tiles
+// go to a slab with plain stores and a second kernel reduces them in a fixed order straight into the PyTorch
+// master layout of the gradient -- deterministic, no float atomics.
+#include "conv_geom.h"
+
+namespace dc {
+
+struct WgradParams {
+  const void* x;   // gathered operand (forward input), channels -> ci
+  const void* dy;  // output-side operand, channels -> co
+  float* slab;     // [splits][taps][Co][Ci]
+  GatherGeom g;    // forward geometry: Cin = ci extent, Cout = co extent
+  int N, ldx, lddy;
+  int M;           // pixels per phase
+  int splits;
+  int chunk;       // pixels per split (multiple of BP)
+};
+
+template <typename T>
+struct WgTraits;
+template <>
+struct WgTraits<bf16> {
+  static constexpr int BP = 64;            // pixels per step
+  static constexpr int ROW = 128 * 2 + 32; // padded LDS row bytes (conflict-free transposed reads)
+};
+template <>
+struct WgTraits<float> {
+  static constexpr int BP = 32;
+  static constexpr int ROW = 128 * 4 + 64;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  using TR = WgTraits<T>;
+  constexpr int KPV = Elem<T>::kPerVec;
+  constexpr int BP = TR::BP, ROW = TR::ROW;
+  constexpr int VPR = 128 * (int)sizeof(T) / 16;   // 16-byte vectors per tile row: 16 / 32
+  constexpr int TILE = BP * ROW;                   // bytes per operand tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const GatherGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ci0 = blockIdx.x * 128, co0 = blockIdx.y * 128;
+  const int tapi = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
+  const Tap tap = g.taps[tapi];
+  const int py = tap.phase / g.os, px = tap.phase % g.os;
+  const int mbeg = split * p.chunk;
+  const int mend = min(p.M, mbeg + p.chunk);
+  const int steps = mend > mbeg ? (mend - mbeg + BP - 1) / BP : 0;
+
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ dg = reinterpret_cast<const T*>(p.dy);
+
+  // each thread moves 4 vectors per operand per step: vector v = tid + 256*i -> (row = v / VPR, col = v % VPR)
+  vec16 rq[4], rp[4];
+  auto load_step = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = tid + 256 * i;
+      const int row = v / VPR, col = v % VPR;
+      const int m = mbeg + s * BP + row;
+      rq[i] = zero16();
+      rp[i] = zero16();
+      if (m < mend) {
+        const int n = m / (g.Qh * g.Qw);
+        const int rem = m - n * (g.Qh * g.Qw);
+        const int qy = rem / g.Qw, qx = rem - qy * g.Qw;
+        const int co = co0 + col * KPV;
+        if (co < g.Cout) {
+          const int oy = qy * g.os + py, ox = qx * g.os + px;
+          rq[i] = ldg16(dg + ((size_t)(n * g.Hout + oy) * g.Wout + ox) * p.lddy + co);
+        }
+        const int ci = ci0 + col * KPV;
+        const int iy = qy * g.is + tap.dy, ix = qx * g.is + tap.dx;
+        if (ci < g.Cin && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win)
+          rp[i] = ldg16(xg + ((size_t)(n * g.Hin + iy) * g.Win + ix) * p.ldx + ci);
+      }
+    }
+  };
+  auto store_step = [&](int buf) {
+    char* q = smem + buf * (2 * TILE);
+    char* pp = q + TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = tid + 256 * i;
+      const int row = v / VPR, col = v % VPR;
+      *reinterpret_cast<vec16*>(q + row * ROW + col * 16) = rq[i];
+      *reinterpret_cast<vec16*>(pp + row * ROW + col * 16) = rp[i];
+    }
+  };
+
+  f32x4 acc[4][4];  // [co rep][ci rep]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wq = wave >> 1, wp = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  if (steps > 0) {
+    load_step(0);
+    store_step(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    const bool more = (s + 1) < steps;
+    if (more) load_step(s + 1);
+    const char* q = smem + (s & 1) * (2 * TILE);
+    const char* pp = q + TILE;
+    if constexpr (sizeof(T) == 2) {
+      // two K=32 sub-steps; lane group fg owns pixels 8*fg .. 8*fg+7 of the sub-step
+      const int tq = (lane & 15) >> 2, tp = lane & 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int prow = ks * 32 + 8 * fg + tq;
+        vec16 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int cq = (wq * 64 + i * 16 + 4 * tp) * 2;
+          const int cp = (wp * 64 + i * 16 + 4 * tp) * 2;
+          typedef __attribute__((address_space(3))) short4v lds_s4;
+          const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(q + prow * ROW + cq));
+          const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(q + (prow + 4) * ROW + cq));
+          const short4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pp + prow * ROW + cp));
+          const short4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pp + (prow + 4) * ROW + cp));
+          uint2 t0 = __builtin_bit_cast(uint2, a0), t1 = __builtin_bit_cast(uint2, a1);
+          fa[i].w[0] = t0.x; fa[i].w[1] = t0.y; fa[i].w[2] = t1.x; fa[i].w[3] = t1.y;
+          t0 = __builtin_bit_cast(uint2, b0); t1 = __builtin_bit_cast(uint2, b1);
+          fb[i].w[0] = t0.x; fb[i].w[1] = t0.y; fb[i].w[2] = t1.x; fb[i].w[3] = t1.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // 8 sub-steps of 4 pixels: lane group fg owns pixel 4*ks + fg
+#pragma unroll
+      for (int ks = 0; ks < BP / 4; ++ks) {
+        const int prow = ks * 4 + fg;
+        float fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          fa[i] = *reinterpret_cast<const float*>(q + prow * ROW + (wq * 64 + i * 16 + fr) * 4);
+          fb[i] = *reinterpret_cast<const float*>(pp + prow * ROW + (wp * 64 + i * 16 + fr) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) store_step((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // D[row = co][col = ci]: lane holds co = (lane>>4)*4 + r, ci = lane&15 of each 16x16 tile
+  float* out = p.slab + ((size_t)split * g.ntaps + tap.widx) * g.Cout * g.Cin;  // widx: the master's (ky,kx) index
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + wq * 64 + i * 16 + fg * 4 + r;
+      if (co >= g.Cout) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + wp * 64 + j * 16 + fr;
+        if (ci < g.Cin) out[(size_t)co * g.Cin + ci] = acc[i][j][r];
+      }
+    }
+}
+
+// grad[master layout] = sum over splits of slab[split][tap][co][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int splits, int taps,
+                                    int Co, int Ci, int transposed) {
+  const long per = (long)Co * Ci;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i / Ci), ci = (int)(i % Ci);
+    const long base = transposed ? ((long)ci * Co + co) * taps : ((long)co * Ci + ci) * taps;
+    for (int t = 0; t < taps; ++t) {
+      float a = 0.f;
+      for (int s = 0; s < splits; ++s) a += slab[((size_t)s * taps + t) * per + i];
+      grad[base + t] = a;
+    }
+  }
+}
+
+static void plan_splits(const GatherGeom& g, long M, int BP, int* splits, int* chunk) {
+  const long tiles = (long)cdiv(g.Cin, 128) * cdiv(g.Cout, 128) * g.ntaps;
+  long want = (1024 + tiles - 1) / tiles;          // aim for ~1024 workgroups
+  const long maxs = (M + 2 * BP - 1) / (2 * BP);   // at least two steps per split
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 64) want = 64;
+  long c = (M + want - 1) / want;
+  c = (c + BP - 1) / BP * BP;
+  *chunk = (int)c;
+  *splits = (int)((M + c - 1) / c);
+}
+
+}  // namespace dc
+
+using namespace dc;
+
+extern "C" size_t dc_conv_wgrad_workspace(const dc_conv_desc* d, int N, int Hi, int Wi) {
+  GatherGeom g;
+  if (d == nullptr || !build_geom(*d, Hi, Wi, kFwd, &g)) return 0;
+  int splits, chunk;
+  plan_splits(g, (long)N * g.Qh * g.Qw, d->dtype == DC_BF16 ? 64 : 32, &splits, &chunk);
+  return (size_t)splits * g.ntaps * g.Cout * g.Cin * sizeof(float);
+}
+
+extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* dy,
+                             int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream) {
+  DC_REQUIRE(d != nullptr && grad_w != nullptr && workspace != nullptr, "dc_conv_wgrad: null argument");
+  WgradParams p;
+  if (!build_geom(*d, Hi, Wi, kFwd, &p.g)) return dc_fail("dc_conv_wgrad: unsupported geometry", __FILE__, __LINE__);
+  if (int e = dc_check_view(x, ldx, p.g.Cin, d->dtype, "dc_conv_wgrad x")) return e;
+  if (int e = dc_check_view(dy, lddy, p.g.Cout, d->dtype, "dc_conv_wgrad dy")) return e;
+  const long M = (long)N * p.g.Qh * p.g.Qw;
+  DC_REQUIRE(M < (1L << 31) - 256, "dc_conv_wgrad: too many pixels for 32-bit indexing");
+  const int BP = d->dtype == DC_BF16 ? 64 : 32;
+  plan_splits(p.g, M, BP, &p.splits, &p.chunk);
+  const size_t need = (size_t)p.splits * p.g.ntaps * p.g.Cout * p.g.Cin * sizeof(float);
+  DC_REQUIRE(workspace_bytes >= need, "dc_conv_wgrad: workspace too small");
+  p.x = x; p.dy = dy; p.slab = (float*)workspace;
+  p.N = N; p.ldx = ldx; p.lddy = lddy; p.M = (int)M;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv(p.g.Cin, 128), cdiv(p.g.Cout, 128), p.g.ntaps * p.splits);
+  DC_REQUIRE(grid.z <= 65535, "dc_conv_wgrad: grid.z overflow");
+  if (d->dtype == DC_BF16) {
+    const size_t lds = 4 * (size_t)WgTraits<bf16>::BP * WgTraits<bf16>::ROW;
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    hipLaunchKernelGGL(wgrad_kernel<bf16>, grid, dim3(256), lds, st, p);
+  } else {
+    const size_t lds = 4 * (size_t)WgTraits<float>::BP * WgTraits<float>::ROW;
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), lds, st, p);
+  }
+  DC_CHECK_LAUNCH();
+  const long per = (long)p.g.Cout * p.g.Cin;
+  const int blocks = (int)((per + 255) / 256 > 2048 ? 2048 : (per + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, grad_w, p.splits, p.g.ntaps, p.g.Cout, p.g.Cin, d->transposed);
+  DC_CHECK_LAUNCH();
+  return 0;
+}

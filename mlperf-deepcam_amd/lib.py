@@ -1,0 +1,140 @@
+"""ctypes binding of libdeepcam_hip.so (the C ABI declared in include/deepcam_hip.h).
+
+There is NO fallback: if the shared library is missing, ``load()`` raises.  Tensors cross the boundary as raw
+device pointers (``tensor.data_ptr()``) plus sizes; the HIP stream is torch's current stream handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdeepcam_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+DC_F32, DC_BF16 = 0, 1
+DC_ADAM, DC_ADAMW, DC_LAMB = 0, 1, 2
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("k", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("dil", C.c_int),
+                ("transposed", C.c_int), ("cin", C.c_int), ("cout", C.c_int)]
+
+
+P, I, L, F, SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+CD = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes).  Order and meaning of arguments: include/deepcam_hip.h.
+_SIGS = {
+    "dc_last_error": (C.c_char_p, []),
+    "dc_version": (I, []),
+    "dc_conv_out_hw": (I, [CD, I, I, C.POINTER(I), C.POINTER(I)]),
+    "dc_conv_pack_weights": (I, [CD, P, P, P, P]),
+    "dc_conv_stat_rows": (I, [CD, I, I, I]),
+    "dc_conv_fwd": (I, [CD, I, I, I, P, I, P, P, P, I, P, I, P]),
+    "dc_conv_dgrad": (I, [CD, I, I, I, P, I, P, P, I, I, P]),
+    "dc_conv_wgrad_workspace": (SZ, [CD, I, I, I]),
+    "dc_conv_wgrad": (I, [CD, I, I, I, P, I, P, I, P, SZ, P, P]),
+    "dc_colsum": (I, [I, L, I, P, I, P, P, P]),
+    "dc_colsum_workspace": (SZ, [L, I]),
+    "dc_dwconv_fwd": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P]),
+    "dc_dwconv_dgrad": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P]),
+    "dc_dwconv_wgrad_workspace": (SZ, [I, I, I, I, I]),
+    "dc_dwconv_wgrad": (I, [I, I, I, I, I, I, I, P, I, P, I, P, P, P]),
+    "dc_bn_stat_rows": (I, [L]),
+    "dc_bn_stats": (I, [I, L, I, P, I, P, P]),
+    "dc_bn_finalize": (I, [I, L, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),
+    "dc_bn_eval_coeffs": (I, [I, P, P, P, P, F, P, P, P]),
+    "dc_bn_apply": (I, [I, L, I, P, I, P, P, P, I, I, P, I, P]),
+    "dc_bn_bwd_reduce": (I, [I, L, I, P, I, P, I, P, I, I, P, P, P, P]),
+    "dc_bn_bwd_finalize": (I, [I, P, I, P, P, P]),
+    "dc_bn_bwd_apply": (I, [I, L, I, L, P, I, P, I, P, I, I, P, P, P, P, P, P, I, P, I, P]),
+    "dc_stem_stat_rows": (I, [I, I, I]),
+    "dc_stem_fwd": (I, [I, I, I, I, I, P, P, P, I, P, P]),
+    "dc_stem_wgrad_workspace": (SZ, [I, I, I, I]),
+    "dc_stem_wgrad": (I, [I, I, I, I, I, P, P, I, P, P, P]),
+    "dc_head_fwd": (I, [I, I, I, I, I, P, I, P, P, P]),
+    "dc_head_dgrad": (I, [I, I, I, I, I, P, P, P, I, P]),
+    "dc_head_wgrad_workspace": (SZ, [I, I, I, I]),
+    "dc_head_wgrad": (I, [I, I, I, I, I, P, I, P, P, P, P]),
+    "dc_wce_fused": (I, [I, I, I, P, P, I, P, F, P, P, P, P, P]),
+    "dc_confusion_counts": (I, [L, P, P, I, P, P]),
+    "dc_avgpool_fwd": (I, [I, I, I, I, P, I, P, P]),
+    "dc_avgpool_bwd_add": (I, [I, I, I, I, P, P, I, P]),
+    "dc_broadcast_hw": (I, [I, I, I, I, P, P, I, P]),
+    "dc_sum_hw": (I, [I, I, I, I, P, I, P, P]),
+    "dc_copy_view": (I, [I, L, I, P, I, P, I, P]),
+    "dc_adam_step": (I, [I, L, P, P, P, P, P, F, F, F, F, P, F, P]),
+    "dc_lamb_step": (I, [I, P, L, P, P, P, P, P, F, F, F, F, P, F, F, P, P]),
+}
+EXPORTS = sorted(_SIGS)
+
+_lib: Optional[C.CDLL] = None
+
+
+class DeepcamHipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/ into libdeepcam_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise DeepcamHipError("building libdeepcam_hip.so failed")
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DeepcamHipError(
+            f"{LIB_PATH} not found: the HIP library is the product, there is no fallback path. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C mlperf-deepcam_amd/csrc`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().dc_last_error().decode()
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise DeepcamHipError(last_error())
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point and raise on failure."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise DeepcamHipError(f"{name}: {last_error()}")
+
+
+def dtype_code(torch_dtype) -> int:
+    import torch
+    if torch_dtype == torch.float32:
+        return DC_F32
+    if torch_dtype == torch.bfloat16:
+        return DC_BF16
+    raise DeepcamHipError(f"unsupported activation dtype {torch_dtype}")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t) -> C.c_void_p:
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,451 @@
+"""Per-kernel parity: every C-ABI entry point of libdeepcam_hip.so against plain PyTorch fp32 ops on the CPU.
+
+All calls go through the C ABI (ctypes, raw device pointers).  fp32 storage is compared tightly; bf16 storage is
+compared against the same fp32 reference evaluated on bf16-rounded inputs, with a tolerance of a few bf16 ulps of the
+output scale (the MFMA accumulates in fp32, only the stored result is rounded).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mlperf_deepcam_amd import lib as L  # noqa: E402
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t, dtype):
+    """Round to the storage dtype and come back to fp32 (what the kernel actually sees)."""
+    return t.to(dtype).float()
+
+
+def to_nhwc(t_nchw, dtype, ld=None, off=0):
+    """NCHW fp32 CPU -> device NHWC view of width C inside a [N,H,W,ld] buffer poisoned with NaN."""
+    n, c, h, w = t_nchw.shape
+    ld = ld or c
+    buf = torch.full((n, h, w, ld), float("nan"), dtype=dtype, device=dev())
+    buf[..., off:off + c] = t_nchw.permute(0, 2, 3, 1).to(dtype).to(dev())
+    view = buf[..., off:off + c]
+    return buf, view
+
+
+def from_nhwc(view):
+    return view.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def empty_nhwc(n, h, w, c, dtype, ld=None, off=0, fill=float("nan")):
+    ld = ld or c
+    buf = torch.full((n, h, w, ld), fill, dtype=dtype, device=dev())
+    return buf, buf[..., off:off + c]
+
+
+def vptr(view):
+    return C.c_void_p(view.data_ptr())
+
+
+def tol(dtype, ref, f32=2e-4, bf16=2.5e-2):
+    scale = float(ref.abs().max()) + 1e-12
+    return (f32 if dtype == torch.float32 else bf16) * scale
+
+
+def assert_close(got, ref, dtype, **kw):
+    t = tol(dtype, ref, **kw)
+    err = float((got - ref).abs().max())
+    assert err <= t, f"max abs err {err:.3e} > tol {t:.3e} (scale {float(ref.abs().max()):.3e})"
+
+
+def desc(dtype, k, stride, pad, dil, transposed, cin, cout):
+    return L.ConvDesc(L.dtype_code(dtype), k, stride, pad, dil, transposed, cin, cout)
+
+
+def S():
+    return L.stream_ptr()
+
+
+CONV_CASES = [
+    # name, k, stride, pad, dil, transposed, cin, cout, N, H, W
+    ("pw728", 1, 1, 0, 1, 0, 728, 728, 2, 12, 10),
+    ("pw_s2", 1, 2, 0, 1, 0, 64, 128, 2, 16, 12),
+    ("pw_small_n", 1, 1, 0, 1, 0, 128, 48, 1, 9, 7),
+    ("dense3x3", 3, 1, 1, 1, 0, 304, 256, 2, 10, 12),
+    ("atrous6", 3, 1, 6, 6, 0, 64, 256, 2, 16, 20),
+    ("atrous18", 3, 1, 18, 18, 0, 32, 40, 1, 48, 72),
+    ("convT", 3, 2, 1, 1, 1, 256, 256, 2, 8, 6),
+    ("convT_small", 3, 2, 1, 1, 1, 24, 40, 1, 5, 7),
+    ("gemm_rows2", 1, 1, 0, 1, 0, 2048, 256, 2, 1, 1),
+]
+
+
+def conv_ref(x, w, bias, k, stride, pad, dil, transposed):
+    if transposed:
+        return F.conv_transpose2d(x, w, bias, 2, 1, 1)
+    return F.conv2d(x, w, bias, stride, pad, dil)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    name, k, stride, pad, dil, tr, cin, cout, N, H, W = case
+    d = desc(dtype, k, stride, pad, dil, tr, cin, cout)
+    kk = 3 if tr else k
+    wshape = (cin, cout, kk, kk) if tr else (cout, cin, kk, kk)
+    fan = cin * kk * kk
+    x = q(rnd(N, cin, H, W, seed=1), dtype)
+    w = rnd(*wshape, seed=2, scale=fan ** -0.5)
+    wq = q(w, dtype)
+    Ho, Wo = C.c_int(), C.c_int()
+    L.call("dc_conv_out_hw", C.byref(d), H, W, C.byref(Ho), C.byref(Wo))
+    Ho, Wo = Ho.value, Wo.value
+    xr = x.clone().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    yref = conv_ref(xr, wr, None, k, stride, pad, dil, tr)
+    assert (yref.shape[2], yref.shape[3]) == (Ho, Wo)
+    gy = q(rnd(*yref.shape, seed=3), dtype)
+    gx_ref, gw_ref = torch.autograd.grad(yref, (xr, wr), gy)
+    # also the weight gradient with unrounded master weights is the same function of (x, gy)
+
+    wm = w.to(dev())
+    wf = torch.empty(kk * kk * cout * cin, dtype=dtype, device=dev())
+    wb = torch.empty(kk * kk * cout * cin, dtype=dtype, device=dev())
+    L.call("dc_conv_pack_weights", C.byref(d), vptr(wm), vptr(wf), vptr(wb), S())
+
+    # forward into a channel slice of a wider buffer, with the BN partial statistics
+    _, xv = to_nhwc(x, dtype, ld=cin + 16, off=8)
+    ybuf, yv = empty_nhwc(N, Ho, Wo, cout, dtype, ld=cout + 24, off=16)
+    rows = L.load().dc_conv_stat_rows(C.byref(d), N, H, W)
+    slab = torch.full((2, rows, cout), float("nan"), device=dev())
+    L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, vptr(slab), 0, S())
+    torch.cuda.synchronize()
+    y = from_nhwc(yv)
+    assert_close(y, yref.detach(), dtype)
+    # untouched bytes outside the slice stay poisoned
+    assert torch.isnan(ybuf[..., :16].float()).all() and torch.isnan(ybuf[..., 16 + cout:].float()).all()
+    ssum = slab[0].sum(0).cpu()
+    ssq = slab[1].sum(0).cpu()
+    np.testing.assert_allclose(ssum.numpy(), y.sum((0, 2, 3)).numpy(), rtol=2e-3, atol=2e-3 * float(y.abs().sum((0, 2, 3)).max()))
+    np.testing.assert_allclose(ssq.numpy(), (y * y).sum((0, 2, 3)).numpy(), rtol=2e-3)
+
+    # accumulate: y += conv(x)
+    L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, None, 1, S())
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(yv), 2 * yref.detach(), dtype, bf16=4e-2)
+
+    # bias
+    bias = rnd(cout, seed=5).to(dev())
+    L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), vptr(bias), vptr(yv), cout + 24, None, 0, S())
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(yv), yref.detach() + bias.cpu()[None, :, None, None], dtype)
+
+    # data gradient
+    _, gyv = to_nhwc(gy, dtype)
+    _, gxv = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
+    L.call("dc_conv_dgrad", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(gxv), cin + 8, 0, S())
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(gxv), gx_ref, dtype)
+    L.call("dc_conv_dgrad", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(gxv), cin + 8, 1, S())
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(gxv), 2 * gx_ref, dtype, bf16=4e-2)
+
+    # weight gradient (fp32, master layout)
+    wsb = L.load().dc_conv_wgrad_workspace(C.byref(d), N, H, W)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev())
+    gw = torch.full(wshape, float("nan"), device=dev())
+    L.call("dc_conv_wgrad", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(gyv), cout, vptr(ws), wsb, vptr(gw), S())
+    torch.cuda.synchronize()
+    assert_close(gw.cpu(), gw_ref, dtype, f32=3e-4, bf16=1e-2)
+
+
+def test_conv_rejects_bad_arguments():
+    d = desc(torch.bfloat16, 5, 1, 0, 1, 0, 64, 64)
+    x = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device=dev())
+    with pytest.raises(L.DeepcamHipError, match="kernel size"):
+        L.call("dc_conv_fwd", C.byref(d), 1, 4, 4, vptr(x), 64, vptr(x), None, vptr(x), 64, None, 0, S())
+    d = desc(torch.bfloat16, 1, 1, 0, 1, 0, 60, 64)   # 60 is not a multiple of 8
+    with pytest.raises(L.DeepcamHipError, match="channel count"):
+        L.call("dc_conv_fwd", C.byref(d), 1, 4, 4, vptr(x), 64, vptr(x), None, vptr(x), 64, None, 0, S())
+    d = desc(torch.bfloat16, 1, 2, 0, 1, 0, 64, 64)
+    with pytest.raises(L.DeepcamHipError, match="odd extent"):
+        L.call("dc_conv_dgrad", C.byref(d), 1, 5, 5, vptr(x), 64, vptr(x), vptr(x), 64, 0, S())
+
+
+DW_CASES = [("s1", 728, 1, 1, 2, 12, 10), ("s2", 128, 2, 1, 2, 16, 12), ("d2", 1024, 1, 2, 1, 10, 14), ("odd", 64, 2, 1, 1, 9, 11)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", DW_CASES, ids=[c[0] for c in DW_CASES])
+def test_depthwise(case, dtype):
+    _, Cc, stride, dil, N, H, W = case
+    dt = L.dtype_code(dtype)
+    x = q(rnd(N, Cc, H, W, seed=1), dtype)
+    w = rnd(Cc, 1, 3, 3, seed=2, scale=1 / 3)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yref = F.conv2d(F.pad(xr, (dil, dil, dil, dil)), wr, None, stride, 0, dil, groups=Cc)
+    Ho, Wo = yref.shape[2:]
+    gy = q(rnd(*yref.shape, seed=3), dtype)
+    gx_ref, gw_ref = torch.autograd.grad(yref, (xr, wr), gy)
+    wd = w.to(dev())
+    _, xv = to_nhwc(x, dtype, ld=Cc + 8)
+    _, yv = empty_nhwc(N, Ho, Wo, Cc, dtype)
+    L.call("dc_dwconv_fwd", dt, Cc, stride, dil, N, H, W, vptr(xv), Cc + 8, vptr(wd), vptr(yv), Cc, S())
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(yv), yref.detach(), dtype, bf16=1e-2)
+    _, gyv = to_nhwc(gy, dtype)
+    add = q(rnd(N, Cc, H, W, seed=4), dtype)
+    _, addv = to_nhwc(add, dtype)
+    _, gxv = empty_nhwc(N, H, W, Cc, dtype)
+    L.call("dc_dwconv_dgrad", dt, Cc, stride, dil, N, H, W, vptr(gyv), Cc, vptr(wd), None, 0, vptr(gxv), Cc, S())
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(gxv), gx_ref, dtype, bf16=1e-2)
+    L.call("dc_dwconv_dgrad", dt, Cc, stride, dil, N, H, W, vptr(gyv), Cc, vptr(wd), vptr(addv), Cc, vptr(gxv), Cc, S())
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(gxv), gx_ref + add, dtype, bf16=1e-2)
+    wsb = L.load().dc_dwconv_wgrad_workspace(Cc, N, H, W, stride)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    gw = torch.full((Cc, 1, 3, 3), float("nan"), device=dev())
+    L.call("dc_dwconv_wgrad", dt, Cc, stride, dil, N, H, W, vptr(xv), Cc + 8, vptr(gyv), Cc, vptr(ws), vptr(gw), S())
+    torch.cuda.synchronize()
+    assert_close(gw.cpu(), gw_ref, dtype, f32=2e-4, bf16=2e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 728, 12, 10), (2, 32, 40, 33), (2, 256, 1, 1)], ids=["c728", "c32", "pool"])
+@pytest.mark.parametrize("relu,use_res", [(1, 0), (1, 1), (0, 1), (0, 0)])
+def test_batchnorm_train_fwd_bwd(shape, dtype, relu, use_res):
+    N, Cc, H, W = shape
+    dt = L.dtype_code(dtype)
+    M = N * H * W
+    y = q(rnd(N, Cc, H, W, seed=1) * 2 + 0.5, dtype)
+    res = q(rnd(N, Cc, H, W, seed=2), dtype) if use_res else None
+    gamma = torch.rand(Cc, generator=torch.Generator().manual_seed(3)) + 0.5
+    beta = rnd(Cc, seed=4, scale=0.3)
+    rm0, rv0 = rnd(Cc, seed=5), torch.rand(Cc, generator=torch.Generator().manual_seed(6)) + 0.5
+    # reference
+    yr = y.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    o = F.batch_norm(yr, rm, rv, gr, br, True, 0.1, 1e-5)
+    if use_res:
+        rr = res.clone().requires_grad_(True)
+        o = o + rr
+    if relu:
+        o = F.relu(o)
+    go = q(rnd(N, Cc, H, W, seed=7), dtype)
+    grads = torch.autograd.grad(o, (yr, gr, br) + ((rr,) if use_res else ()), go)
+    # device
+    _, yv = to_nhwc(y, dtype, ld=Cc + 8)
+    rows = L.load().dc_bn_stat_rows(M)
+    slab = torch.empty(2, rows, Cc, device=dev())
+    L.call("dc_bn_stats", dt, M, Cc, vptr(yv), Cc + 8, vptr(slab), S())
+    dv = lambda t: t.clone().to(dev())  # noqa: E731
+    g_d, b_d, rm_d, rv_d = dv(gamma), dv(beta), dv(rm0), dv(rv0)
+    nbt = torch.zeros(1, dtype=torch.int64, device=dev())
+    scale, shift, smean, sinv = (torch.empty(Cc, device=dev()) for _ in range(4))
+    L.call("dc_bn_finalize", Cc, M, vptr(slab), rows, vptr(g_d), vptr(b_d), vptr(rm_d), vptr(rv_d), vptr(nbt), 0.1, 1e-5,
+           vptr(scale), vptr(shift), vptr(smean), vptr(sinv), S())
+    resv = to_nhwc(res, dtype)[1] if use_res else None
+    _, ov = empty_nhwc(N, H, W, Cc, dtype, ld=Cc + 16, off=8)
+    L.call("dc_bn_apply", dt, M, Cc, vptr(yv), Cc + 8, vptr(scale), vptr(shift), vptr(resv) if use_res else None, Cc, relu,
+           vptr(ov), Cc + 16, S())
+    torch.cuda.synchronize()
+    assert int(nbt) == 1
+    np.testing.assert_allclose(rm_d.cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rv_d.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-5)
+    assert_close(from_nhwc(ov), o.detach(), dtype, bf16=1e-2)
+    # backward
+    _, gov = to_nhwc(go, dtype)
+    slab2 = torch.empty(2, rows, Cc, device=dev())
+    L.call("dc_bn_bwd_reduce", dt, M, Cc, vptr(gov), Cc, vptr(yv), Cc + 8, vptr(ov), Cc + 16, relu, vptr(smean), vptr(sinv), vptr(slab2), S())
+    dgamma, dbeta = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
+    L.call("dc_bn_bwd_finalize", Cc, vptr(slab2), rows, vptr(dgamma), vptr(dbeta), S())
+    _, dyv = empty_nhwc(N, H, W, Cc, dtype)
+    _, gv = empty_nhwc(N, H, W, Cc, dtype)
+    L.call("dc_bn_bwd_apply", dt, M, Cc, M, vptr(gov), Cc, vptr(yv), Cc + 8, vptr(ov), Cc + 16, relu, vptr(g_d), vptr(smean),
+           vptr(sinv), vptr(dgamma), vptr(dbeta), vptr(dyv), Cc, vptr(gv), Cc, S())
+    torch.cuda.synchronize()
+    # with bf16 storage the ReLU mask is taken from the ROUNDED output; compare against a reference using that mask
+    if M > 2:  # (a 2-sample BN has |xhat| == 1: dgamma/dy are cancellation-dominated, checked loosely below)
+        assert_close(dgamma.cpu(), grads[1], dtype, f32=5e-4, bf16=2e-2)
+        assert_close(from_nhwc(dyv), grads[0], dtype, f32=1e-3, bf16=4e-2)
+    assert_close(dbeta.cpu(), grads[2], dtype, f32=5e-4, bf16=2e-2)
+    if use_res:
+        assert_close(from_nhwc(gv), grads[3], dtype, bf16=1e-2)
+
+
+def test_bn_single_value_per_channel_raises():
+    slab = torch.zeros(2, 1, 8, device=dev())
+    v = torch.ones(8, device=dev())
+    with pytest.raises(L.DeepcamHipError, match="Expected more than 1 value per channel"):
+        L.call("dc_bn_finalize", 8, 1, vptr(slab), 1, vptr(v), vptr(v), None, None, None, 0.1, 1e-5, vptr(v), vptr(v), None, None, S())
+
+
+def test_bn_eval_coeffs():
+    Cc = 48
+    g, b, rm = rnd(Cc, seed=1), rnd(Cc, seed=2), rnd(Cc, seed=3)
+    rv = torch.rand(Cc) + 0.1
+    sc, sh = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
+    L.call("dc_bn_eval_coeffs", Cc, vptr(g.to(dev())), vptr(b.to(dev())), vptr(rm.to(dev())), vptr(rv.to(dev())), 1e-5, vptr(sc), vptr(sh), S())
+    x = rnd(3, Cc, 2, 2, seed=4)
+    ref = F.batch_norm(x, rm, rv, g, b, False, 0.1, 1e-5)
+    got = x * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None]
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_stem(dtype):
+    N, Cin, H, W = 2, 16, 20, 28
+    dt = L.dtype_code(dtype)
+    x = torch.rand(N, Cin, H, W, generator=torch.Generator().manual_seed(1))
+    w = rnd(32, Cin, 3, 3, seed=2, scale=(2.0 / (Cin * 9)) ** 0.5)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yref = F.conv2d(xr, wr, None, 2, 1)
+    Ho, Wo = yref.shape[2:]
+    xd, wd = x.to(dev()), w.to(dev())
+    _, yv = empty_nhwc(N, Ho, Wo, 32, dtype)
+    rows = L.load().dc_stem_stat_rows(N, H, W)
+    slab = torch.empty(2, rows, 32, device=dev())
+    L.call("dc_stem_fwd", dt, N, Cin, H, W, vptr(xd), vptr(wd), vptr(yv), 32, vptr(slab), S())
+    torch.cuda.synchronize()
+    y = from_nhwc(yv)
+    assert_close(y, yref.detach(), dtype, bf16=1e-2)
+    np.testing.assert_allclose(slab[0].sum(0).cpu().numpy(), y.sum((0, 2, 3)).numpy(), rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(slab[1].sum(0).cpu().numpy(), (y * y).sum((0, 2, 3)).numpy(), rtol=1e-3)
+    gy = q(rnd(*yref.shape, seed=3), dtype)
+    (gw_ref,) = torch.autograd.grad(yref, (wr,), gy)
+    _, gyv = to_nhwc(gy, dtype)
+    wsb = L.load().dc_stem_wgrad_workspace(N, Cin, H, W)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    gw = torch.full((32, Cin, 3, 3), float("nan"), device=dev())
+    L.call("dc_stem_wgrad", dt, N, Cin, H, W, vptr(xd), vptr(gyv), 32, vptr(ws), vptr(gw), S())
+    torch.cuda.synchronize()
+    assert_close(gw.cpu(), gw_ref, dtype, f32=2e-4, bf16=2e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_head(dtype):
+    N, Cin, H, W = 2, 256, 6, 9
+    dt = L.dtype_code(dtype)
+    x = q(rnd(N, Cin, H, W, seed=1), dtype)
+    w = rnd(Cin, 3, 3, 3, seed=2, scale=0.05)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, None, 2, 1, 1)
+    gl = rnd(*ref.shape, seed=3)
+    gx_ref, gw_ref = torch.autograd.grad(ref, (xr, wr), gl)
+    _, xv = to_nhwc(x, dtype, ld=Cin + 8)
+    wd = w.to(dev())
+    out = torch.full((N, 3, 2 * H, 2 * W), float("nan"), device=dev())
+    L.call("dc_head_fwd", dt, N, Cin, H, W, vptr(xv), Cin + 8, vptr(wd), vptr(out), S())
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), ref.detach(), torch.float32, f32=2e-4)        # fp32 accumulate on exact inputs
+    gld = gl.to(dev())
+    _, gxv = empty_nhwc(N, H, W, Cin, dtype)
+    L.call("dc_head_dgrad", dt, N, Cin, H, W, vptr(gld), vptr(wd), vptr(gxv), Cin, S())
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(gxv), gx_ref, dtype, bf16=1e-2)
+    wsb = L.load().dc_head_wgrad_workspace(N, Cin, H, W)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    gw = torch.full((Cin, 3, 3, 3), float("nan"), device=dev())
+    L.call("dc_head_wgrad", dt, N, Cin, H, W, vptr(xv), Cin + 8, vptr(gld), vptr(ws), vptr(gw), S())
+    torch.cuda.synchronize()
+    assert_close(gw.cpu(), gw_ref, torch.float32, f32=2e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_pool_branch_helpers(dtype):
+    N, Cc, H, W = 2, 2048, 6, 5
+    dt = L.dtype_code(dtype)
+    HW = H * W
+    x = q(rnd(N, Cc, H, W, seed=1), dtype)
+    _, xv = to_nhwc(x, dtype)
+    pooled = torch.empty(N, Cc, dtype=dtype, device=dev())
+    L.call("dc_avgpool_fwd", dt, N, HW, Cc, vptr(xv), Cc, vptr(pooled), S())
+    torch.cuda.synchronize()
+    assert_close(pooled.float().cpu(), x.mean((2, 3)), dtype, bf16=1e-2)
+    _, bv = empty_nhwc(N, H, W, Cc, dtype, ld=Cc + 8)
+    L.call("dc_broadcast_hw", dt, N, HW, Cc, vptr(pooled), vptr(bv), Cc + 8, S())
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(bv), pooled.float().cpu()[:, :, None, None].expand(N, Cc, H, W))
+    summed = torch.empty(N, Cc, dtype=dtype, device=dev())
+    L.call("dc_sum_hw", dt, N, HW, Cc, vptr(xv), Cc, vptr(summed), S())
+    torch.cuda.synchronize()
+    assert_close(summed.float().cpu(), x.sum((2, 3)), dtype, bf16=1e-2)
+    acc0 = q(rnd(N, Cc, H, W, seed=2), dtype)
+    _, av = to_nhwc(acc0, dtype)
+    L.call("dc_avgpool_bwd_add", dt, N, HW, Cc, vptr(pooled), vptr(av), Cc, S())
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(av), acc0 + pooled.float().cpu()[:, :, None, None] / HW, dtype, bf16=1e-2)
+    _, cv = empty_nhwc(N, H, W, Cc, dtype, ld=Cc + 8, off=8)
+    L.call("dc_copy_view", dt, N * HW, Cc, vptr(xv), Cc, vptr(cv), Cc + 8, S())
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(cv), x)
+    # column sum (bias gradient)
+    wsb = L.load().dc_colsum_workspace(N * HW, Cc)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    out = torch.empty(Cc, device=dev())
+    L.call("dc_colsum", dt, N * HW, Cc, vptr(xv), Cc, vptr(out), vptr(ws), S())
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), x.sum((0, 2, 3)), torch.float32, f32=1e-4)
+
+
+@pytest.mark.parametrize("kind,wd", [("Adam", 1e-6), ("AdamW", 1e-2)])
+def test_adam_matches_torch_optim(kind, wd):
+    n = 100003
+    p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.1)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = (torch.optim.Adam if kind == "Adam" else torch.optim.AdamW)([pr], lr=1e-3, eps=1e-8, weight_decay=wd)
+    npad = (n + 3) // 4 * 4
+    p = torch.zeros(npad, device=dev()); p[:n] = p0.to(dev())
+    gd = torch.zeros(npad, device=dev())
+    m, v = torch.zeros(npad, device=dev()), torch.zeros(npad, device=dev())
+    lr = torch.tensor([1e-3], device=dev())
+    step = torch.zeros(1, dtype=torch.int32, device=dev())
+    for s in range(1, 4):
+        gs = g * s
+        pr.grad = gs.clone()
+        opt.step()
+        gd[:n] = (gs * 2).to(dev())      # fed with grad_scale = 0.5
+        step.fill_(s)
+        L.call("dc_adam_step", L.DC_ADAM if kind == "Adam" else L.DC_ADAMW, n, vptr(p), vptr(gd), vptr(m), vptr(v), vptr(lr),
+               0.9, 0.999, 1e-8, wd, vptr(step), 0.5, S())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(p[:n].cpu().numpy(), pr.detach().numpy(), rtol=2e-6, atol=2e-7)
+
+
+def test_lamb_matches_oracle():
+    from oracle.optim import OracleOptimizer
+    sizes = [1000, 7, 4096, 33]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offs[-1])
+    p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=3.0)
+    p0[offs[1]:offs[2]] = 0.0        # a zero-norm tensor -> trust ratio 1
+    cpu_p = [p0[offs[i]:offs[i + 1]].clone() for i in range(4)]
+    ref = OracleOptimizer(cpu_p, "LAMB", lr=1e-2, eps=1e-6, weight_decay=1e-2)
+    p = p0.clone().to(dev())
+    m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    lr = torch.tensor([1e-2], device=dev())
+    step = torch.zeros(1, dtype=torch.int32, device=dev())
+    ws = torch.empty(2 * 4 + 2, device=dev())
+    od = torch.from_numpy(offs).to(dev())
+    for s in range(1, 4):
+        gs = g / s
+        ref.step([gs[offs[i]:offs[i + 1]] for i in range(4)])
+        gd = gs.clone().to(dev())
+        step.fill_(s)
+        L.call("dc_lamb_step", 4, vptr(od), n, vptr(p), vptr(gd), vptr(m), vptr(v), vptr(lr), 0.9, 0.999, 1e-6, 1e-2, vptr(step),
+               1.0, 1.0, vptr(ws), S())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(p.cpu().numpy(), torch.cat(cpu_p).numpy(), rtol=2e-5, atol=2e-6)
