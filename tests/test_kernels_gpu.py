@@ -298,7 +298,9 @@ def test_bn_eval_coeffs():
     g, b, rm = rnd(Cc, seed=1), rnd(Cc, seed=2), rnd(Cc, seed=3)
     rv = torch.rand(Cc) + 0.1
     sc, sh = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
-    L.call("dc_bn_eval_coeffs", Cc, vptr(g.to(dev())), vptr(b.to(dev())), vptr(rm.to(dev())), vptr(rv.to(dev())), 1e-5, vptr(sc), vptr(sh), S())
+    gd, bd, rmd, rvd = g.to(dev()), b.to(dev()), rm.to(dev()), rv.to(dev())     # keep the device copies alive
+    L.call("dc_bn_eval_coeffs", Cc, vptr(gd), vptr(bd), vptr(rmd), vptr(rvd), 1e-5, vptr(sc), vptr(sh), S())
+    torch.cuda.synchronize()
     x = rnd(3, Cc, 2, 2, seed=4)
     ref = F.batch_norm(x, rm, rv, g, b, False, 0.1, 1e-5)
     got = x * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None]
