@@ -1,0 +1,495 @@
+"""Explicit forward / backward program of the DeepCAM train step over preallocated channels-last buffers.
+
+No tracing compiler and no autograd graph: the network is a static list of kernel launches (``fwd`` program) and a
+hand-written reverse list (``bwd`` program) over buffers whose shapes are fixed at construction, so the same call
+sequence can be replayed eagerly or captured once into a hipGraph.  Every arithmetic step is a call into
+libdeepcam_hip.so (mlperf-deepcam_amd/lib.py); torch is used for device memory and streams only.
+
+Data layout in HBM
+  * activations / activation gradients: NHWC, dtype T (bf16 or fp32), concat inputs are channel slices of one buffer
+  * parameters, gradients, Adam/LAMB moments: three flat fp32 arenas in the reference's parameter order
+  * GEMM weights: packed per step from the fp32 master into T, once in forward ([tap][cout][cin]) and once in
+    data-gradient ([tap][cin][cout]) orientation
+  * BatchNorm: fp32 per-tile partial statistics slabs, fp32 scale/shift/mean/invstd vectors, fp32 running buffers
+
+Reference: DeepLabv3_plus.forward (architecture/deeplab_xception.py:441-465) and everything it calls; the backward is
+what ``loss.backward()`` (train_hdf5_ddp.py:363) would produce for it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import lib as L
+from . import spec as S
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class Act:
+    """NHWC activation view: element (n,h,w,c) at base[((n*H+h)*W+w)*ld + off + c]."""
+
+    def __init__(self, eng: "Engine", name: str, N: int, H: int, W: int, Cc: int, parent: "Act" = None, off: int = 0,
+                 dtype=None):
+        self.eng, self.name, self.N, self.H, self.W, self.C = eng, name, N, H, W, Cc
+        self.parent, self.off = parent, off
+        if parent is None:
+            self.buf = torch.empty((N, H, W, Cc), dtype=dtype or eng.dtype, device=eng.device)
+            self.ld = Cc
+            eng.act_bytes += self.buf.numel() * self.buf.element_size()
+        else:
+            assert (parent.N, parent.H, parent.W) == (N, H, W) and off + Cc <= parent.C
+            self.buf, self.ld = parent.buf, parent.ld
+            self.off = parent.off + off
+        self._grad: Optional[Act] = None
+        self.grad_init = False      # set while the backward program is built: has some op written the gradient yet?
+
+    @property
+    def M(self) -> int:
+        return self.N * self.H * self.W
+
+    @property
+    def ptr(self) -> C.c_void_p:
+        return C.c_void_p(self.buf.data_ptr() + self.off * self.buf.element_size())
+
+    def slice(self, name: str, off: int, Cc: int) -> "Act":
+        return Act(self.eng, name, self.N, self.H, self.W, Cc, parent=self, off=off)
+
+    def view(self) -> torch.Tensor:
+        return self.buf.view(self.N, self.H, self.W, self.ld)[..., self.off:self.off + self.C]
+
+    @property
+    def grad(self) -> "Act":
+        if self._grad is None:
+            if self.parent is not None:
+                self._grad = Act(self.eng, "d" + self.name, self.N, self.H, self.W, self.C, parent=self.parent.grad,
+                                 off=self.off - self.parent.off)
+            else:
+                self._grad = Act(self.eng, "d" + self.name, self.N, self.H, self.W, self.C)
+        return self._grad
+
+    def take_grad_mode(self) -> int:
+        """0 = this op is the first writer of the gradient, 1 = accumulate (read-modify-write).
+        Called while the backward program is resolved, in execution order."""
+        a, init = self, False
+        while a is not None:
+            init = init or a.grad_init
+            a = a.parent
+        self.grad_init = True
+        return 1 if init else 0
+
+
+class Engine:
+    def __init__(self, batch: int, height: int, width: int, dtype=torch.bfloat16, device=None, n_input: int = 16,
+                 n_classes: int = 3, seed: Optional[int] = 333, share_from: "Engine" = None):
+        if not torch.cuda.is_available():
+            raise L.DeepcamHipError("mlperf_deepcam_amd.Engine needs a HIP device: there is no CPU path")
+        L.load()
+        assert n_classes == 3, "the fused loss / head kernels are built for the 3 DeepCAM classes"
+        assert height % 16 == 0 and width % 16 == 0, "input extents must be multiples of the output stride (16)"
+        self.B, self.H, self.W = batch, height, width
+        self.dtype, self.dt = dtype, L.dtype_code(dtype)
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.n_input, self.n_classes = n_input, n_classes
+        self.layout = S.Layout(n_input, n_classes)
+        lay = self.layout
+        self.act_bytes = 0
+
+        # ---- flat arenas (shared between engines of different batch shape, e.g. train B=2 and validation B=1) ----
+        if share_from is not None:
+            assert share_from.layout.n_params == lay.n_params and share_from.device == self.device
+            self.params, self.grads, self.buffers, self.nbt = share_from.params, share_from.grads, share_from.buffers, share_from.nbt
+            self.version = share_from.version
+        else:
+            host = torch.empty(lay.n_params, dtype=torch.float32)
+            S.init_arena(lay, host, seed)
+            self.params = host.to(self.device)
+            self.grads = torch.zeros(lay.n_params, dtype=torch.float32, device=self.device)
+            hb = torch.zeros(lay.n_buffers, dtype=torch.float32)
+            for name, (off, c) in lay.buffers.items():
+                if name.endswith("running_var"):
+                    hb[off:off + c] = 1.0
+            self.buffers = hb.to(self.device)
+            self.nbt = torch.zeros(len(lay.nbt), dtype=torch.int64, device=self.device)
+            self.version = [0]          # bumped whenever the master weights change (optimizer step, load_state_dict)
+        self.packed_version = -1
+
+        # ---- program containers -----------------------------------------------------------------------------
+        self.fwd_train: List[Callable[[], None]] = []
+        self.fwd_eval: List[Callable[[], None]] = []
+        self.bwd: List[Callable[[], None]] = []      # appended in forward order, executed reversed
+        self.pack_ops: List[Callable[[], None]] = []
+        self.grad_ready: List[List[str]] = []        # per bwd entry: parameter names whose gradient is final after it
+        self.ws_bytes = 0
+        self._ws_users: List[Callable[[], int]] = []
+        self.x_in: Optional[torch.Tensor] = None     # caller's NCHW fp32 batch (set per call)
+        self.x_static = torch.empty((batch, n_input, height, width), dtype=torch.float32, device=self.device)
+        self.logits = torch.empty((batch, n_classes, height, width), dtype=torch.float32, device=self.device)
+        self.dlogits = torch.empty_like(self.logits)
+        self._build()
+        self.workspace = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=self.device)
+        self.on_grad_ready: Optional[Callable[[List[str]], None]] = None
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def pptr(self, name: str) -> C.c_void_p:
+        return C.c_void_p(self.params.data_ptr() + self.layout.params[name].offset * 4)
+
+    def gptr(self, name: str) -> C.c_void_p:
+        return C.c_void_p(self.grads.data_ptr() + self.layout.params[name].offset * 4)
+
+    def bptr(self, name: str) -> C.c_void_p:
+        return C.c_void_p(self.buffers.data_ptr() + self.layout.buffers[name][0] * 4)
+
+    def param_view(self, name: str) -> torch.Tensor:
+        p = self.layout.params[name]
+        return self.params[p.offset:p.offset + math.prod(p.shape)].view(p.shape)
+
+    def grad_view(self, name: str) -> torch.Tensor:
+        p = self.layout.params[name]
+        return self.grads[p.offset:p.offset + math.prod(p.shape)].view(p.shape)
+
+    def buffer_view(self, name: str) -> torch.Tensor:
+        if name in self.layout.nbt:
+            return self.nbt[self.layout.nbt[name]]
+        off, c = self.layout.buffers[name]
+        return self.buffers[off:off + c]
+
+    def _need_ws(self, nbytes: int) -> None:
+        self.ws_bytes = max(self.ws_bytes, int(nbytes))
+
+    def _wsptr(self) -> C.c_void_p:
+        return C.c_void_p(self.workspace.data_ptr())
+
+    @staticmethod
+    def _st():
+        return L.stream_ptr()
+
+    def _f32(self, n: int) -> torch.Tensor:
+        return torch.empty(n, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------------------------------------ op builders
+    def _conv(self, x: Act, wname: str, cout: int, k: int = 1, stride: int = 1, pad: int = 0, dil: int = 1,
+              transposed: bool = False, out: Act = None, stats: bool = True, bias: str = None, name: str = None,
+              need_dx: bool = True):
+        """Dense conv (implicit GEMM).  Returns (y, slab, rows)."""
+        lib = L.load()
+        d = L.ConvDesc(self.dt, 3 if transposed else k, stride, pad, dil, 1 if transposed else 0, x.C, cout)
+        ho, wo = C.c_int(), C.c_int()
+        L.call("dc_conv_out_hw", C.byref(d), x.H, x.W, C.byref(ho), C.byref(wo))
+        y = out or Act(self, name or wname, x.N, ho.value, wo.value, cout)
+        assert (y.H, y.W, y.C) == (ho.value, wo.value, cout)
+        kk = d.k * d.k
+        wf = torch.empty(kk * cout * x.C, dtype=self.dtype, device=self.device)
+        wb = torch.empty(kk * cout * x.C, dtype=self.dtype, device=self.device) if need_dx else None
+        rows = lib.dc_conv_stat_rows(C.byref(d), x.N, x.H, x.W) if stats else 0
+        slab = self._f32(2 * rows * cout) if stats else None
+        wsb = lib.dc_conv_wgrad_workspace(C.byref(d), x.N, x.H, x.W)
+        self._need_ws(wsb)
+        N, H, W = x.N, x.H, x.W
+        pw, gw = self.pptr(wname), self.gptr(wname)
+        pb = self.pptr(bias) if bias else None
+        self.pack_ops.append(lambda: L.call("dc_conv_pack_weights", C.byref(d), pw, L.dptr(wf), L.dptr(wb), self._st()))
+
+        def fwd(train: bool):
+            L.call("dc_conv_fwd", C.byref(d), N, H, W, x.ptr, x.ld, L.dptr(wf), pb, y.ptr, y.ld,
+                   L.dptr(slab) if train else None, 0, self._st())
+
+        self.fwd_train.append(lambda: fwd(True))
+        self.fwd_eval.append(lambda: fwd(False))
+
+        def make_bwd():
+            dy = y.grad
+            mode = x.take_grad_mode() if need_dx else 0
+            dx = x.grad if need_dx else None
+            ready = [wname] + ([bias] if bias else [])
+            if bias:
+                self._need_ws(lib.dc_colsum_workspace(y.M, cout))
+
+            def bwd():
+                if bias:
+                    L.call("dc_colsum", self.dt, y.M, cout, dy.ptr, dy.ld, self.gptr(bias), self._wsptr(), self._st())
+                L.call("dc_conv_wgrad", C.byref(d), N, H, W, x.ptr, x.ld, dy.ptr, dy.ld, self._wsptr(), wsb, gw, self._st())
+                if need_dx:
+                    L.call("dc_conv_dgrad", C.byref(d), N, H, W, dy.ptr, dy.ld, L.dptr(wb), dx.ptr, dx.ld, mode, self._st())
+            return bwd, ready
+
+        self.bwd.append(make_bwd)
+        return y, slab, rows
+
+    def _dw(self, x: Act, wname: str, stride: int, dil: int, name: str) -> Act:
+        lib = L.load()
+        Ho, Wo = (x.H - 1) // stride + 1, (x.W - 1) // stride + 1
+        y = Act(self, name, x.N, Ho, Wo, x.C)
+        N, H, W, Cc = x.N, x.H, x.W, x.C
+        pw, gw = self.pptr(wname), self.gptr(wname)
+        self._need_ws(lib.dc_dwconv_wgrad_workspace(Cc, N, H, W, stride))
+
+        def fwd():
+            L.call("dc_dwconv_fwd", self.dt, Cc, stride, dil, N, H, W, x.ptr, x.ld, pw, y.ptr, y.ld, self._st())
+
+        self.fwd_train.append(fwd)
+        self.fwd_eval.append(fwd)
+
+        def make_bwd():
+            dy = y.grad
+            mode = x.take_grad_mode()
+            dx = x.grad
+
+            def bwd():
+                L.call("dc_dwconv_wgrad", self.dt, Cc, stride, dil, N, H, W, x.ptr, x.ld, dy.ptr, dy.ld, self._wsptr(), gw, self._st())
+                L.call("dc_dwconv_dgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
+                       dx.ptr, dx.ld, self._st())
+            return bwd, [wname]
+
+        self.bwd.append(make_bwd)
+        return y
+
+    def _bn(self, y: Act, slab: torch.Tensor, rows: int, bname: str, relu: bool, residual: Act = None, out: Act = None,
+            name: str = None) -> Act:
+        lib = L.load()
+        Cc, M = y.C, y.M
+        o = out or Act(self, name or bname, y.N, y.H, y.W, Cc)
+        scale, shift, mean, invstd = (self._f32(Cc) for _ in range(4))
+        gam, bet = self.pptr(bname + ".weight"), self.pptr(bname + ".bias")
+        rm, rv = self.bptr(bname + ".running_mean"), self.bptr(bname + ".running_var")
+        nbt = C.c_void_p(self.nbt.data_ptr() + 8 * self.layout.nbt[bname + ".num_batches_tracked"])
+        relu_i = 1 if relu else 0
+        rptr = (lambda: residual.ptr) if residual is not None else (lambda: None)
+        rld = residual.ld if residual is not None else 0
+
+        def fwd_train():
+            L.call("dc_bn_finalize", Cc, M, L.dptr(slab), rows, gam, bet, rm, rv, nbt, BN_MOMENTUM, BN_EPS, L.dptr(scale),
+                   L.dptr(shift), L.dptr(mean), L.dptr(invstd), self._st())
+            L.call("dc_bn_apply", self.dt, M, Cc, y.ptr, y.ld, L.dptr(scale), L.dptr(shift), rptr(), rld, relu_i, o.ptr, o.ld, self._st())
+
+        def fwd_eval():
+            L.call("dc_bn_eval_coeffs", Cc, gam, bet, rm, rv, BN_EPS, L.dptr(scale), L.dptr(shift), self._st())
+            L.call("dc_bn_apply", self.dt, M, Cc, y.ptr, y.ld, L.dptr(scale), L.dptr(shift), rptr(), rld, relu_i, o.ptr, o.ld, self._st())
+
+        self.fwd_train.append(fwd_train)
+        self.fwd_eval.append(fwd_eval)
+        brows = lib.dc_bn_stat_rows(M)
+        bslab = self._f32(2 * brows * Cc)
+
+        def make_bwd():
+            do = o.grad
+            assert y.take_grad_mode() == 0, "a conv output feeds exactly one BatchNorm"
+            dy = y.grad
+            g_out = None
+            if residual is not None:
+                assert residual.take_grad_mode() == 0, f"{bname}: residual gradient must be first written here"
+                g_out = residual.grad
+            dgam, dbet = self.gptr(bname + ".weight"), self.gptr(bname + ".bias")
+
+            def bwd():
+                L.call("dc_bn_bwd_reduce", self.dt, M, Cc, do.ptr, do.ld, y.ptr, y.ld, o.ptr, o.ld, relu_i, L.dptr(mean),
+                       L.dptr(invstd), L.dptr(bslab), self._st())
+                L.call("dc_bn_bwd_finalize", Cc, L.dptr(bslab), brows, dgam, dbet, self._st())
+                L.call("dc_bn_bwd_apply", self.dt, M, Cc, M, do.ptr, do.ld, y.ptr, y.ld, o.ptr, o.ld, relu_i, gam, L.dptr(mean),
+                       L.dptr(invstd), dgam, dbet, dy.ptr, dy.ld, g_out.ptr if g_out is not None else None,
+                       g_out.ld if g_out is not None else 0, self._st())
+            return bwd, [bname + ".weight", bname + ".bias"]
+
+        self.bwd.append(make_bwd)
+        return o
+
+    def _sep(self, x: Act, s: S.SepSpec, residual: Act = None, relu_override: Optional[bool] = None, tag: str = "") -> Act:
+        """depthwise 3x3 -> pointwise 1x1 [-> BN (+residual) (+ReLU)]"""
+        d = self._dw(x, s.prefix + ".conv1.weight", s.stride, s.dil, s.prefix + ".dw")
+        y, slab, rows = self._conv(d, s.prefix + ".pointwise.weight", s.cout, stats=bool(s.bn), name=s.prefix + ".pw")
+        if not s.bn:
+            return y
+        relu = s.relu_after if relu_override is None else relu_override
+        return self._bn(y, slab, rows, s.bn, relu, residual=residual, name=s.bn + ".out")
+
+    # ------------------------------------------------------------------------------------------------ network
+    def _build(self) -> None:
+        lib = L.load()
+        B, H, W = self.B, self.H, self.W
+        X = "xception_features."
+        # ---- stem: reads NCHW fp32 input directly
+        c1 = Act(self, "stem", B, H // 2, W // 2, 32)
+        srows = lib.dc_stem_stat_rows(B, H, W)
+        sslab = self._f32(2 * srows * 32)
+        self._need_ws(lib.dc_stem_wgrad_workspace(B, self.n_input, H, W))
+        w1 = X + "conv1.weight"
+
+        def stem_fwd():
+            L.call("dc_stem_fwd", self.dt, B, self.n_input, H, W, L.dptr(self.x_in), self.pptr(w1), c1.ptr, c1.ld, L.dptr(sslab), self._st())
+
+        self.fwd_train.append(stem_fwd)
+        self.fwd_eval.append(stem_fwd)
+
+        def stem_bwd_make():
+            dy = c1.grad
+
+            def bwd():
+                L.call("dc_stem_wgrad", self.dt, B, self.n_input, H, W, L.dptr(self.x_in), dy.ptr, dy.ld, self._wsptr(), self.gptr(w1), self._st())
+            return bwd, [w1]
+
+        self.bwd.append(stem_bwd_make)
+        x = self._bn(c1, sslab, srows, X + "bn1", True)
+        y, slab, rows = self._conv(x, X + "conv2.weight", 64, k=3, pad=1)
+        x = self._bn(y, slab, rows, X + "bn2", True)
+
+        # ---- Xception blocks.  Every block input `z` is already ReLU'd (the reference's in-place leading ReLU).
+        low = None
+        for blk in S.blocks():
+            z = x
+            t = z
+            nsep = len(blk.seps)
+            for i, s in enumerate(blk.seps):
+                last = i == nsep - 1
+                if last and not blk.skip:
+                    # identity shortcut: out = relu(bn(pw(dw(t))) + z)   (x += skip, then the next block's in-place ReLU)
+                    t = self._sep(t, s, residual=z, relu_override=True)
+                else:
+                    t = self._sep(t, s)
+            if blk.skip:
+                ys, slab, rows = self._conv(z, f"{X}{blk.name}.skip.weight", blk.cout, stride=blk.stride, name=blk.name + ".skip")
+                t = self._bn(ys, slab, rows, f"{X}{blk.name}.skipbn", blk.relu_out, residual=t, name=blk.name + ".out")
+            x = t
+            if blk.name == "block1":
+                low = x            # low_level_feat, after block2's in-place ReLU has hit it
+        for s in S.EXIT_SEPS:
+            x = self._sep(x, s)
+        e = x
+        h16, w16 = e.H, e.W
+
+        # ---- ASPP: five branches write channel slices of one buffer (torch.cat is free)
+        cat1 = Act(self, "aspp_cat", B, h16, w16, 1280)
+        # image-pool branch first, so that in the backward program it is the LAST contributor to d(e)
+        pooled = Act(self, "gap", B, 1, 1, 2048)
+        HW = h16 * w16
+
+        def pool_fwd():
+            L.call("dc_avgpool_fwd", self.dt, B, HW, 2048, e.ptr, e.ld, pooled.ptr, self._st())
+
+        self.fwd_train.append(pool_fwd)
+        self.fwd_eval.append(pool_fwd)
+
+        def pool_bwd_make():
+            dg = pooled.grad
+            mode = e.take_grad_mode()
+            assert mode == 1, "avg-pool backward accumulates: another branch must have written d(e) first"
+            de = e.grad
+
+            def bwd():
+                L.call("dc_avgpool_bwd_add", self.dt, B, HW, 2048, dg.ptr, de.ptr, de.ld, self._st())
+            return bwd, []
+
+        self.bwd.append(pool_bwd_make)
+        yg, slab, rows = self._conv(pooled, "global_avg_pool.1.weight", 256, name="gap.conv")
+        ag = self._bn(yg, slab, rows, "global_avg_pool.2", True)
+        bslice = cat1.slice("aspp5", 1024, 256)
+
+        def bc_fwd():
+            L.call("dc_broadcast_hw", self.dt, B, HW, 256, ag.ptr, bslice.ptr, bslice.ld, self._st())
+
+        self.fwd_train.append(bc_fwd)
+        self.fwd_eval.append(bc_fwd)
+
+        def bc_bwd_make():
+            ds = bslice.grad
+            assert ag.take_grad_mode() == 0
+            dag = ag.grad
+
+            def bwd():
+                L.call("dc_sum_hw", self.dt, B, HW, 256, ds.ptr, ds.ld, dag.ptr, self._st())
+            return bwd, []
+
+        self.bwd.append(bc_bwd_make)
+        for i, rate in enumerate(S.ASPP_RATES, start=1):
+            k, pad = (1, 0) if rate == 1 else (3, rate)
+            y, slab, rows = self._conv(e, f"aspp{i}.atrous_convolution.weight", 256, k=k, pad=pad, dil=rate, name=f"aspp{i}.conv")
+            self._bn(y, slab, rows, f"aspp{i}.bn", True, out=cat1.slice(f"aspp{i}", 256 * (i - 1), 256))
+        y, slab, rows = self._conv(cat1, "conv1.weight", 256, name="proj")
+        p = self._bn(y, slab, rows, "bn1", True)
+
+        # ---- decoder
+        cat2 = Act(self, "dec_cat", B, H // 4, W // 4, 304)
+        yl, slab, rows = self._conv(low, "conv2.weight", 48, name="lowproj")
+        self._bn(yl, slab, rows, "bn2", True, out=cat2.slice("low48", 256, 48))
+        U = "upsample."
+        y, slab, rows = self._conv(p, U + "deconv1.0.weight", 256, transposed=True, name="deconv1")
+        a = self._bn(y, slab, rows, U + "deconv1.1", True)
+        y, slab, rows = self._conv(a, U + "deconv2.0.weight", 256, transposed=True, name="deconv2")
+        self._bn(y, slab, rows, U + "deconv2.1", True, out=cat2.slice("up256", 0, 256))
+        y, slab, rows = self._conv(cat2, U + "conv1.0.weight", 256, k=3, pad=1, name="dec.conv0")
+        a = self._bn(y, slab, rows, U + "conv1.1", True)
+        y, slab, rows = self._conv(a, U + "conv1.3.weight", 256, k=3, pad=1, name="dec.conv3")
+        a = self._bn(y, slab, rows, U + "conv1.4", True)
+        y, _, _ = self._conv(a, U + "conv1.6.weight", 256, stats=False, bias=U + "conv1.6.bias", name="dec.conv6")
+        y, slab, rows = self._conv(y, U + "deconv3.0.weight", 256, transposed=True, name="deconv3")
+        a = self._bn(y, slab, rows, U + "deconv3.1", True)
+
+        # ---- classifier head -> NCHW fp32 logits
+        wl = U + "last_deconv.0.weight"
+        self._need_ws(lib.dc_head_wgrad_workspace(B, 256, a.H, a.W))
+
+        def head_fwd():
+            L.call("dc_head_fwd", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, self.pptr(wl), L.dptr(self.logits), self._st())
+
+        self.fwd_train.append(head_fwd)
+        self.fwd_eval.append(head_fwd)
+
+        def head_bwd_make():
+            assert a.take_grad_mode() == 0
+            da = a.grad
+
+            def bwd():
+                L.call("dc_head_wgrad", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, L.dptr(self.dlogits), self._wsptr(), self.gptr(wl), self._st())
+                L.call("dc_head_dgrad", self.dt, B, 256, a.H, a.W, L.dptr(self.dlogits), self.pptr(wl), da.ptr, da.ld, self._st())
+            return bwd, [wl]
+
+        self.bwd.append(head_bwd_make)
+
+        # ---- resolve the backward program in reverse order (fixes write/accumulate modes of every gradient)
+        makers = self.bwd
+        self.bwd = []
+        self.grad_ready = []
+        for mk in reversed(makers):
+            fn, ready = mk()
+            self.bwd.append(fn)
+            self.grad_ready.append(ready)
+        seen = [n for r in self.grad_ready for n in r]
+        assert sorted(seen) == sorted(self.layout.params), "every parameter must receive its gradient exactly once"
+
+    # ------------------------------------------------------------------------------------------------ execution
+    def pack_weights(self) -> None:
+        for op in self.pack_ops:
+            op()
+        self.packed_version = self.version[0]
+
+    def mark_weights_changed(self) -> None:
+        self.version[0] += 1
+
+    def forward(self, x_nchw: torch.Tensor, train: bool = True) -> torch.Tensor:
+        """logits[B,3,H,W] (fp32, NCHW) = net(x[B,16,H,W]); returns the engine-owned logits buffer."""
+        if tuple(x_nchw.shape) != (self.B, self.n_input, self.H, self.W):
+            raise L.DeepcamHipError(f"engine built for input {(self.B, self.n_input, self.H, self.W)}, got {tuple(x_nchw.shape)}")
+        if train and self.B * (self.H // 16) * (self.W // 16) < 1:
+            raise ValueError("empty batch")
+        if train and self.B < 2:
+            # the image-pool BatchNorm sees B values per channel (deeplab_xception.py:425-428,449)
+            raise ValueError("Expected more than 1 value per channel when training, got input size torch.Size([1, 256, 1, 1])")
+        if x_nchw.dtype != torch.float32 or not x_nchw.is_contiguous() or x_nchw.device != self.device:
+            x_nchw = x_nchw.to(device=self.device, dtype=torch.float32).contiguous()
+        self.x_in = x_nchw
+        if self.packed_version != self.version[0]:
+            self.pack_weights()
+        for op in (self.fwd_train if train else self.fwd_eval):
+            op()
+        return self.logits
+
+    def backward(self) -> None:
+        """Consumes self.dlogits (NCHW fp32); leaves every parameter gradient in self.grads."""
+        cb = self.on_grad_ready
+        for op, ready in zip(self.bwd, self.grad_ready):
+            op()
+            if cb is not None and ready:
+                cb(ready)
