@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""DeepCAM train-step benchmark on MI355X: samples/s of forward + weighted CE + backward + gradient all-reduce + optimizer
+on synthetic 768x1152x16 batches resident in HBM, plus the MFMA-roofline fraction of the dominant kernel and a CPU
+baseline (the oracle restatement of the reference step on the node's host cores).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU; weak scaling (local batch fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_PER_SAMPLE = 1963.97e9      # conv fwd + dgrad + wgrad, 2*MAC, BASELINE.md section 2
+PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}
+CLASS_FREQ = (0.986267818390377, 0.0004578708870701058, 0.01327431072255291)
+
+
+def synthetic_batch(B, H, W, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 16, H, W, generator=g)
+    y = torch.multinomial(torch.tensor(CLASS_FREQ), B * H * W, replacement=True, generator=g).view(B, H, W)
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(local_batch, H, W, budget_s=30.0):
+    """Oracle train step (forward, loss, backward, Adam) on the host cores.  Bounded: a quarter-area step is timed first;
+    the full-size step is run only if it is predicted to fit the budget, otherwise the quarter-area rate is scaled by area."""
+    from oracle import loss_metric as olm, model as omodel, optim as ooptim     # timed as the baseline, never shipped
+    cw = olm.class_weights(-0.125)
+    threads = torch.get_num_threads()
+
+    def one(h, w, warm):
+        sd = omodel.init_state(333)
+        keys = omodel.param_keys(sd)
+        params = [sd[k].requires_grad_(True) for k in keys]
+        opt = ooptim.OracleOptimizer([p.detach() for p in params], "Adam", lr=1e-3, eps=1e-8, weight_decay=1e-6)
+        g = torch.Generator().manual_seed(1234)
+        x = torch.rand(local_batch, 16, h, w, generator=g)
+        y = torch.randint(0, 3, (local_batch, h, w), generator=g)
+        ts = []
+        for _ in range(warm + 1):
+            t0 = time.perf_counter()
+            for p in params:
+                p.grad = None
+            loss = olm.fp_loss(omodel.forward(sd, x, training=True), y, cw)
+            loss.backward()
+            opt.step([p.grad for p in params])
+            ts.append(time.perf_counter() - t0)
+        return ts[-1]
+
+    one(64, 96, 0)                                     # thread-pool / allocator warm-up
+    tq = one(H // 2, W // 2, 1)
+    if 4.0 * tq * 1.2 <= budget_s:
+        tf = one(H, W, 0)
+        return {"value": local_batch / tf, "unit": "samples/s", "cores": threads, "kind": "port",
+                "sample": f"1 full train step (fwd+loss+bwd+Adam) of the oracle, B={local_batch} {H}x{W} fp32, {tf:.2f} s"}
+    return {"value": local_batch / (4.0 * tq), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"1 warmed train step of the oracle at B={local_batch} {H // 2}x{W // 2} fp32 ({tq:.2f} s), scaled x4 by pixel count"}
+
+
+class KernelTimer:
+    """HIP-event timing of every launch of the dominant kernel family (dense-conv implicit GEMM: dc_conv_fwd and
+    dc_conv_dgrad both launch dc::igemm_kernel<T>) on the stream the kernels run on."""
+
+    def __init__(self, lib_module):
+        self.L = lib_module
+        self.events = []
+        self.flops = 0.0
+        self._orig = lib_module.call
+
+    def __enter__(self):
+        L = self.L
+        timer = self
+
+        def call(name, *args):
+            if name in ("dc_conv_fwd", "dc_conv_dgrad"):
+                d = args[0]._obj
+                N, Hi, Wi = args[1], args[2], args[3]
+                k = 3 if d.transposed else d.k
+                if d.transposed:
+                    macs = N * Hi * Wi * d.cin * d.cout * 9
+                else:
+                    Ho = (Hi + 2 * d.pad - d.dil * (k - 1) - 1) // d.stride + 1
+                    Wo = (Wi + 2 * d.pad - d.dil * (k - 1) - 1) // d.stride + 1
+                    macs = N * Ho * Wo * d.cin * d.cout * k * k
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                timer._orig(name, *args)
+                e1.record()
+                timer.events.append((e0, e1))
+                timer.flops += 2.0 * macs
+            else:
+                timer._orig(name, *args)
+
+        L.call = call
+        import mlperf_deepcam_amd.engine as E
+        import mlperf_deepcam_amd.nn as NN
+        self._mods = (E.L, NN.L)
+        return self
+
+    def __exit__(self, *exc):
+        self.L.call = self._orig
+
+    def result(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        return self.flops, ms * 1e-3, len(self.events)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--local_batch_size", type=int, default=2)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--optimizer", choices=["Adam", "AdamW", "LAMB"], default="AdamW")
+    ap.add_argument("--height", type=int, default=768)
+    ap.add_argument("--width", type=int, default=1152)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mlperf_deepcam_amd import lib as L, nn as dnn
+    from mlperf_deepcam_amd import dist as ddist
+
+    B, H, W = a.local_batch_size, a.height, a.width
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=dtype, seed=333)
+    net.materialize(B, H, W)
+    net.train()
+    wd = 1e-2 if a.optimizer != "Adam" else 1e-6
+    opt = dnn.make_optimizer(a.optimizer, net, 1e-3, 1e-8, wd)
+    step = dnn.TrainStep(net, opt, dnn.class_weights(-0.125), B, H, W, with_metrics=False)
+    reducer = None
+    if world > 1:
+        reducer = ddist.GradReducer(net.engine, world)
+        reducer.broadcast_parameters()
+        step.after_backward = reducer.finish
+        opt.grad_scale = 1.0 / world
+    x, y = synthetic_batch(B, H, W, 1234 + rank, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(x, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(x, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = step.loss()
+    sps = a.steps * B * world / dt
+
+    # ---- roofline of the dominant kernel family, timed per launch with HIP events on the launch stream ----------------
+    roof = None
+    if rank == 0:
+        with KernelTimer(L) as kt:
+            for _ in range(min(a.steps, 3)):
+                step(x, y)
+            flops, secs, n = kt.result()
+        peak = PEAK[a.dtype]
+        ach = flops / secs if secs > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "kernel": f"dc::igemm_kernel<{a.dtype}> (dense conv fwd + dgrad)",
+                "launches_timed": n, "avg_launch_us": round(secs / max(n, 1) * 1e6, 2),
+                "whole_step_frac": round(sps / world * FLOP_PER_SAMPLE * (H * W) / (768 * 1152) / peak, 4)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        out = {"metric": "samples/sec (768x1152x16) train step", "value": round(sps, 3), "unit": "samples/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": f"DeepLabV3+/Xception train step (fwd + weighted CE + bwd + {a.optimizer}"
+                                      f"{' + RCCL grad all-reduce' if world > 1 else ''}), {H}x{W}x16, local_batch={B}, "
+                                      f"{a.dtype} activations / fp32 master weights, random-init seed 333",
+                          "local_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": a.optimizer,
+                          "hip_graph": False},
+               "loss_last_step": round(loss, 6), "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(B, H, W)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

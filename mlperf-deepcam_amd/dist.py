@@ -1,0 +1,173 @@
+"""Data parallelism: rank wire-up (reference utils/comm.py:26-113) and the gradient all-reduce that apex/torch DDP does
+implicitly at train_hdf5_ddp.py:227,363 -- here explicit, zero-copy and overlapped with backward.
+
+Design for xGMI (point-to-point links, ring collectives per-link bound): all 301 gradients already live in ONE flat fp32
+arena in parameter order, and backward finishes them roughly from the arena's end to its start.  Buckets are therefore
+plain contiguous arena ranges (no gather/scatter copies): as soon as the last gradient of a range has been written, the
+range is handed to RCCL (``all_reduce(SUM)`` on the process group's own stream, which first waits for the compute stream's
+current position) while backward keeps running.  ``finish()`` makes the compute stream wait for the outstanding
+collectives; the 1/world averaging is folded into the optimizer kernel (grad_scale).  BatchNorm statistics stay per
+rank, as in the reference (no SyncBN).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# wire-up (same method names as the reference, plus "env" for torchrun-style launches)
+# ---------------------------------------------------------------------------------------------------------------------
+def get_rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def get_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_local_rank() -> int:
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    if "LOCAL_RANK" in os.environ:
+        return int(os.environ["LOCAL_RANK"])
+    n = torch.cuda.device_count()
+    return dist.get_rank() % n if n > 0 else 0                       # comm.py:45-46
+
+
+def init(method: str, backend: Optional[str] = None) -> None:
+    """comm.init: derive rank / world / master from the launcher's environment and bring up the process group.
+    'nccl' is RCCL on ROCm.  `backend` overrides (tests use gloo on CPU)."""
+    if method == "nccl-openmpi":
+        addrport = os.getenv("PMIX_SERVER_URI2").split("//")[1]
+        os.environ["MASTER_ADDR"] = addrport.split(":")[0]
+        os.environ["MASTER_PORT"] = "29500"
+        rank = int(os.getenv("OMPI_COMM_WORLD_RANK", 0))
+        world = int(os.getenv("OMPI_COMM_WORLD_SIZE", 0))
+    elif method == "nccl-slurm":
+        rank, world = int(os.getenv("PMIX_RANK")), int(os.getenv("SLURM_NTASKS"))
+        os.environ["MASTER_ADDR"] = os.getenv("SLURM_LAUNCH_NODE_IPADDR")
+        os.environ["MASTER_PORT"] = "29500"
+    elif method == "nccl-slurm-pmi":
+        rank, world = int(os.getenv("PMI_RANK")), int(os.getenv("SLURM_NTASKS"))
+        os.environ["MASTER_ADDR"] = os.getenv("SLURM_LAUNCH_NODE_IPADDR")
+        os.environ["MASTER_PORT"] = "29500"
+    elif method == "mpi":
+        dist.init_process_group(backend="mpi")
+        return
+    elif method == "env":
+        rank, world = int(os.getenv("RANK", 0)), int(os.getenv("WORLD_SIZE", 1))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+    elif method == "single":
+        return
+    else:
+        raise NotImplementedError()
+    dist.init_process_group(backend=backend or "nccl", rank=rank, world_size=world)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bucketed, overlapped gradient all-reduce over contiguous arena ranges
+# ---------------------------------------------------------------------------------------------------------------------
+class Bucket:
+    __slots__ = ("lo", "hi", "names", "remaining", "work")
+
+    def __init__(self, lo: int, hi: int, names: List[str]):
+        self.lo, self.hi, self.names = lo, hi, names
+        self.remaining = len(names)
+        self.work = None
+
+
+def plan_buckets(param_offsets: "Dict[str, tuple]", total: int, bucket_elems: int) -> List[Bucket]:
+    """Cut [0,total) at tensor boundaries into ranges of about bucket_elems, walking from the END of the arena (the part
+    backward finishes first) so that the last, possibly short, bucket is the one that completes last."""
+    items = sorted(((off, n, name) for name, (off, n) in param_offsets.items()), reverse=True)
+    buckets: List[Bucket] = []
+    hi, names, size = total, [], 0
+    for off, n, name in items:
+        names.append(name)
+        size += n
+        if size >= bucket_elems:
+            buckets.append(Bucket(off, hi, names))
+            hi, names, size = off, [], 0
+    if names:
+        buckets.append(Bucket(0, hi, names))
+    return buckets
+
+
+class GradReducer:
+    def __init__(self, engine, world: int, bucket_mb: float = 32.0, group=None):
+        self.eng, self.world, self.group = engine, world, group
+        lay = engine.layout
+        import math
+        offs = {name: (p.offset, math.prod(p.shape)) for name, p in lay.params.items()}
+        self.buckets = plan_buckets(offs, lay.n_params, int(bucket_mb * 2 ** 20 / 4))
+        self.of: Dict[str, Bucket] = {n: b for b in self.buckets for n in b.names}
+        covered = sum(b.hi - b.lo for b in self.buckets)
+        assert covered == lay.n_params and all(b.hi > b.lo for b in self.buckets)
+        engine.on_grad_ready = self.ready
+        self.launched = 0
+
+    def reset(self) -> None:
+        for b in self.buckets:
+            b.remaining = len(b.names)
+            b.work = None
+        self.launched = 0
+
+    def ready(self, names: List[str]) -> None:
+        """Engine callback: these parameters' gradients have just been enqueued (final values) on the compute stream."""
+        for n in names:
+            b = self.of[n]
+            b.remaining -= 1
+            if b.remaining == 0:
+                # the process group's stream waits for everything enqueued so far on the current stream, then reduces
+                b.work = dist.all_reduce(self.eng.grads[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.launched += 1
+
+    def finish(self) -> None:
+        """Order the optimizer behind all outstanding collectives (stream-side wait on GPU; blocking on CPU/gloo)."""
+        for b in self.buckets:
+            assert b.remaining == 0, f"bucket [{b.lo},{b.hi}) never completed: {b.remaining} gradients missing"
+            if b.work is not None:
+                b.work.wait()
+        self.reset()
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """DDP construction semantics (train_hdf5_ddp.py:227): every rank starts from rank 0's weights and BN buffers."""
+        dist.broadcast(self.eng.params, src=src, group=self.group)
+        dist.broadcast(self.eng.buffers, src=src, group=self.group)
+        dist.broadcast(self.eng.nbt, src=src, group=self.group)
+        if hasattr(self.eng, "mark_weights_changed"):
+            self.eng.mark_weights_changed()
+
+
+class DistributedDataParallel(torch.nn.Module):
+    """The wrapper the reference applies at train_hdf5_ddp.py:227: forwards to the module, prefixes state-dict keys with
+    'module.' (checkpoint format, :521) and averages gradients across ranks during backward."""
+
+    def __init__(self, module, bucket_mb: float = 32.0):
+        super().__init__()
+        self.module = module
+        self.reducer = None
+        self._bucket_mb = bucket_mb
+        if get_size() > 1 and module.engine is not None:
+            self._attach()
+
+    def _attach(self):
+        self.reducer = GradReducer(self.module.engine, get_size(), self._bucket_mb)
+        self.reducer.broadcast_parameters()
+
+    def forward(self, *args, **kw):
+        if self.reducer is None and get_size() > 1 and self.module.engine is not None:
+            self._attach()
+        return self.module.forward(*args, **kw)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        return self.module.load_state_dict(state_dict, strict=strict)
+
+    def state_dict(self, *args, **kw):
+        from collections import OrderedDict
+        return OrderedDict(("module." + k, v) for k, v in self.module.state_dict(*args, **kw).items())

@@ -1,0 +1,296 @@
+"""train_hdf5_ddp.py-compatible driver for the MI355X engine.
+
+Same command line as the reference (src/deepCam/train_hdf5_ddp.py:548-578, flag for flag), same step order (:345-371),
+same logging-frequency reductions (:398-414), validation averaging (:423-512: mean of per-sample IoUs at batch 1),
+checkpoint dictionary (:515-527: step, epoch, model with 'module.'-prefixed keys, optimizer) and ``:::MLLOG`` event keys
+(utils/mlperf_log_utils.py).  Out of scope by SURVEY section 8: W&B, Basemap plots (flags accepted, ignored) and the HDF5
+reader (section 8f, next): without h5py the driver runs on synthetic batches (``--synthetic_samples``).
+
+Extra flags (not in the reference): --wireup_method env|single, --dtype, --synthetic_samples, --height/--width, --max_steps.
+"""
+from __future__ import annotations
+
+import argparse as ap
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import dist as comm
+from . import nn as dnn
+
+
+class StoreDictKeyPair(ap.Action):
+    def __call__(self, parser, namespace, values, option_string=None):
+        d = {}
+        for kv in values.split(","):
+            k, v = kv.split("=")
+            d[k] = v.strip('"')
+        setattr(namespace, self.dest, d)
+
+
+class MLLogger:
+    """Writes the mlperf_logging line format directly (the package is not a dependency here): rank 0 only, optional
+    barrier before the event (mlperf_log_utils.py:92-105)."""
+
+    def __init__(self, filename, benchmark="deepcam", org="MI355X-native"):
+        self.rank = comm.get_rank()
+        self.f = None
+        if self.rank == 0:
+            os.makedirs(os.path.dirname(filename), exist_ok=True)
+            self.f = open(filename, "a")
+        self.barrier()
+        for k, v in (("submission_benchmark", benchmark), ("submission_org", org), ("submission_division", "closed"),
+                     ("submission_status", "onprem"), ("submission_platform", "1xMI355X")):
+            self.log_event(k, v)
+
+    @staticmethod
+    def barrier():
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+
+    def _emit(self, etype, key, value, metadata, sync):
+        if sync:
+            self.barrier()
+        if self.rank != 0:
+            return
+        rec = {"namespace": "", "time_ms": int(time.time() * 1000), "event_type": etype, "key": key, "value": value,
+               "metadata": metadata or {}}
+        line = ":::MLLOG " + json.dumps(rec)
+        print(line, flush=True)
+        self.f.write(line + "\n")
+        self.f.flush()
+
+    def log_start(self, key, value=None, metadata=None, sync=False):
+        self._emit("INTERVAL_START", key, value, metadata, sync)
+
+    def log_end(self, key, value=None, metadata=None, sync=False):
+        self._emit("INTERVAL_END", key, value, metadata, sync)
+
+    def log_event(self, key, value=None, metadata=None, sync=False):
+        self._emit("POINT_IN_TIME", key, value, metadata, sync)
+
+
+class SyntheticSet:
+    """Stand-in for CamDataset (data/cam_hdf5_dataset.py) with the same sharding rule (:43-62): `global_size` samples,
+    rank r owns a contiguous slice; samples are seeded by their global index so every rank count sees the same data."""
+
+    def __init__(self, global_size, H, W, comm_size, comm_rank, allow_uneven, base_seed):
+        self.global_size, self.H, self.W = global_size, H, W
+        n = global_size // comm_size
+        if allow_uneven and comm_rank == comm_size - 1:
+            self.start, self.local_size = n * comm_rank, global_size - n * comm_rank
+        else:
+            self.start, self.local_size = n * comm_rank, n
+        self.base_seed = base_seed
+
+    def batch(self, first, count, device):
+        xs, ys, names = [], [], []
+        for i in range(first, first + count):
+            g = torch.Generator().manual_seed(self.base_seed + self.start + i)
+            xs.append(torch.rand(16, self.H, self.W, generator=g))
+            ys.append(torch.multinomial(torch.tensor(dnn.CLASS_FREQ), self.H * self.W, replacement=True, generator=g).view(self.H, self.W))
+            names.append(f"data-synthetic-{self.start + i:06d}.h5")
+        return torch.stack(xs).to(device, non_blocking=True), torch.stack(ys).to(device, non_blocking=True), names
+
+    def loader(self, batch_size, device):
+        for b in range(self.local_size // batch_size):                 # drop_last=True (train_hdf5_ddp.py:289,306)
+            yield self.batch(b * batch_size, batch_size, device)
+
+
+def build_parser():
+    AP = ap.ArgumentParser()
+    AP.add_argument("--wireup_method", type=str, default="nccl-openmpi",
+                    choices=["nccl-openmpi", "nccl-slurm", "nccl-slurm-pmi", "mpi", "env", "single"], help="Specify what is used for wiring up the ranks")
+    AP.add_argument("--wandb_certdir", type=str, default="/opt/certs", help="accepted for compatibility; W&B is out of scope")
+    AP.add_argument("--run_tag", type=str, help="Unique run tag, to allow for better identification")
+    AP.add_argument("--output_dir", type=str, help="Directory used for storing output. Needs to read/writeable from rank 0")
+    AP.add_argument("--checkpoint", type=str, default=None, help="Checkpoint file to restart training from.")
+    AP.add_argument("--data_dir_prefix", type=str, default="/", help="prefix to data dir")
+    AP.add_argument("--max_inter_threads", type=int, default=1, help="Maximum number of concurrent readers")
+    AP.add_argument("--max_epochs", type=int, default=30, help="Maximum number of epochs to train")
+    AP.add_argument("--save_frequency", type=int, default=100, help="Frequency with which the model is saved in number of steps")
+    AP.add_argument("--validation_frequency", type=int, default=100, help="Frequency with which the model is validated")
+    AP.add_argument("--max_validation_steps", type=int, default=None, help="Number of validation steps to perform (invalidates a submission)")
+    AP.add_argument("--logging_frequency", type=int, default=100, help="Frequency with which the training progress is logged")
+    AP.add_argument("--training_visualization_frequency", type=int, default=50, help="accepted; plotting is out of scope (0 = off)")
+    AP.add_argument("--validation_visualization_frequency", type=int, default=50, help="accepted; plotting is out of scope (0 = off)")
+    AP.add_argument("--local_batch_size", type=int, default=1, help="Number of samples per local minibatch")
+    AP.add_argument("--channels", type=int, nargs="+", default=list(range(16)), help="Channels used in input")
+    AP.add_argument("--optimizer", type=str, default="Adam", choices=["Adam", "AdamW", "LAMB"], help="Optimizer to use")
+    AP.add_argument("--start_lr", type=float, default=1e-3, help="Start LR")
+    AP.add_argument("--adam_eps", type=float, default=1e-8, help="Adam Epsilon")
+    AP.add_argument("--weight_decay", type=float, default=1e-6, help="Weight decay")
+    AP.add_argument("--loss_weight_pow", type=float, default=-0.125, help="Decay factor to adjust the weights")
+    AP.add_argument("--lr_warmup_steps", type=int, default=0, help="Number of steps for linear LR warmup")
+    AP.add_argument("--lr_warmup_factor", type=float, default=1.0, help="Multiplier for linear LR warmup")
+    AP.add_argument("--lr_schedule", action=StoreDictKeyPair)
+    AP.add_argument("--target_iou", type=float, default=0.82, help="Target IoU score.")
+    AP.add_argument("--model_prefix", type=str, default="model", help="Prefix for the stored model")
+    AP.add_argument("--amp_opt_level", type=str, default="O0", help="O0 = fp32 activations, O1/O2 = bf16 activations (no loss scaling needed)")
+    AP.add_argument("--enable_wandb", action="store_true")
+    AP.add_argument("--resume_logging", action="store_true")
+    # extensions
+    AP.add_argument("--dtype", type=str, default=None, choices=["fp32", "bf16"], help="overrides --amp_opt_level")
+    AP.add_argument("--synthetic_samples", type=int, default=0, help="train on this many synthetic samples instead of HDF5 files")
+    AP.add_argument("--height", type=int, default=768)
+    AP.add_argument("--width", type=int, default=1152)
+    AP.add_argument("--max_steps", type=int, default=None)
+    return AP
+
+
+def main(pargs):
+    comm.init(pargs.wireup_method)
+    rank, local_rank, size = comm.get_rank(), comm.get_local_rank(), comm.get_size()
+    pargs.logging_frequency = max([pargs.logging_frequency, 1])                               # train_hdf5_ddp.py:106
+    log_file = os.path.normpath(os.path.join(pargs.output_dir, "logs", pargs.run_tag + ".log"))
+    logger = MLLogger(log_file)
+    logger.log_start(key="init_start", sync=True)
+    logger.log_event(key="cache_clear")
+    seed = 333
+    logger.log_event(key="seed", value=seed)
+    torch.manual_seed(seed)
+    if not torch.cuda.is_available():
+        raise RuntimeError("mlperf_deepcam_amd.train needs an MI355X: there is no CPU path")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.manual_seed(seed)
+    torch.cuda.set_device(device)
+    if rank == 0:
+        os.makedirs(pargs.output_dir, exist_ok=True)
+
+    logger.log_event(key="global_batch_size", value=pargs.local_batch_size * size)
+    logger.log_event(key="opt_name", value=pargs.optimizer)
+    logger.log_event(key="opt_base_learning_rate", value=pargs.start_lr * pargs.lr_warmup_factor)
+    logger.log_event(key="opt_learning_rate_warmup_steps", value=pargs.lr_warmup_steps)
+    logger.log_event(key="opt_learning_rate_warmup_factor", value=pargs.lr_warmup_factor)
+    logger.log_event(key="opt_epsilon", value=pargs.adam_eps)
+
+    dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[pargs.dtype] if pargs.dtype else \
+        (torch.float32 if pargs.amp_opt_level == "O0" else torch.bfloat16)
+    H, W, B = pargs.height, pargs.width, pargs.local_batch_size
+    net = dnn.DeepLabv3_plus(n_input=len(pargs.channels), n_classes=3, os=16, pretrained=False, rank=rank, dtype=dtype)
+    net.to(device)
+    net.materialize(B, H, W)
+    class_weights = dnn.class_weights(pargs.loss_weight_pow)
+    optimizer = dnn.make_optimizer(pargs.optimizer, net, pargs.start_lr, pargs.adam_eps, pargs.weight_decay)
+    ddp = comm.DistributedDataParallel(net)
+    if ddp.reducer is not None:
+        optimizer.grad_scale = 1.0 / size
+
+    if pargs.checkpoint:
+        checkpoint = torch.load(pargs.checkpoint, map_location=device, weights_only=False)
+        start_step, start_epoch = checkpoint["step"], checkpoint["epoch"]
+        optimizer.load_state_dict(checkpoint["optimizer"])
+        ddp.load_state_dict(checkpoint["model"])
+    else:
+        start_step, start_epoch = 0, 0
+
+    scheduler = None
+    if pargs.lr_schedule:
+        scheduler_after = dnn.get_lr_schedule(pargs.start_lr, pargs.lr_schedule, optimizer, last_step=start_step)
+        scheduler = scheduler_after
+        if pargs.lr_warmup_steps > 0:
+            scheduler = dnn.GradualWarmupScheduler(optimizer, multiplier=pargs.lr_warmup_factor, total_epoch=pargs.lr_warmup_steps,
+                                                   after_scheduler=scheduler_after)
+    if size > 1:
+        steptens = torch.tensor(np.array([start_step, start_epoch]), requires_grad=False).to(device)
+        dist.broadcast(steptens, src=0)
+        start_step, start_epoch = int(steptens[0]), int(steptens[1])
+
+    if pargs.synthetic_samples <= 0:
+        try:
+            import h5py  # noqa: F401
+        except ImportError:
+            raise RuntimeError("the HDF5 reader (SURVEY section 8f, next) needs h5py, which this image lacks: "
+                               "use --synthetic_samples N") from None
+        raise NotImplementedError("HDF5 input pipeline is the next scope row (SURVEY section 8f)")
+    train_set = SyntheticSet(pargs.synthetic_samples, H, W, size, rank, False, base_seed=12345)
+    n_val = max(size, pargs.synthetic_samples // 8)
+    validation_set = SyntheticSet(n_val, H, W, size, rank, True, base_seed=54321)
+    logger.log_event(key="train_samples", value=train_set.global_size)
+    val_size = validation_set.global_size if pargs.max_validation_steps is None else \
+        min([validation_set.global_size, pargs.max_validation_steps * B * size])
+    logger.log_event(key="eval_samples", value=val_size)
+    if pargs.max_validation_steps is not None:
+        logger.log_event(key="invalid_submission")
+
+    train_step = dnn.TrainStep(net, optimizer, class_weights, B, H, W, with_metrics=True)
+    if ddp.reducer is not None:
+        train_step.after_backward = ddp.reducer.finish
+    step, epoch = start_step, start_epoch
+    current_lr = pargs.start_lr if scheduler is None else scheduler.get_last_lr()[0]
+    stop_training = False
+    net.train()
+    logger.log_end(key="init_stop", sync=True)
+    logger.log_start(key="run_start", sync=True)
+
+    while True:
+        logger.log_start(key="epoch_start", metadata={"epoch_num": epoch + 1, "step_num": step}, sync=True)
+        for inputs, label, filename in train_set.loader(B, device):
+            train_step(inputs, label)                          # forward, loss, backward (+all-reduce), optimizer.step
+            step += 1
+            if scheduler is not None:
+                current_lr = scheduler.get_last_lr()[0]
+                scheduler.step()
+            if step % pargs.logging_frequency == 0:
+                vals = torch.tensor([train_step.loss(), train_step.iou()], dtype=torch.float32, device=device)
+                if size > 1:
+                    dist.reduce(vals, dst=0, op=dist.ReduceOp.SUM)
+                loss_avg_train, iou_avg_train = (vals / float(size)).tolist()
+                md = {"epoch_num": epoch + 1, "step_num": step}
+                logger.log_event(key="learning_rate", value=current_lr, metadata=md)
+                logger.log_event(key="train_accuracy", value=iou_avg_train, metadata=md)
+                logger.log_event(key="train_loss", value=loss_avg_train, metadata=md)
+            if step % pargs.validation_frequency == 0:
+                logger.log_start(key="eval_start", metadata={"epoch_num": epoch + 1})
+                net.eval()
+                sums = torch.zeros(3, dtype=torch.float64, device=device)            # count, loss, iou
+                with torch.no_grad():
+                    step_val = 0
+                    for inputs_val, label_val, _ in validation_set.loader(1, device):
+                        outputs_val = net.forward(inputs_val)
+                        counts = torch.zeros(9, dtype=torch.int64, device=device)
+                        ls = dnn.wce_fused(outputs_val, label_val, class_weights, counts=counts)
+                        sums[0] += 1.0
+                        sums[1] += ls[0] / label_val.numel()
+                        sums[2] += dnn.iou_from_counts(counts.cpu().tolist())          # per-sample IoU, then averaged
+                        step_val += 1
+                        if pargs.max_validation_steps is not None and step_val > pargs.max_validation_steps:
+                            break
+                if size > 1:
+                    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+                loss_avg_val, iou_avg_val = float(sums[1] / sums[0]), float(sums[2] / sums[0])
+                md = {"epoch_num": epoch + 1, "step_num": step}
+                logger.log_event(key="eval_accuracy", value=iou_avg_val, metadata=md)
+                logger.log_event(key="eval_loss", value=loss_avg_val, metadata=md)
+                if iou_avg_val >= pargs.target_iou:
+                    logger.log_event(key="target_accuracy_reached", value=pargs.target_iou, metadata=md)
+                    stop_training = True
+                net.train()
+                logger.log_end(key="eval_stop", metadata={"epoch_num": epoch + 1})
+            if pargs.save_frequency > 0 and step % pargs.save_frequency == 0:
+                md = {"epoch_num": epoch + 1, "step_num": step}
+                logger.log_start(key="save_start", metadata=md, sync=True)
+                if rank == 0:
+                    checkpoint = {"step": step, "epoch": epoch, "model": ddp.state_dict(), "optimizer": optimizer.state_dict()}
+                    torch.save(checkpoint, os.path.join(pargs.output_dir, pargs.model_prefix + "_step_" + str(step) + ".cpt"))
+                logger.log_end(key="save_stop", metadata=md, sync=True)
+            if pargs.max_steps is not None and step >= pargs.max_steps:
+                stop_training = True
+            if stop_training:
+                break
+        logger.log_end(key="epoch_stop", metadata={"epoch_num": epoch + 1, "step_num": step}, sync=True)
+        epoch += 1
+        if epoch >= pargs.max_epochs or stop_training:
+            break
+    logger.log_end(key="run_stop", sync=True, metadata={"status": "success"})
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())
