@@ -165,7 +165,8 @@ int dc_confusion_counts(long n, const int64_t* pred, const void* labels, int lab
 
 /* ------------------------------------------------------------------------------------------------
  * Image-pool branch helpers (deeplab_xception.py:425,449-450): AdaptiveAvgPool2d((1,1)), the 1x1 ->
- * HxW "bilinear" broadcast and their backward passes.
+ * HxW "bilinear" broadcast and their backward passes.  The per-sample vectors ([N][C]: out, g, v below) are ALWAYS
+ * fp32 whatever `dtype` the NHWC side uses: the branch's BatchNorm sees only N values per channel.
  * ------------------------------------------------------------------------------------------------ */
 int dc_avgpool_fwd(int dtype, int N, int HW, int C, const void* x, int ldx, void* out /*[N][C]*/, void* stream);
 /* dx[n,p,c] += g[n,c] / HW */

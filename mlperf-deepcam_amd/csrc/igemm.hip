@@ -283,7 +283,7 @@ static int launch_igemm(const IgemmParams& p, hipStream_t st) {
   const size_t lds = ((size_t)(4 * OPER_BYTES) > (size_t)BM * CROW ? (size_t)(4 * OPER_BYTES) : (size_t)BM * CROW) + 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(cdiv(p.g.Cout, BN), p.mtiles, p.g.os * p.g.os);

@@ -4,9 +4,11 @@
 namespace dc {
 
 // out[n][c] = scale * sum_p x[n,p,c]     (AdaptiveAvgPool2d((1,1)) with scale = 1/HW; its transpose with scale = 1)
+// The per-sample vectors of the image-pool branch are ALWAYS fp32: its BatchNorm sees only B values per channel and a
+// bf16 rounding of two nearly equal values can flip the sign of the normalised output (SURVEY hard part 6).
 template <typename T>
 __global__ __launch_bounds__(256) void hw_reduce_kernel(int HW, int C, const T* __restrict__ x, int ldx, float scale,
-                                                        T* __restrict__ out) {
+                                                        float* __restrict__ out) {
   constexpr int KPV = Elem<T>::kPerVec;
   __shared__ float red[16][16 * KPV];
   const int cgl = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(256) void hw_reduce_kernel(int HW, int C, const T* 
       float s = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s += red[r][threadIdx.x];
-      Elem<T>::store(out + (size_t)n * C + c, s * scale);
+      out[(size_t)n * C + c] = s * scale;
     }
   }
 }
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(256) void hw_reduce_kernel(int HW, int C, const T* 
 // MODE 1: out[n,p,c] += v[n,c] * scale   (avg-pool backward, accumulating)
 // MODE 2: out[r,c]    = src[r,c]         (view copy; v is the source, HW rows per "n")
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void hw_ew_kernel(long rows, int HW, int C, const T* __restrict__ v, int ldv,
+__global__ __launch_bounds__(256) void hw_ew_kernel(long rows, int HW, int C, const void* __restrict__ vsrc, int ldv,
                                                     float scale, T* __restrict__ out, int ldo) {
   constexpr int KPV = Elem<T>::kPerVec;
   const int ngroups = C / KPV;
@@ -50,19 +52,22 @@ __global__ __launch_bounds__(256) void hw_ew_kernel(long rows, int HW, int C, co
     const long r = i / ngroups;
     const int c0 = cg * KPV;
     if (MODE == 2) {
-      stg16(out + (size_t)r * ldo + c0, ldg16(v + (size_t)r * ldv + c0));
+      stg16(out + (size_t)r * ldo + c0, ldg16(reinterpret_cast<const T*>(vsrc) + (size_t)r * ldv + c0));
     } else {
       const long n = r / HW;
-      vec16 src = ldg16(v + (size_t)n * C + c0);
+      const float* v = reinterpret_cast<const float*>(vsrc) + (size_t)n * C + c0;   // fp32 per-sample vector
+      float a[KPV];
+#pragma unroll
+      for (int e = 0; e < KPV; ++e) a[e] = v[e];
       if (MODE == 1) {
-        float a[KPV], b[KPV];
-        unpack(src, a, T());
+        float b[KPV];
         unpack(ldg16(out + (size_t)r * ldo + c0), b, T());
 #pragma unroll
-        for (int e = 0; e < KPV; ++e) b[e] = fmaf(a[e], scale, b[e]);
-        pack(src, b, T());
+        for (int e = 0; e < KPV; ++e) a[e] = fmaf(a[e], scale, b[e]);
       }
-      stg16(out + (size_t)r * ldo + c0, src);
+      vec16 res;
+      pack(res, a, T());
+      stg16(out + (size_t)r * ldo + c0, res);
     }
   }
 }
@@ -209,7 +214,7 @@ extern "C" int dc_avgpool_fwd(int dtype, int N, int HW, int C, const void* x, in
   hipStream_t st = (hipStream_t)stream;
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   dim3 grid(cdiv(C / kpv, 16), N);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(hw_reduce_kernel<T>, grid, dim3(256), 0, st, HW, C, (const T*)x, ldx, 1.0f / (float)HW, (T*)out));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(hw_reduce_kernel<T>, grid, dim3(256), 0, st, HW, C, (const T*)x, ldx, 1.0f / (float)HW, (float*)out));
   DC_CHECK_LAUNCH();
   return 0;
 }
@@ -220,7 +225,7 @@ extern "C" int dc_sum_hw(int dtype, int N, int HW, int C, const void* dout, int 
   hipStream_t st = (hipStream_t)stream;
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   dim3 grid(cdiv(C / kpv, 16), N);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(hw_reduce_kernel<T>, grid, dim3(256), 0, st, HW, C, (const T*)dout, lddo, 1.0f, (T*)g));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(hw_reduce_kernel<T>, grid, dim3(256), 0, st, HW, C, (const T*)dout, lddo, 1.0f, (float*)g));
   DC_CHECK_LAUNCH();
   return 0;
 }
@@ -232,7 +237,7 @@ extern "C" int dc_broadcast_hw(int dtype, int N, int HW, int C, const void* v, v
   const long rows = (long)N * HW;
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const int blocks = ew_blocks2(rows * (C / kpv));
-  DISPATCH_T(dtype, hipLaunchKernelGGL((hw_ew_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, rows, HW, C, (const T*)v, C, 1.f, (T*)out, ldo));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((hw_ew_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, rows, HW, C, v, C, 1.f, (T*)out, ldo));
   DC_CHECK_LAUNCH();
   return 0;
 }
@@ -244,7 +249,7 @@ extern "C" int dc_avgpool_bwd_add(int dtype, int N, int HW, int C, const void* g
   const long rows = (long)N * HW;
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const int blocks = ew_blocks2(rows * (C / kpv));
-  DISPATCH_T(dtype, hipLaunchKernelGGL((hw_ew_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, rows, HW, C, (const T*)g, C, 1.0f / (float)HW, (T*)dx, lddx));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((hw_ew_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, rows, HW, C, g, C, 1.0f / (float)HW, (T*)dx, lddx));
   DC_CHECK_LAUNCH();
   return 0;
 }
@@ -255,7 +260,7 @@ extern "C" int dc_copy_view(int dtype, long M, int C, const void* src, int lds, 
   hipStream_t st = (hipStream_t)stream;
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const int blocks = ew_blocks2(M * (C / kpv));
-  DISPATCH_T(dtype, hipLaunchKernelGGL((hw_ew_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, M, 1, C, (const T*)src, lds, 1.f, (T*)dst, ldd));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((hw_ew_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, M, 1, C, src, lds, 1.f, (T*)dst, ldd));
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -69,7 +69,7 @@ class Act:
                 self._grad = Act(self.eng, "d" + self.name, self.N, self.H, self.W, self.C, parent=self.parent.grad,
                                  off=self.off - self.parent.off)
             else:
-                self._grad = Act(self.eng, "d" + self.name, self.N, self.H, self.W, self.C)
+                self._grad = Act(self.eng, "d" + self.name, self.N, self.H, self.W, self.C, dtype=self.buf.dtype)
         return self._grad
 
     def take_grad_mode(self) -> int:
@@ -174,17 +174,18 @@ class Engine:
     # ------------------------------------------------------------------------------------------------ op builders
     def _conv(self, x: Act, wname: str, cout: int, k: int = 1, stride: int = 1, pad: int = 0, dil: int = 1,
               transposed: bool = False, out: Act = None, stats: bool = True, bias: str = None, name: str = None,
-              need_dx: bool = True):
+              need_dx: bool = True, f32: bool = False):
         """Dense conv (implicit GEMM).  Returns (y, slab, rows)."""
         lib = L.load()
-        d = L.ConvDesc(self.dt, 3 if transposed else k, stride, pad, dil, 1 if transposed else 0, x.C, cout)
+        dt, tdtype = (L.DC_F32, torch.float32) if f32 else (self.dt, self.dtype)
+        d = L.ConvDesc(dt, 3 if transposed else k, stride, pad, dil, 1 if transposed else 0, x.C, cout)
         ho, wo = C.c_int(), C.c_int()
         L.call("dc_conv_out_hw", C.byref(d), x.H, x.W, C.byref(ho), C.byref(wo))
-        y = out or Act(self, name or wname, x.N, ho.value, wo.value, cout)
-        assert (y.H, y.W, y.C) == (ho.value, wo.value, cout)
+        y = out or Act(self, name or wname, x.N, ho.value, wo.value, cout, dtype=tdtype)
+        assert (y.H, y.W, y.C) == (ho.value, wo.value, cout) and y.buf.dtype == tdtype and x.buf.dtype == tdtype
         kk = d.k * d.k
-        wf = torch.empty(kk * cout * x.C, dtype=self.dtype, device=self.device)
-        wb = torch.empty(kk * cout * x.C, dtype=self.dtype, device=self.device) if need_dx else None
+        wf = torch.empty(kk * cout * x.C, dtype=tdtype, device=self.device)
+        wb = torch.empty(kk * cout * x.C, dtype=tdtype, device=self.device) if need_dx else None
         rows = lib.dc_conv_stat_rows(C.byref(d), x.N, x.H, x.W) if stats else 0
         slab = self._f32(2 * rows * cout) if stats else None
         wsb = lib.dc_conv_wgrad_workspace(C.byref(d), x.N, x.H, x.W)
@@ -211,7 +212,7 @@ class Engine:
 
             def bwd():
                 if bias:
-                    L.call("dc_colsum", self.dt, y.M, cout, dy.ptr, dy.ld, self.gptr(bias), self._wsptr(), self._st())
+                    L.call("dc_colsum", dt, y.M, cout, dy.ptr, dy.ld, self.gptr(bias), self._wsptr(), self._st())
                 L.call("dc_conv_wgrad", C.byref(d), N, H, W, x.ptr, x.ld, dy.ptr, dy.ld, self._wsptr(), wsb, gw, self._st())
                 if need_dx:
                     L.call("dc_conv_dgrad", C.byref(d), N, H, W, dy.ptr, dy.ld, L.dptr(wb), dx.ptr, dx.ld, mode, self._st())
@@ -252,7 +253,9 @@ class Engine:
             name: str = None) -> Act:
         lib = L.load()
         Cc, M = y.C, y.M
-        o = out or Act(self, name or bname, y.N, y.H, y.W, Cc)
+        o = out or Act(self, name or bname, y.N, y.H, y.W, Cc, dtype=y.buf.dtype)
+        bdt = L.dtype_code(y.buf.dtype)
+        assert o.buf.dtype == y.buf.dtype
         scale, shift, mean, invstd = (self._f32(Cc) for _ in range(4))
         gam, bet = self.pptr(bname + ".weight"), self.pptr(bname + ".bias")
         rm, rv = self.bptr(bname + ".running_mean"), self.bptr(bname + ".running_var")
@@ -264,11 +267,11 @@ class Engine:
         def fwd_train():
             L.call("dc_bn_finalize", Cc, M, L.dptr(slab), rows, gam, bet, rm, rv, nbt, BN_MOMENTUM, BN_EPS, L.dptr(scale),
                    L.dptr(shift), L.dptr(mean), L.dptr(invstd), self._st())
-            L.call("dc_bn_apply", self.dt, M, Cc, y.ptr, y.ld, L.dptr(scale), L.dptr(shift), rptr(), rld, relu_i, o.ptr, o.ld, self._st())
+            L.call("dc_bn_apply", bdt, M, Cc, y.ptr, y.ld, L.dptr(scale), L.dptr(shift), rptr(), rld, relu_i, o.ptr, o.ld, self._st())
 
         def fwd_eval():
             L.call("dc_bn_eval_coeffs", Cc, gam, bet, rm, rv, BN_EPS, L.dptr(scale), L.dptr(shift), self._st())
-            L.call("dc_bn_apply", self.dt, M, Cc, y.ptr, y.ld, L.dptr(scale), L.dptr(shift), rptr(), rld, relu_i, o.ptr, o.ld, self._st())
+            L.call("dc_bn_apply", bdt, M, Cc, y.ptr, y.ld, L.dptr(scale), L.dptr(shift), rptr(), rld, relu_i, o.ptr, o.ld, self._st())
 
         self.fwd_train.append(fwd_train)
         self.fwd_eval.append(fwd_eval)
@@ -286,10 +289,10 @@ class Engine:
             dgam, dbet = self.gptr(bname + ".weight"), self.gptr(bname + ".bias")
 
             def bwd():
-                L.call("dc_bn_bwd_reduce", self.dt, M, Cc, do.ptr, do.ld, y.ptr, y.ld, o.ptr, o.ld, relu_i, L.dptr(mean),
+                L.call("dc_bn_bwd_reduce", bdt, M, Cc, do.ptr, do.ld, y.ptr, y.ld, o.ptr, o.ld, relu_i, L.dptr(mean),
                        L.dptr(invstd), L.dptr(bslab), self._st())
                 L.call("dc_bn_bwd_finalize", Cc, L.dptr(bslab), brows, dgam, dbet, self._st())
-                L.call("dc_bn_bwd_apply", self.dt, M, Cc, M, do.ptr, do.ld, y.ptr, y.ld, o.ptr, o.ld, relu_i, gam, L.dptr(mean),
+                L.call("dc_bn_bwd_apply", bdt, M, Cc, M, do.ptr, do.ld, y.ptr, y.ld, o.ptr, o.ld, relu_i, gam, L.dptr(mean),
                        L.dptr(invstd), dgam, dbet, dy.ptr, dy.ld, g_out.ptr if g_out is not None else None,
                        g_out.ld if g_out is not None else 0, self._st())
             return bwd, [bname + ".weight", bname + ".bias"]
@@ -363,7 +366,7 @@ class Engine:
         # ---- ASPP: five branches write channel slices of one buffer (torch.cat is free)
         cat1 = Act(self, "aspp_cat", B, h16, w16, 1280)
         # image-pool branch first, so that in the backward program it is the LAST contributor to d(e)
-        pooled = Act(self, "gap", B, 1, 1, 2048)
+        pooled = Act(self, "gap", B, 1, 1, 2048, dtype=torch.float32)     # this branch runs in fp32 (B values per channel)
         HW = h16 * w16
 
         def pool_fwd():
@@ -383,7 +386,7 @@ class Engine:
             return bwd, []
 
         self.bwd.append(pool_bwd_make)
-        yg, slab, rows = self._conv(pooled, "global_avg_pool.1.weight", 256, name="gap.conv")
+        yg, slab, rows = self._conv(pooled, "global_avg_pool.1.weight", 256, name="gap.conv", f32=True)
         ag = self._bn(yg, slab, rows, "global_avg_pool.2", True)
         bslice = cat1.slice("aspp5", 1024, 256)
 

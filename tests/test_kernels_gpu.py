@@ -373,15 +373,15 @@ def test_pool_branch_helpers(dtype):
     HW = H * W
     x = q(rnd(N, Cc, H, W, seed=1), dtype)
     _, xv = to_nhwc(x, dtype)
-    pooled = torch.empty(N, Cc, dtype=dtype, device=dev())
+    pooled = torch.empty(N, Cc, dtype=torch.float32, device=dev())
     L.call("dc_avgpool_fwd", dt, N, HW, Cc, vptr(xv), Cc, vptr(pooled), S())
     torch.cuda.synchronize()
     assert_close(pooled.float().cpu(), x.mean((2, 3)), dtype, bf16=1e-2)
     _, bv = empty_nhwc(N, H, W, Cc, dtype, ld=Cc + 8)
     L.call("dc_broadcast_hw", dt, N, HW, Cc, vptr(pooled), vptr(bv), Cc + 8, S())
     torch.cuda.synchronize()
-    assert torch.equal(from_nhwc(bv), pooled.float().cpu()[:, :, None, None].expand(N, Cc, H, W))
-    summed = torch.empty(N, Cc, dtype=dtype, device=dev())
+    assert torch.equal(from_nhwc(bv), q(pooled.cpu(), dtype)[:, :, None, None].expand(N, Cc, H, W))
+    summed = torch.empty(N, Cc, dtype=torch.float32, device=dev())
     L.call("dc_sum_hw", dt, N, HW, Cc, vptr(xv), Cc, vptr(summed), S())
     torch.cuda.synchronize()
     assert_close(summed.float().cpu(), x.sum((2, 3)), dtype, bf16=1e-2)
