@@ -83,13 +83,15 @@ size_t dc_colsum_workspace(long M, int C);
 
 /* ------------------------------------------------------------------------------------------------
  * Depthwise 3x3 ("SeparableConv2d_same.conv1" after fixed_padding): deeplab_xception.py:45-51,58-59,63-64.
- * Zero padding of `dil` on every side is implicit.  Weights: fp32 master [C][1][3][3] used directly.
+ * Zero padding of `dil` on every side is implicit.  Forward and data-gradient take the weights repacked as
+ * fp32 [9][C] (`wp`, from dc_dwconv_pack_weights); the weight gradient comes back in the master layout [C][1][3][3].
  * ------------------------------------------------------------------------------------------------ */
+int dc_dwconv_pack_weights(int C, const float* master, float* packed, void* stream);
 int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
-                  const float* w, void* y, int ldy, void* stream);
+                  const float* wp, void* y, int ldy, void* stream);
 /* dx = dw_backward_data(dy) [+ addend]  (addend: same shape as dx, e.g. the residual branch's gradient) */
 int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
-                    const float* w, const void* addend, int ldadd, void* dx, int lddx, void* stream);
+                    const float* wp, const void* addend, int ldadd, void* dx, int lddx, void* stream);
 size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int stride);
 int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
                     const void* dy, int lddy, void* workspace, float* grad_w, void* stream);

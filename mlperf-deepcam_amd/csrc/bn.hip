@@ -84,18 +84,50 @@ __global__ __launch_bounds__(256) void colred_kernel(long M, int C, const T* __r
   }
 }
 
-__global__ void bn_finalize_kernel(int C, double inv_count, double unbias, const float* __restrict__ slab, int rows,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
-                                   float* scale, float* shift, float* save_mean, float* save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt != nullptr) *nbt += 1;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int r = 0; r < rows; ++r) {
-    s += (double)slab[(size_t)r * C + c];
-    q += (double)slab[((size_t)rows + r) * C + c];
+// Column sums of a [rows][C] fp32 slab in fp64: 4 channels x 64 row-lanes per 256-thread block, so that even the
+// 3456-row slabs of the 384x576 layers cost ~50 dependent loads per thread instead of thousands.
+constexpr int FIN_CH = 4, FIN_RL = 64;
+__device__ inline void slab_colsum2(const float* __restrict__ s0, const float* __restrict__ s1, int rows, int C, int c,
+                                    bool ok, double (&red)[2][FIN_RL][FIN_CH], double& a, double& b) {
+  const int cl = threadIdx.x & (FIN_CH - 1), rl = threadIdx.x / FIN_CH;
+  double x0 = 0.0, x1 = 0.0, y0 = 0.0, y1 = 0.0;
+  if (ok) {
+    int r = rl;
+    for (; r + FIN_RL < rows; r += 2 * FIN_RL) {
+      x0 += (double)s0[(size_t)r * C + c];
+      x1 += (double)s0[(size_t)(r + FIN_RL) * C + c];
+      y0 += (double)s1[(size_t)r * C + c];
+      y1 += (double)s1[(size_t)(r + FIN_RL) * C + c];
+    }
+    if (r < rows) {
+      x0 += (double)s0[(size_t)r * C + c];
+      y0 += (double)s1[(size_t)r * C + c];
+    }
   }
+  red[0][rl][cl] = x0 + x1;
+  red[1][rl][cl] = y0 + y1;
+  __syncthreads();
+  a = b = 0.0;
+  if (threadIdx.x < FIN_CH) {
+#pragma unroll 8
+    for (int i = 0; i < FIN_RL; ++i) {
+      a += red[0][i][threadIdx.x];
+      b += red[1][i][threadIdx.x];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(int C, double inv_count, double unbias, const float* __restrict__ slab,
+                                                          int rows, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* running_mean,
+                                                          float* running_var, int64_t* nbt, float momentum, float eps,
+                                                          float* scale, float* shift, float* save_mean, float* save_invstd) {
+  __shared__ double red[2][FIN_RL][FIN_CH];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
+  double s, q;
+  slab_colsum2(slab, slab + (size_t)rows * C, rows, C, c, c < C, red, s, q);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;
+  if (threadIdx.x >= FIN_CH || c >= C) return;
   const double mean = s * inv_count;
   double var = q * inv_count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -151,14 +183,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(long M, int C, const T* _
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(int C, const float* __restrict__ slab, int rows, float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int r = 0; r < rows; ++r) {
-    s += (double)slab[(size_t)r * C + c];
-    q += (double)slab[((size_t)rows + r) * C + c];
-  }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, const float* __restrict__ slab, int rows, float* dgamma,
+                                                              float* dbeta) {
+  __shared__ double red[2][FIN_RL][FIN_CH];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
+  double s, q;
+  slab_colsum2(slab, slab + (size_t)rows * C, rows, C, c, c < C, red, s, q);
+  if (threadIdx.x >= FIN_CH || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
 }
@@ -248,7 +279,7 @@ extern "C" int dc_colsum(int dtype, long M, int C, const void* dy, int lddy, flo
   if (e) return e;
   // reuse the BN backward finalize: "dbeta" = column sum; the second output goes to the slab's own tail
   const int rows = cdiv(M, RED_ROWS);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, C, (const float*)slab, rows,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, st, C, (const float*)slab, rows,
                      slab + (size_t)rows * C, out);
   DC_CHECK_LAUNCH();
   return 0;
@@ -260,7 +291,7 @@ extern "C" int dc_bn_finalize(int C, long count, const float* slab, int rows, co
   DC_REQUIRE(C > 0 && rows > 0 && slab && gamma && beta && scale && shift, "dc_bn_finalize: bad argument");
   if (count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
   const double unbias = (double)count / (double)(count - 1);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, C, 1.0 / (double)count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, (hipStream_t)stream, C, 1.0 / (double)count,
                      unbias, slab, rows, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                      scale, shift, save_mean, save_invstd);
   DC_CHECK_LAUNCH();
@@ -309,7 +340,7 @@ extern "C" int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int 
 
 extern "C" int dc_bn_bwd_finalize(int C, const float* slab, int rows, float* dgamma, float* dbeta, void* stream) {
   DC_REQUIRE(C > 0 && rows > 0 && slab && dgamma && dbeta, "dc_bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, C, slab, rows, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, (hipStream_t)stream, C, slab, rows, dgamma, dbeta);
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -1,20 +1,33 @@
 // Depthwise 3x3 convolution of SeparableConv2d_same (fixed_padding + groups=C conv), NHWC, HBM-bound.
 // One lane owns one 16-byte channel group (8 bf16 / 4 f32 channels) so every global access is a full vector and
 // a wave covers up to 1 KiB of contiguous channels; each thread walks PX output pixels along W with the nine
-// per-channel weights held in registers.  Weights are the fp32 master tensor [C][1][3][3] itself.
+// per-channel weights held in registers.  Forward / data-gradient read the weights repacked as [9][C] fp32.
 #include "common.h"
 
 namespace dc {
 
 constexpr int DW_PX = 4;  // output pixels per thread (along W)
 
+// weights arrive packed as [9][C] fp32 (dc_dwconv_pack_weights): one thread's 8 (4) channels of a tap are 1-2 vector loads
 template <typename T>
-__device__ inline void load_w9(const float* __restrict__ w, int c0, int C, float (&wr)[9][Elem<T>::kPerVec]) {
+__device__ inline void load_w9(const float* __restrict__ wp, int c0, int C, float (&wr)[9][Elem<T>::kPerVec]) {
   constexpr int KPV = Elem<T>::kPerVec;
 #pragma unroll
-  for (int e = 0; e < KPV; ++e)
+  for (int t = 0; t < 9; ++t) {
+    const float4* src = reinterpret_cast<const float4*>(wp + (size_t)t * C + c0);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wr[t][e] = (c0 + e < C) ? w[(size_t)(c0 + e) * 9 + t] : 0.f;
+    for (int q = 0; q < KPV / 4; ++q) {
+      const float4 v = src[q];
+      wr[t][4 * q] = v.x; wr[t][4 * q + 1] = v.y; wr[t][4 * q + 2] = v.z; wr[t][4 * q + 3] = v.w;
+    }
+  }
+}
+
+__global__ void dw_pack_kernel(const float* __restrict__ master, float* __restrict__ packed, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * C) return;
+  const int c = i / 9, t = i % 9;
+  packed[(size_t)t * C + c] = master[i];
 }
 
 // mode 0: forward   out[n,oy,ox] = sum_t in[n, oy*s - d + ky*d, ox*s - d + kx*d] * w[t]
@@ -93,17 +106,192 @@ __global__ __launch_bounds__(256) void dw_kernel(const T* __restrict__ in, int l
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-1 fast path (60 of the 63 depthwise layers).  The generic kernel above is latency-bound: it issues nine dependent
+// batches of loads per pixel.  Here a thread owns DW_PX=4 consecutive output pixels of one channel group and first issues
+// ALL loads of their 3 x (4+2*DIL) input window (18 or 24 independent 16-byte loads in flight), then does the arithmetic.
+// The data gradient of a stride-1 depthwise conv is the same stencil with the taps reversed (FLIP) plus the optional addend.
+template <typename T, int DIL, bool FLIP>
+__global__ __launch_bounds__(256) void dw_s1_kernel(const T* __restrict__ in, int ldin, const float* __restrict__ wp,
+                                                    const T* __restrict__ addend, int ldadd, T* __restrict__ out, int ldout,
+                                                    int N, int H, int W, int C) {
+  constexpr int KPV = Elem<T>::kPerVec;
+  constexpr int WC = DW_PX + 2 * DIL;  // window columns
+  const int ngroups = C / KPV;
+  const int wq = (W + DW_PX - 1) / DW_PX;
+  const int total = N * H * wq * ngroups;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = idx % ngroups;
+  int r = idx / ngroups;
+  const int xq = r % wq;
+  r /= wq;
+  const int oy = r % H;
+  const int n = r / H;
+  const int c0 = cg * KPV;
+  const int x0 = xq * DW_PX;
+  vec16 win[3][WC];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy - DIL + ky * DIL;
+    const bool yok = (unsigned)iy < (unsigned)H;
+    const T* rowp = in + ((size_t)(n * H + (yok ? iy : 0)) * W) * ldin + c0;
+#pragma unroll
+    for (int c = 0; c < WC; ++c) {
+      const int ix = x0 - DIL + c;
+      win[ky][c] = (yok && (unsigned)ix < (unsigned)W) ? ldg16(rowp + (size_t)ix * ldin) : zero16();
+    }
+  }
+  float acc[DW_PX][KPV];
+#pragma unroll
+  for (int j = 0; j < DW_PX; ++j)
+#pragma unroll
+    for (int e = 0; e < KPV; ++e) acc[j][e] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    float wk[3][KPV];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int t = FLIP ? 8 - (ky * 3 + kx) : ky * 3 + kx;
+      const float4* src = reinterpret_cast<const float4*>(wp + (size_t)t * C + c0);
+#pragma unroll
+      for (int q = 0; q < KPV / 4; ++q) {
+        const float4 v = src[q];
+        wk[kx][4 * q] = v.x; wk[kx][4 * q + 1] = v.y; wk[kx][4 * q + 2] = v.z; wk[kx][4 * q + 3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < WC; ++c) {
+      float f[KPV];
+      unpack(win[ky][c], f, T());
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int j = c - kx * DIL;          // output pixel that sees window column c through tap kx
+        if (j >= 0 && j < DW_PX) {
+#pragma unroll
+          for (int e = 0; e < KPV; ++e) acc[j][e] = fmaf(f[e], wk[kx][e], acc[j][e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < DW_PX; ++j) {
+    const int ox = x0 + j;
+    if (ox < W) {
+      const size_t opix = (size_t)(n * H + oy) * W + ox;
+      if (FLIP && addend != nullptr) {
+        float f[KPV];
+        unpack(ldg16(addend + opix * ldadd + c0), f, T());
+#pragma unroll
+        for (int e = 0; e < KPV; ++e) acc[j][e] += f[e];
+      }
+      vec16 v;
+      pack(v, acc[j], T());
+      stg16(out + opix * ldout + c0, v);
+    }
+  }
+}
+
+// Stride-1 weight gradient: a thread owns 4 consecutive pixels x one channel group, loads their dy and the 3 x (4+2*DIL)
+// window of x at once, and adds the 9 x KPV products; lanes of a wave = consecutive channel groups (x pixel strips), the
+// strips of a block are folded through LDS, one partial row per block goes to the slab.
+template <typename T, int DIL>
+__global__ __launch_bounds__(256) void dw_s1_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                          float* __restrict__ slab, int N, int H, int W, int C, int strips_per_block,
+                                                          int cgw) {
+  constexpr int KPV = Elem<T>::kPerVec;
+  constexpr int WC = DW_PX + 2 * DIL;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [256/cgw][9][cgw]
+  const int ngroups = C / KPV;
+  const int cgl = threadIdx.x % cgw, sl = threadIdx.x / cgw;   // lane -> (channel group, strip lane)
+  const int nsl = 256 / cgw;
+  const int cg = blockIdx.x * cgw + cgl;
+  const int c0 = cg * KPV;
+  const bool cok = cg < ngroups;
+  const int wq = (W + DW_PX - 1) / DW_PX;
+  const int nstrips = N * H * wq;
+  const int sbeg = blockIdx.y * strips_per_block;
+  const int send = min(nstrips, sbeg + strips_per_block);
+  float acc[9][KPV];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < KPV; ++e) acc[t][e] = 0.f;
+  if (cok) {
+    for (int sidx = sbeg + sl; sidx < send; sidx += nsl) {
+      const int xq = sidx % wq;
+      int r = sidx / wq;
+      const int oy = r % H;
+      const int n = r / H;
+      const int x0 = xq * DW_PX;
+      vec16 g[DW_PX], win[3][WC];
+#pragma unroll
+      for (int j = 0; j < DW_PX; ++j)
+        g[j] = (x0 + j < W) ? ldg16(dy + ((size_t)(n * H + oy) * W + x0 + j) * lddy + c0) : zero16();
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy - DIL + ky * DIL;
+        const bool yok = (unsigned)iy < (unsigned)H;
+        const T* rowp = x + ((size_t)(n * H + (yok ? iy : 0)) * W) * ldx + c0;
+#pragma unroll
+        for (int c = 0; c < WC; ++c) {
+          const int ix = x0 - DIL + c;
+          win[ky][c] = (yok && (unsigned)ix < (unsigned)W) ? ldg16(rowp + (size_t)ix * ldx) : zero16();
+        }
+      }
+      float gf[DW_PX][KPV];
+#pragma unroll
+      for (int j = 0; j < DW_PX; ++j) unpack(g[j], gf[j], T());
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int c = 0; c < WC; ++c) {
+          float f[KPV];
+          unpack(win[ky][c], f, T());
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int j = c - kx * DIL;
+            if (j >= 0 && j < DW_PX) {
+#pragma unroll
+              for (int e = 0; e < KPV; ++e) acc[ky * 3 + kx][e] = fmaf(gf[j][e], f[e], acc[ky * 3 + kx][e]);
+            }
+          }
+        }
+    }
+  }
+  // fold the strip lanes of the block, one channel element at a time
+#pragma unroll
+  for (int e = 0; e < KPV; ++e) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[(sl * 9 + t) * cgw + cgl] = acc[t][e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * cgw; i += 256) {
+      const int t = i / cgw, l = i % cgw;
+      const int c = (blockIdx.x * cgw + l) * KPV + e;
+      if (c < C) {
+        float a = 0.f;
+        for (int q = 0; q < nsl; ++q) a += red[(q * 9 + t) * cgw + l];
+        slab[((size_t)blockIdx.y * 9 + t) * C + c] = a;
+      }
+    }
+  }
+}
+
 // Weight gradient: dw[c][t] = sum over output pixels of dy[n,oy,ox,c] * x[n, oy*s - d + ky*d, ox*s - d + kx*d, c].
-// grid (channel-group chunks of 64, pixel blocks); lane <-> channel group, the block's 4 waves take interleaved
-// pixels, are combined through LDS and leave one partial row per block in slab[pixel block][9][C].
-template <typename T>
+// A wave is tiled as CGW channel groups x (64/CGW) pixels so that thin layers (128 channels = 16 groups) still use all 64
+// lanes; the pixel sub-lanes are folded with shuffles, the block's 4 waves through LDS, and every block leaves one
+// partial row in slab[pixel block][9][C] (reduced in a fixed order afterwards: deterministic, no atomics).
+template <typename T, int CGW>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy,
                                                        int lddy, float* __restrict__ slab, int N, int Hi, int Wi,
                                                        int Ho, int Wo, int C, int stride, int dil, int pix_per_block) {
   constexpr int KPV = Elem<T>::kPerVec;
-  __shared__ float red[4][9][64];
+  constexpr int PPW = 64 / CGW;
+  __shared__ float red[4][9][CGW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cg = blockIdx.x * 64 + lane;
+  const int cgl = lane % CGW, psub = lane / CGW;
+  const int cg = blockIdx.x * CGW + cgl;
   const int c0 = cg * KPV;
   const bool cok = c0 < C;
   const long P = (long)N * Ho * Wo;
@@ -115,7 +303,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int e = 0; e < KPV; ++e) acc[t][e] = 0.f;
   if (cok) {
-    for (long pix = pbeg + wave; pix < pend; pix += 4) {
+    for (long pix = pbeg + wave * PPW + psub; pix < pend; pix += 4 * PPW) {
       const int ox = (int)(pix % Wo);
       const long r = pix / Wo;
       const int oy = (int)(r % Ho);
@@ -138,35 +326,64 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, 
       }
     }
   }
-  // combine the 4 waves, one channel element at a time (keeps LDS at 9 KiB)
+  // fold the pixel sub-lanes of the wave
+#pragma unroll
+  for (int off = CGW; off < 64; off <<= 1)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < KPV; ++e) acc[t][e] += __shfl_xor(acc[t][e], off, 64);
+  // combine the 4 waves, one channel element at a time
 #pragma unroll
   for (int e = 0; e < KPV; ++e) {
     __syncthreads();
+    if (psub == 0)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[wave][t][lane] = acc[t][e];
+      for (int t = 0; t < 9; ++t) red[wave][t][cgl] = acc[t][e];
     __syncthreads();
-    for (int i = threadIdx.x; i < 9 * 64; i += 256) {
-      const int t = i / 64, l = i % 64;
-      const int c = (blockIdx.x * 64 + l) * KPV + e;
+    for (int i = threadIdx.x; i < 9 * CGW; i += 256) {
+      const int t = i / CGW, l = i % CGW;
+      const int c = (blockIdx.x * CGW + l) * KPV + e;
       if (c < C) slab[((size_t)blockIdx.y * 9 + t) * C + c] = red[0][t][l] + red[1][t][l] + red[2][t][l] + red[3][t][l];
     }
   }
 }
 
-// grad[c][t] = sum over rows of slab[row][t][c]
-__global__ void dw_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int rows, int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 9 * C) return;
-  const int t = i / C, c = i % C;
+// grad[c][t] = sum over rows of slab[row][t][c]: 8 columns x 32 row-lanes per block, fp64, fixed order
+__global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int rows, int C) {
+  __shared__ double red[32][8];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int n = 9 * C;
+  const int i = blockIdx.x * 8 + cl;
   double a = 0.0;
-  for (int r = 0; r < rows; ++r) a += (double)slab[((size_t)r * 9 + t) * C + c];
-  grad[(size_t)c * 9 + t] = (float)a;
+  if (i < n)
+    for (int r = rl; r < rows; r += 32) a += (double)slab[(size_t)r * n + i];
+  red[rl][cl] = a;
+  __syncthreads();
+  if (threadIdx.x < 8 && blockIdx.x * 8 + threadIdx.x < n) {
+    const int j = blockIdx.x * 8 + threadIdx.x;
+    double s2 = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) s2 += red[k][threadIdx.x];
+    const int t = j / C, c = j % C;
+    grad[(size_t)c * 9 + t] = (float)s2;
+  }
+}
+
+// channel groups per wave row: the power of two that wastes the fewest lanes (ties -> wider, better coalescing)
+static int dw_pick_cgw(int ngroups) {
+  int best = 64, waste = cdiv(ngroups, 64) * 64 - ngroups;
+  for (int w = 32; w >= 8; w >>= 1) {
+    const int ws = cdiv(ngroups, w) * w - ngroups;
+    if (ws < waste) { best = w; waste = ws; }
+  }
+  return best;
 }
 
 static int dw_out(int Hi, int stride, int dil) { return (Hi + 2 * dil - 2 * dil - 1) / stride + 1; }
 static int dw_pix_per_block(long P) {
-  long ppb = (P + 255) / 256;  // at most 256 pixel blocks
-  if (ppb < 64) ppb = 64;
+  long ppb = (P + 255) / 256;  // at most 256 pixel blocks (= slab rows)
+  if (ppb < 32) ppb = 32;
   return (int)ppb;
 }
 
@@ -186,10 +403,37 @@ static int launch_dw(const void* in, int ldin, const float* w, const void* adden
   return 0;
 }
 
+static int launch_dw_s1(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
+                        void* out, int ldout, int N, int H, int W, int C, hipStream_t st) {
+  const int kpv = dtype == DC_BF16 ? 8 : 4;
+  const long total = (long)N * H * ((W + DW_PX - 1) / DW_PX) * (C / kpv);
+  DC_REQUIRE(total < (1L << 31), "dc_dwconv: tensor too large for the stride-1 fast path");
+  dim3 grid((unsigned)((total + 255) / 256));
+#define DW_S1(TT, D, F) hipLaunchKernelGGL((dw_s1_kernel<TT, D, F>), grid, dim3(256), 0, st, (const TT*)in, ldin, wp, (const TT*)addend, ldadd, (TT*)out, ldout, N, H, W, C)
+  if (dtype == DC_BF16) {
+    if (dil == 1) { if (flip) DW_S1(bf16, 1, true); else DW_S1(bf16, 1, false); }
+    else          { if (flip) DW_S1(bf16, 2, true); else DW_S1(bf16, 2, false); }
+  } else {
+    if (dil == 1) { if (flip) DW_S1(float, 1, true); else DW_S1(float, 1, false); }
+    else          { if (flip) DW_S1(float, 2, true); else DW_S1(float, 2, false); }
+  }
+#undef DW_S1
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
 static int dw_check(int dtype, int C, int stride, int dil, int N, int Hi, int Wi) {
   DC_REQUIRE(dtype == DC_F32 || dtype == DC_BF16, "dc_dwconv: bad dtype");
   DC_REQUIRE(stride == 1 || stride == 2, "dc_dwconv: stride must be 1 or 2");
   DC_REQUIRE(dil >= 1 && C > 0 && N > 0 && Hi > 0 && Wi > 0, "dc_dwconv: bad shape");
+  return 0;
+}
+
+extern "C" int dc_dwconv_pack_weights(int C, const float* master, float* packed, void* stream) {
+  DC_REQUIRE(C > 0 && C % 4 == 0 && master && packed, "dc_dwconv_pack_weights: bad argument");
+  DC_REQUIRE(((uintptr_t)packed & 15) == 0, "dc_dwconv_pack_weights: packed buffer must be 16-byte aligned");
+  hipLaunchKernelGGL(dw_pack_kernel, dim3(cdiv(9 * C, 256)), dim3(256), 0, (hipStream_t)stream, master, packed, C);
+  DC_CHECK_LAUNCH();
   return 0;
 }
 
@@ -201,6 +445,7 @@ extern "C" int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int H
   DC_REQUIRE(w != nullptr, "dc_dwconv_fwd: null weights");
   const int Ho = dw_out(Hi, stride, dil), Wo = dw_out(Wi, stride, dil);
   hipStream_t st = (hipStream_t)stream;
+  if (stride == 1 && (dil == 1 || dil == 2)) return launch_dw_s1(dtype, dil, false, x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, C, st);
   return dtype == DC_BF16 ? launch_dw<bf16, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st)
                           : launch_dw<float, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st);
 }
@@ -215,6 +460,7 @@ extern "C" int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int
   DC_REQUIRE(w != nullptr, "dc_dwconv_dgrad: null weights");
   const int Ho = dw_out(Hi, stride, dil), Wo = dw_out(Wi, stride, dil);
   hipStream_t st = (hipStream_t)stream;
+  if (stride == 1 && (dil == 1 || dil == 2)) return launch_dw_s1(dtype, dil, true, dy, lddy, w, addend, ldadd, dx, lddx, N, Hi, Wi, C, st);
   // gather from dy [Ho,Wo] into dx [Hi,Wi]
   return dtype == DC_BF16 ? launch_dw<bf16, 1>(dy, lddy, w, addend, ldadd, dx, lddx, N, Ho, Wo, Hi, Wi, C, stride, dil, st)
                           : launch_dw<float, 1>(dy, lddy, w, addend, ldadd, dx, lddx, N, Ho, Wo, Hi, Wi, C, stride, dil, st);
@@ -224,7 +470,8 @@ extern "C" size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int st
   const int Ho = dw_out(Hi, stride, 1), Wo = dw_out(Wi, stride, 1);
   const long P = (long)N * Ho * Wo;
   const int ppb = dw_pix_per_block(P);
-  const int rows = (int)((P + ppb - 1) / ppb);
+  int rows = (int)((P + ppb - 1) / ppb);
+  if (rows < 256) rows = 256;            // the stride-1 fast path uses up to 256 slab rows
   return (size_t)rows * 9 * C * sizeof(float);
 }
 
@@ -240,13 +487,35 @@ extern "C" int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int
   const int rows = (int)((P + ppb - 1) / ppb);
   hipStream_t st = (hipStream_t)stream;
   const int kpv = dtype == DC_BF16 ? 8 : 4;
-  dim3 grid(cdiv(C / kpv, 64), rows);
-  if (dtype == DC_BF16)
-    hipLaunchKernelGGL(dw_wgrad_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dy, lddy, (float*)workspace, N, Hi, Wi, Ho, Wo, C, stride, dil, ppb);
-  else
-    hipLaunchKernelGGL(dw_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, (const float*)dy, lddy, (float*)workspace, N, Hi, Wi, Ho, Wo, C, stride, dil, ppb);
+  const int cgw = dw_pick_cgw(C / kpv);
+  if (stride == 1 && (dil == 1 || dil == 2)) {
+    const int nstrips = N * Hi * ((Wi + DW_PX - 1) / DW_PX);
+    const int nsl = 256 / cgw;
+    int spb = cdiv(nstrips, 256);
+    if (spb < 2 * nsl) spb = 2 * nsl;
+    spb = cdiv(spb, nsl) * nsl;
+    const int frows = cdiv(nstrips, spb);
+    dim3 fgrid(cdiv(C / kpv, cgw), frows);
+    const size_t lds = (size_t)256 * 9 * sizeof(float);
+#define DW_WS1(TT, D) hipLaunchKernelGGL((dw_s1_wgrad_kernel<TT, D>), fgrid, dim3(256), lds, st, (const TT*)x, ldx, (const TT*)dy, lddy, (float*)workspace, N, Hi, Wi, C, spb, cgw)
+    if (dtype == DC_BF16) { if (dil == 1) DW_WS1(bf16, 1); else DW_WS1(bf16, 2); }
+    else                  { if (dil == 1) DW_WS1(float, 1); else DW_WS1(float, 2); }
+#undef DW_WS1
+    DC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(cdiv(9 * C, 8)), dim3(256), 0, st, (const float*)workspace, grad_w, frows, C);
+    DC_CHECK_LAUNCH();
+    return 0;
+  }
+  dim3 grid(cdiv(C / kpv, cgw), rows);
+#define DW_WG(TT, W) hipLaunchKernelGGL((dw_wgrad_kernel<TT, W>), grid, dim3(256), 0, st, (const TT*)x, ldx, (const TT*)dy, lddy, (float*)workspace, N, Hi, Wi, Ho, Wo, C, stride, dil, ppb)
+  if (dtype == DC_BF16) {
+    if (cgw == 64) DW_WG(bf16, 64); else if (cgw == 32) DW_WG(bf16, 32); else if (cgw == 16) DW_WG(bf16, 16); else DW_WG(bf16, 8);
+  } else {
+    if (cgw == 64) DW_WG(float, 64); else if (cgw == 32) DW_WG(float, 32); else if (cgw == 16) DW_WG(float, 16); else DW_WG(float, 8);
+  }
+#undef DW_WG
   DC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(cdiv(9 * C, 256)), dim3(256), 0, st, (const float*)workspace, grad_w, rows, C);
+  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(cdiv(9 * C, 8)), dim3(256), 0, st, (const float*)workspace, grad_w, rows, C);
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -63,9 +63,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
   const GatherGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * BN;
-  const int m0 = blockIdx.y * BM;
-  const int phase = blockIdx.z;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so the ones that
+  // share an XCD (equal id mod 8) are given CONSECUTIVE tiles, and consecutive tiles walk the output-channel tiles of one
+  // pixel tile first: the 128-pixel A panel is then fetched into that XCD's L2 once instead of once per channel tile.
+  const int ntn = (g.Cout + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + xslot;
+  const int ntile_n = tile % ntn;
+  const int rest = tile / ntn;
+  const int mtile = rest % p.mtiles;
+  const int phase = rest / p.mtiles;
+  const int n0 = ntile_n * BN;
+  const int m0 = mtile * BM;
   const int py = phase / g.os, px = phase % g.os;
 
   if (tid == 0) {
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int r = 0; r < RPP; ++r) a += red[(which * RPP + r) * BN + c];
       const int rows = p.mtiles * g.os * g.os;
-      const int srow = phase * p.mtiles + blockIdx.y;
+      const int srow = phase * p.mtiles + mtile;
       p.slab[((size_t)which * rows + srow) * g.Cout + n0 + c] = a;
     }
   }
@@ -286,7 +296,7 @@ static int launch_igemm(const IgemmParams& p, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(cdiv(p.g.Cout, BN), p.mtiles, p.g.os * p.g.os);
+  dim3 grid(cdiv(p.g.Cout, BN) * p.mtiles * p.g.os * p.g.os);
   hipLaunchKernelGGL(igemm_kernel<T>, grid, dim3(256), lds, st, p);
   DC_CHECK_LAUNCH();
   return 0;

@@ -146,13 +146,28 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   }
 }
 
-// out[i] = sum_r slab[r][i]   (fp64 accumulate, fixed order)
-__global__ void slab_rows_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int rows, long n) {
-  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double a = 0.0;
-  for (int r = 0; r < rows; ++r) a += (double)slab[(size_t)r * n + i];
-  out[i] = (float)a;
+// out[i] = sum_r slab[r][i]   (fp64 accumulate, fixed order): 8 columns x 32 row-lanes per block
+__global__ __launch_bounds__(256) void slab_rows_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int rows, long n) {
+  __shared__ double red[32][8];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const long i = (long)blockIdx.x * 8 + cl;
+  double a = 0.0, b = 0.0;
+  if (i < n) {
+    int r = rl;
+    for (; r + 32 < rows; r += 64) {
+      a += (double)slab[(size_t)r * n + i];
+      b += (double)slab[(size_t)(r + 32) * n + i];
+    }
+    if (r < rows) a += (double)slab[(size_t)r * n + i];
+  }
+  red[rl][cl] = a + b;
+  __syncthreads();
+  if (threadIdx.x < 8 && (long)blockIdx.x * 8 + threadIdx.x < n) {
+    double s = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
+    out[(long)blockIdx.x * 8 + threadIdx.x] = (float)s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------- head forward
@@ -355,7 +370,7 @@ extern "C" int dc_stem_wgrad(int dtype, int N, int Cin, int H, int W, const floa
     hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(rows), dim3(256), lds, st, x_nchw, (const float*)dy, lddy, (float*)workspace, N, Cin, H, W, Ho, Wo, ppb);
   DC_CHECK_LAUNCH();
   const long n = 32L * K;
-  hipLaunchKernelGGL(slab_rows_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, grad_w, rows, n);
+  hipLaunchKernelGGL(slab_rows_reduce_kernel, dim3(cdiv(n, 8)), dim3(256), 0, st, (const float*)workspace, grad_w, rows, n);
   DC_CHECK_LAUNCH();
   return 0;
 }
@@ -412,7 +427,7 @@ extern "C" int dc_head_wgrad(int dtype, int N, int Cin, int Hi, int Wi, const vo
     hipLaunchKernelGGL((head_wgrad_kernel<float, 4>), dim3(rows), dim3(64, 3), 0, st, (const float*)x, ldx, dlogits_nchw, (float*)workspace, N, Cin, Hi, Wi, ppb);
   DC_CHECK_LAUNCH();
   const long n = (long)Cin * HEAD_NC * 9;
-  hipLaunchKernelGGL(slab_rows_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, grad_w, rows, n);
+  hipLaunchKernelGGL(slab_rows_reduce_kernel, dim3(cdiv(n, 8)), dim3(256), 0, st, (const float*)workspace, grad_w, rows, n);
   DC_CHECK_LAUNCH();
   return 0;
 }

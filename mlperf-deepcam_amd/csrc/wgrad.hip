@@ -46,8 +46,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
   const GatherGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ci0 = blockIdx.x * 128, co0 = blockIdx.y * 128;
-  const int tapi = blockIdx.z / p.splits, split = blockIdx.z % p.splits;
+  // XCD-aware order (see igemm.hip): workgroups sharing an XCD take consecutive tiles, and consecutive tiles cover all
+  // (ci, co) tiles of ONE (tap, pixel split), so its x / dy pixel panels are pulled into that XCD's L2 once.
+  const int nci = (g.Cin + 127) / 128, nco = (g.Cout + 127) / 128;
+  const int nwg = gridDim.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int ci0 = (tile % nci) * 128;
+  tile /= nci;
+  const int co0 = (tile % nco) * 128;
+  tile /= nco;
+  const int tapi = tile / p.splits, split = tile % p.splits;
   const Tap tap = g.taps[tapi];
   const int py = tap.phase / g.os, px = tap.phase % g.os;
   const int mbeg = split * p.chunk;
@@ -233,8 +242,7 @@ extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const
   p.x = x; p.dy = dy; p.slab = (float*)workspace;
   p.N = N; p.ldx = ldx; p.lddy = lddy; p.M = (int)M;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(cdiv(p.g.Cin, 128), cdiv(p.g.Cout, 128), p.g.ntaps * p.splits);
-  DC_REQUIRE(grid.z <= 65535, "dc_conv_wgrad: grid.z overflow");
+  dim3 grid(cdiv(p.g.Cin, 128) * cdiv(p.g.Cout, 128) * p.g.ntaps * p.splits);
   if (d->dtype == DC_BF16) {
     const size_t lds = 4 * (size_t)WgTraits<bf16>::BP * WgTraits<bf16>::ROW;
     static bool once = false;

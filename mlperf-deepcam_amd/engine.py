@@ -117,6 +117,7 @@ class Engine:
             self.nbt = torch.zeros(len(lay.nbt), dtype=torch.int64, device=self.device)
             self.version = [0]          # bumped whenever the master weights change (optimizer step, load_state_dict)
         self.packed_version = -1
+        self._keep: List[torch.Tensor] = []
 
         # ---- program containers -----------------------------------------------------------------------------
         self.fwd_train: List[Callable[[], None]] = []
@@ -226,7 +227,11 @@ class Engine:
         Ho, Wo = (x.H - 1) // stride + 1, (x.W - 1) // stride + 1
         y = Act(self, name, x.N, Ho, Wo, x.C)
         N, H, W, Cc = x.N, x.H, x.W, x.C
-        pw, gw = self.pptr(wname), self.gptr(wname)
+        pm, gw = self.pptr(wname), self.gptr(wname)
+        wpk = self._f32(9 * Cc)
+        self._keep.append(wpk)             # closures below hold only the raw pointer
+        pw = L.dptr(wpk)
+        self.pack_ops.append(lambda: L.call("dc_dwconv_pack_weights", Cc, pm, pw, self._st()))
         self._need_ws(lib.dc_dwconv_wgrad_workspace(Cc, N, H, W, stride))
 
         def fwd():

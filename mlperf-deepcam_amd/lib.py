@@ -39,6 +39,7 @@ _SIGS = {
     "dc_conv_wgrad": (I, [CD, I, I, I, P, I, P, I, P, SZ, P, P]),
     "dc_colsum": (I, [I, L, I, P, I, P, P, P]),
     "dc_colsum_workspace": (SZ, [L, I]),
+    "dc_dwconv_pack_weights": (I, [I, P, P, P]),
     "dc_dwconv_fwd": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P]),
     "dc_dwconv_dgrad": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P]),
     "dc_dwconv_wgrad_workspace": (SZ, [I, I, I, I, I]),

@@ -197,7 +197,9 @@ def test_depthwise(case, dtype):
     Ho, Wo = yref.shape[2:]
     gy = q(rnd(*yref.shape, seed=3), dtype)
     gx_ref, gw_ref = torch.autograd.grad(yref, (xr, wr), gy)
-    wd = w.to(dev())
+    wm = w.to(dev())
+    wd = torch.empty(9 * Cc, device=dev())
+    L.call("dc_dwconv_pack_weights", Cc, vptr(wm), vptr(wd), S())
     _, xv = to_nhwc(x, dtype, ld=Cc + 8)
     _, yv = empty_nhwc(N, Ho, Wo, Cc, dtype)
     L.call("dc_dwconv_fwd", dt, Cc, stride, dil, N, H, W, vptr(xv), Cc + 8, vptr(wd), vptr(yv), Cc, S())
