@@ -67,6 +67,11 @@ int dc_conv_stat_rows(const dc_conv_desc* d, int N, int Hi, int Wi);
 int dc_conv_fwd(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,
                 const float* bias, void* y, int ldy, float* stat_slab, int accumulate, void* stream);
 
+/* Same as dc_conv_fwd, but the result is stored as fp32 (y: float NHWC, ldy in floats) whatever d->dtype is:
+ * used where the consumer must not see bf16-rounded sums (the classifier head's logits). */
+int dc_conv_fwd_f32out(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,
+                       float* y, int ldy, void* stream);
+
 /* dx = conv_backward_data(dy, w).  Hi, Wi are the FORWARD input extents (= extents of dx). */
 int dc_conv_dgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb,
                   void* dx, int lddx, int accumulate, void* stream);
@@ -139,15 +144,19 @@ int dc_stem_wgrad(int dtype, int N, int Cin, int H, int W, const float* x_nchw, 
 
 /* ------------------------------------------------------------------------------------------------
  * Classifier head: ConvTranspose2d(256->n_classes=3, k3, s2, p1, op1), deeplab_xception.py:374,382.
- * Reads NHWC `dtype`, writes the NCHW fp32 logits the reference API returns.
+ * Reads NHWC `dtype`, writes the NCHW fp32 logits the reference API returns.  Runs as GEMMs on the MFMA kernels:
+ * P[pixel][co,tap] = x . W (27 products per input pixel, fp32) followed by the sub-pixel tap combination.
  * ------------------------------------------------------------------------------------------------ */
+size_t dc_head_workspace(int dtype, int N, int Cin, int Hi, int Wi);
 int dc_head_fwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx,
-                const float* w /*[Cin][3][3][3]*/, float* logits_nchw, void* stream);
-int dc_head_dgrad(int dtype, int N, int Cin, int Hi, int Wi, const float* dlogits_nchw, const float* w,
-                  void* dx, int lddx, void* stream);
-size_t dc_head_wgrad_workspace(int N, int Cin, int Hi, int Wi);
-int dc_head_wgrad(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
-                  void* workspace, float* grad_w, void* stream);
+                const float* w /*[Cin][3][3][3]*/, float* logits_nchw, void* workspace, void* stream);
+/* dx = d(loss)/dx and grad_w (master layout) from the NCHW fp32 logit gradient, in one call (they share the gathered
+ * 27-tap gradient image).  workspace: dc_head_workspace bytes, 256-byte aligned. */
+int dc_head_bwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
+                const float* w, void* dx, int lddx, float* grad_w, void* workspace, void* stream);
+
+/* NCHW fp32 (the layout train_hdf5_ddp.py:348 hands over) -> NHWC `dtype`: the one layout pass of the step. */
+int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, void* out, int ldo, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Loss and metric: utils/losses.py:28-52 (fp_loss == plain mean of weighted CE), torch.max(.,1)[1]

@@ -9,6 +9,8 @@
 //   epilogue  accumulators -> LDS C tile -> fully coalesced 16-B NHWC stores; optional bias, optional
 //             read-modify-write accumulate, optional per-channel sum / sum-of-squares partials of the STORED
 //             values for the following train-mode BatchNorm (deterministic slab, no atomics)
+#include <type_traits>
+
 #include "conv_geom.h"
 
 namespace dc {
@@ -25,6 +27,7 @@ struct IgemmParams {
   int mtiles;  // tiles per phase
   int accumulate;
 };
+// OUT32: the epilogue stores fp32 regardless of T (used by the classifier head, whose logits must not be rounded to bf16)
 
 constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per LDS row
 constexpr int OPER_BYTES = BM * ROWB;          // 16 KiB per operand tile
@@ -50,12 +53,15 @@ struct Mma<float> {
 
 __device__ inline int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T>
+template <typename T, bool OUT32>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+  typedef typename std::conditional<OUT32, float, T>::type TO;   // stored output type
   constexpr int KPV = Elem<T>::kPerVec;      // elements per 16 B
+  constexpr int KPVO = Elem<TO>::kPerVec;
   constexpr int BK = ROWB / (int)sizeof(T);  // K elements per step
-  constexpr int CROW = BN * (int)sizeof(T) + 16;  // padded C-tile row
+  constexpr int CROW = BN * (int)sizeof(TO) + 16;  // padded C-tile row
   // all LDS lives in the one dynamic array (keeps its base 16-byte aligned); the tap list sits behind the tiles
+  static_assert(!OUT32 || true, "");
   constexpr int MAIN_BYTES = (4 * OPER_BYTES) > (BM * CROW) ? (4 * OPER_BYTES) : (BM * CROW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_tap = reinterpret_cast<int*>(smem + MAIN_BYTES);
@@ -212,8 +218,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int prow = wm * 64 + j * 16 + fr;
-      T* dst = reinterpret_cast<T*>(ct + prow * CROW) + chl;
-      if constexpr (sizeof(T) == 4) {
+      TO* dst = reinterpret_cast<TO*>(ct + prow * CROW) + chl;
+      if constexpr (sizeof(TO) == 4) {
         f32x4 v = acc[i][j];
         v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
         *reinterpret_cast<f32x4*>(dst) = v;
@@ -227,16 +233,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
   __syncthreads();
 
-  constexpr int GPR = BN * (int)sizeof(T) / 16;  // 16-byte groups per C row: 16 (bf16) / 32 (f32)
-  constexpr int RPP = 256 / GPR;                 // rows covered per pass: 16 / 8
-  constexpr int PASSES = BM / RPP;               // 8 / 16
+  constexpr int GPR = BN * (int)sizeof(TO) / 16;  // 16-byte groups per C row: 16 (bf16) / 32 (f32)
+  constexpr int RPP = 256 / GPR;                  // rows covered per pass: 16 / 8
+  constexpr int PASSES = BM / RPP;                // 8 / 16
   const int grp = tid % GPR, rsub = tid / GPR;
-  const int ch0 = n0 + grp * KPV;
+  const int ch0 = n0 + grp * KPVO;
   const bool chok = ch0 < g.Cout;
-  float ssum[KPV], ssq[KPV];
+  float ssum[KPVO], ssq[KPVO];
 #pragma unroll
-  for (int e = 0; e < KPV; ++e) ssum[e] = ssq[e] = 0.f;
-  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+  for (int e = 0; e < KPVO; ++e) ssum[e] = ssq[e] = 0.f;
+  TO* __restrict__ yg = reinterpret_cast<TO*>(p.y);
 #pragma unroll 2
   for (int ps = 0; ps < PASSES; ++ps) {
     const int row = rsub + ps * RPP;
@@ -246,21 +252,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       const int rem = m - n * (g.Qh * g.Qw);
       const int qy = rem / g.Qw, qx = rem - qy * g.Qw;
       const int oy = qy * g.os + py, ox = qx * g.os + px;
-      T* dst = yg + ((size_t)(n * g.Hout + oy) * g.Wout + ox) * p.ldy + ch0;
+      TO* dst = yg + ((size_t)(n * g.Hout + oy) * g.Wout + ox) * p.ldy + ch0;
       vec16 v = *reinterpret_cast<const vec16*>(ct + row * CROW + grp * 16);
-      float f[KPV];
-      unpack(v, f, T());
+      float f[KPVO];
+      unpack(v, f, TO());
       if (p.accumulate) {
-        float o[KPV];
-        unpack(ldg16(dst), o, T());
+        float o[KPVO];
+        unpack(ldg16(dst), o, TO());
 #pragma unroll
-        for (int e = 0; e < KPV; ++e) f[e] += o[e];
-        pack(v, f, T());
-        unpack(v, f, T());
+        for (int e = 0; e < KPVO; ++e) f[e] += o[e];
+        pack(v, f, TO());
+        unpack(v, f, TO());
       }
       stg16(dst, v);
 #pragma unroll
-      for (int e = 0; e < KPV; ++e) {
+      for (int e = 0; e < KPVO; ++e) {
         ssum[e] += f[e];
         ssq[e] += f[e] * f[e];
       }
@@ -270,9 +276,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     __syncthreads();  // everyone is done reading the C tile
     float* red = reinterpret_cast<float*>(smem);  // [2][RPP][BN]
 #pragma unroll
-    for (int e = 0; e < KPV; ++e) {
-      red[(0 * RPP + rsub) * BN + grp * KPV + e] = ssum[e];
-      red[(1 * RPP + rsub) * BN + grp * KPV + e] = ssq[e];
+    for (int e = 0; e < KPVO; ++e) {
+      red[(0 * RPP + rsub) * BN + grp * KPVO + e] = ssum[e];
+      red[(1 * RPP + rsub) * BN + grp * KPVO + e] = ssq[e];
     }
     __syncthreads();
     const int which = tid >> 7, c = tid & 127;
@@ -287,17 +293,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 }
 
-template <typename T>
+template <typename T, bool OUT32>
 static int launch_igemm(const IgemmParams& p, hipStream_t st) {
-  constexpr int CROW = BN * (int)sizeof(T) + 16;
+  constexpr int CROW = BN * (int)(OUT32 ? 4 : sizeof(T)) + 16;
   const size_t lds = ((size_t)(4 * OPER_BYTES) > (size_t)BM * CROW ? (size_t)(4 * OPER_BYTES) : (size_t)BM * CROW) + 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, OUT32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(cdiv(p.g.Cout, BN) * p.mtiles * p.g.os * p.g.os);
-  hipLaunchKernelGGL(igemm_kernel<T>, grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((igemm_kernel<T, OUT32>), grid, dim3(256), lds, st, p);
   DC_CHECK_LAUNCH();
   return 0;
 }
@@ -308,7 +314,7 @@ static int check_view(const void* ptr, int ld, int c, int dtype, const char* wha
 
 static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int Wi, const void* in, int ldin,
                       const void* w, const float* bias, void* out, int ldout, float* slab, int accumulate,
-                      void* stream) {
+                      void* stream, bool out32 = false) {
   DC_REQUIRE(d != nullptr, "dc_conv: null descriptor");
   DC_REQUIRE(d->dtype == DC_F32 || d->dtype == DC_BF16, "dc_conv: bad dtype");
   DC_REQUIRE(d->transposed || d->k == 1 || d->k == 3, "dc_conv: kernel size must be 1 or 3");
@@ -317,7 +323,7 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   IgemmParams p;
   if (!build_geom(*d, Hi, Wi, mode, &p.g)) return dc_fail("dc_conv: odd extent under a stride-2 phase split", __FILE__, __LINE__);
   if (int e = check_view(in, ldin, p.g.Cin, d->dtype, "dc_conv input")) return e;
-  if (int e = check_view(out, ldout, p.g.Cout, d->dtype, "dc_conv output")) return e;
+  if (int e = check_view(out, ldout, p.g.Cout, out32 ? DC_F32 : d->dtype, "dc_conv output")) return e;
   DC_REQUIRE(w != nullptr && ((uintptr_t)w & 15) == 0, "dc_conv: weights null or unaligned");
   DC_REQUIRE(!(slab != nullptr && accumulate), "dc_conv: statistics and accumulate are exclusive");
   p.x = in; p.w = w; p.y = out; p.bias = bias; p.slab = slab;
@@ -328,7 +334,8 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   p.mtiles = cdiv(M, BM);
   p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
-  return d->dtype == DC_BF16 ? launch_igemm<bf16>(p, st) : launch_igemm<float>(p, st);
+  if (d->dtype == DC_BF16) return out32 ? launch_igemm<bf16, true>(p, st) : launch_igemm<bf16, false>(p, st);
+  return launch_igemm<float, false>(p, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -377,6 +384,11 @@ extern "C" int dc_conv_stat_rows(const dc_conv_desc* d, int N, int Hi, int Wi) {
 extern "C" int dc_conv_fwd(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,
                            const float* bias, void* y, int ldy, float* stat_slab, int accumulate, void* stream) {
   return run_gather(d, kFwd, N, Hi, Wi, x, ldx, wf, bias, y, ldy, stat_slab, accumulate, stream);
+}
+
+extern "C" int dc_conv_fwd_f32out(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,
+                                  float* y, int ldy, void* stream) {
+  return run_gather(d, kFwd, N, Hi, Wi, x, ldx, wf, nullptr, y, ldy, nullptr, 0, stream, true);
 }
 
 extern "C" int dc_conv_dgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy,

@@ -170,155 +170,117 @@ __global__ __launch_bounds__(256) void slab_rows_reduce_kernel(const float* __re
   }
 }
 
-// ------------------------------------------------------------------------------------------------- head forward
-// Thread <-> input pixel (qy,qx): produces the 2x2 output quad of all 3 classes from x00,x01,x10,x11.
-//   out(2qy  ,2qx  ) = x00.W[1][1]
-//   out(2qy  ,2qx+1) = x00.W[1][2] + x01.W[1][0]
-//   out(2qy+1,2qx  ) = x00.W[2][1] + x10.W[0][1]
-//   out(2qy+1,2qx+1) = x00.W[2][2] + x01.W[2][0] + x10.W[0][2] + x11.W[0][0]
-// Weights are wave-uniform -> scalar loads.
+// ------------------------------------------------------------------------------------------------- classifier head
+// ConvTranspose2d(Cin -> 3, k3, s2, p1, op1) as GEMMs on the MFMA kernels instead of a VALU stencil:
+//   forward   P[pixel][co*9+t] = x[pixel][:] . W[:, co, t]                (1x1 GEMM, N padded 27 -> 32, fp32 result)
+//             logits(2qy+py, 2qx+px) = sum of the 1/2/2/4 taps of P at (qy,qx), (qy,qx+1), (qy+1,qx), (qy+1,qx+1)
+//   backward  dP[pixel][co*9+t] = dlogits[n, co, 2qy-1+ky, 2qx-1+kx]      (gather, zero outside)
+//             dx = dP . W^T (1x1 data-gradient GEMM),   dW = x^T . dP (pixel-reduction GEMM)
 constexpr int HEAD_NC = 3;
+constexpr int HEAD_NP = 32;   // 27 products padded to an MFMA-friendly width
 
 template <typename T>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                       float* __restrict__ out, int N, int Cin, int Hi, int Wi) {
-  constexpr int KPV = Elem<T>::kPerVec;
-  const long P = (long)N * Hi * Wi;
+__global__ void head_pack_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb, int Cin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= HEAD_NP * Cin) return;
+  const int j = i / Cin, ci = i % Cin;
+  const float v = j < HEAD_NC * 9 ? w[(size_t)ci * (HEAD_NC * 9) + j] : 0.f;   // master [ci][co][ky][kx]
+  Elem<T>::store(wf + (size_t)j * Cin + ci, v);
+  Elem<T>::store(wb + (size_t)ci * HEAD_NP + j, v);
+}
+
+// out(2qy  ,2qx  ) = P00[4];                out(2qy  ,2qx+1) = P00[5] + P01[3]
+// out(2qy+1,2qx  ) = P00[7] + P10[1];       out(2qy+1,2qx+1) = P00[8] + P01[6] + P10[2] + P11[0]      (per class)
+__global__ __launch_bounds__(256) void head_combine_kernel(const float* __restrict__ P, float* __restrict__ out, int N, int Hi, int Wi) {
+  const long total = (long)N * Hi * Wi;
   const long pix = (long)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= P) return;
+  if (pix >= total) return;
   const int qx = (int)(pix % Wi);
   const long r = pix / Wi;
   const int qy = (int)(r % Hi);
   const int n = (int)(r / Hi);
   const bool hx = qx + 1 < Wi, hy = qy + 1 < Hi;
-  const T* p00 = x + (size_t)pix * ldx;
-  const T* p01 = p00 + ldx;
-  const T* p10 = p00 + (size_t)Wi * ldx;
-  const T* p11 = p10 + ldx;
-  float o[4][HEAD_NC];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int c = 0; c < HEAD_NC; ++c) o[q][c] = 0.f;
-  for (int c0 = 0; c0 < Cin; c0 += KPV) {
-    float a[KPV], b[KPV], c_[KPV], d[KPV];
-    unpack(ldg16(p00 + c0), a, T());
-    if (hx) unpack(ldg16(p01 + c0), b, T()); else { _Pragma("unroll") for (int e = 0; e < KPV; ++e) b[e] = 0.f; }
-    if (hy) unpack(ldg16(p10 + c0), c_, T()); else { _Pragma("unroll") for (int e = 0; e < KPV; ++e) c_[e] = 0.f; }
-    if (hx && hy) unpack(ldg16(p11 + c0), d, T()); else { _Pragma("unroll") for (int e = 0; e < KPV; ++e) d[e] = 0.f; }
-#pragma unroll
-    for (int e = 0; e < KPV; ++e) {
-      const float* we = w + (size_t)(c0 + e) * (HEAD_NC * 9);  // [ci][co][ky][kx]
-#pragma unroll
-      for (int co = 0; co < HEAD_NC; ++co) {
-        const float* k = we + co * 9;
-        o[0][co] = fmaf(a[e], k[4], o[0][co]);
-        o[1][co] = fmaf(a[e], k[5], fmaf(b[e], k[3], o[1][co]));
-        o[2][co] = fmaf(a[e], k[7], fmaf(c_[e], k[1], o[2][co]));
-        o[3][co] = fmaf(a[e], k[8], fmaf(b[e], k[6], fmaf(c_[e], k[2], fmaf(d[e], k[0], o[3][co]))));
-      }
-    }
-  }
+  const float* p00 = P + (size_t)pix * HEAD_NP;
+  const float* p01 = p00 + HEAD_NP;
+  const float* p10 = p00 + (size_t)Wi * HEAD_NP;
+  const float* p11 = p10 + HEAD_NP;
   const int Ho = 2 * Hi, Wo = 2 * Wi;
 #pragma unroll
   for (int co = 0; co < HEAD_NC; ++co) {
+    const float* a = p00 + co * 9;
+    const float o00 = a[4];
+    float o01 = a[5], o10 = a[7], o11 = a[8];
+    if (hx) { o01 += p01[co * 9 + 3]; o11 += p01[co * 9 + 6]; }
+    if (hy) { o10 += p10[co * 9 + 1]; o11 += p10[co * 9 + 2]; }
+    if (hx && hy) o11 += p11[co * 9 + 0];
     float* base = out + (((size_t)n * HEAD_NC + co) * Ho + 2 * qy) * Wo + 2 * qx;
-    *reinterpret_cast<float2*>(base) = make_float2(o[0][co], o[1][co]);
-    *reinterpret_cast<float2*>(base + Wo) = make_float2(o[2][co], o[3][co]);
+    *reinterpret_cast<float2*>(base) = make_float2(o00, o01);
+    *reinterpret_cast<float2*>(base + Wo) = make_float2(o10, o11);
   }
 }
 
-// ------------------------------------------------------------------------------------------------- head dgrad
-// dx[n,qy,qx,ci] = sum_{co,ky,kx} dl[n,co,2qy-1+ky,2qx-1+kx] * W[ci][co][ky][kx];  thread <-> (pixel, channel group)
 template <typename T>
-__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ w,
-                                                         T* __restrict__ dx, int lddx, int N, int Cin, int Hi, int Wi) {
-  constexpr int KPV = Elem<T>::kPerVec;
-  const int ngroups = Cin / KPV;
-  const long total = (long)N * Hi * Wi * ngroups;
+__global__ __launch_bounds__(256) void head_gather_kernel(const float* __restrict__ dl, T* __restrict__ dP, int N, int Hi, int Wi) {
+  const long total = (long)N * Hi * Wi;
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= total) return;
+  const int qx = (int)(pix % Wi);
+  const long r = pix / Wi;
+  const int qy = (int)(r % Hi);
+  const int n = (int)(r / Hi);
   const int Ho = 2 * Hi, Wo = 2 * Wi;
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int cg = (int)(idx % ngroups);
-    const long pix = idx / ngroups;
-    const int qx = (int)(pix % Wi);
-    const long r = pix / Wi;
-    const int qy = (int)(r % Hi);
-    const int n = (int)(r / Hi);
-    float g[HEAD_NC][9];
+  float v[HEAD_NP];
 #pragma unroll
-    for (int co = 0; co < HEAD_NC; ++co)
+  for (int j = 0; j < HEAD_NP; ++j) v[j] = 0.f;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int oy = 2 * qy - 1 + t / 3, ox = 2 * qx - 1 + t % 3;
-        g[co][t] = ((unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo)
-                       ? dl[(((size_t)n * HEAD_NC + co) * Ho + oy) * Wo + ox] : 0.f;
-      }
-    float acc[KPV];
-#pragma unroll
-    for (int e = 0; e < KPV; ++e) {
-      const float* we = w + (size_t)(cg * KPV + e) * (HEAD_NC * 9);
-      float a = 0.f;
-#pragma unroll
-      for (int co = 0; co < HEAD_NC; ++co)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) a = fmaf(g[co][t], we[co * 9 + t], a);
-      acc[e] = a;
-    }
-    vec16 v;
-    pack(v, acc, T());
-    stg16(dx + (size_t)pix * lddx + cg * KPV, v);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------- head wgrad
-// dW[ci][co][t] = sum_pix x[pix][ci] * dl[n,co,2qy-1+ky,2qx-1+kx].  grid (pixel blocks); block = 64 lanes x 3 classes;
-// lane <-> Cin/64 consecutive channels; dl values are wave-uniform.
-template <typename T, int CPL>
-__global__ __launch_bounds__(192) void head_wgrad_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ dl,
-                                                         float* __restrict__ slab, int N, int Cin, int Hi, int Wi,
-                                                         int pix_per_block) {
-  const int lane = threadIdx.x, co = threadIdx.y;
-  const int c0 = lane * CPL;
-  const long P = (long)N * Hi * Wi;
-  const long pbeg = (long)blockIdx.x * pix_per_block;
-  const long pend = pbeg + pix_per_block < P ? pbeg + pix_per_block : P;
-  const int Ho = 2 * Hi, Wo = 2 * Wi;
-  float acc[9][CPL];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int e = 0; e < CPL; ++e) acc[t][e] = 0.f;
-  for (long pix = pbeg; pix < pend; ++pix) {
-    const int qx = (int)(pix % Wi);
-    const long r = pix / Wi;
-    const int qy = (int)(r % Hi);
-    const int n = (int)(r / Hi);
-    float xv[CPL];
-#pragma unroll
-    for (int e = 0; e < CPL; ++e) xv[e] = Elem<T>::load(x + (size_t)pix * ldx + c0 + e);
-    const float* dlp = dl + ((size_t)n * HEAD_NC + co) * Ho * Wo;
+  for (int co = 0; co < HEAD_NC; ++co)
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int oy = 2 * qy - 1 + t / 3, ox = 2 * qx - 1 + t % 3;
-      if ((unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo) {
-        const float g = dlp[(size_t)oy * Wo + ox];
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) acc[t][e] = fmaf(xv[e], g, acc[t][e]);
-      }
+      if ((unsigned)oy < (unsigned)Ho && (unsigned)ox < (unsigned)Wo) v[co * 9 + t] = dl[(((size_t)n * HEAD_NC + co) * Ho + oy) * Wo + ox];
     }
+  constexpr int KPV = Elem<T>::kPerVec;
+  T* dst = dP + (size_t)pix * HEAD_NP;
+#pragma unroll
+  for (int q = 0; q < HEAD_NP / KPV; ++q) {
+    float f[KPV];
+#pragma unroll
+    for (int e = 0; e < KPV; ++e) f[e] = v[q * KPV + e];
+    vec16 o;
+    pack(o, f, T());
+    stg16(dst + q * KPV, o);
   }
-#pragma unroll
-  for (int e = 0; e < CPL; ++e)
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-      slab[(size_t)blockIdx.x * (Cin * HEAD_NC * 9) + (size_t)(c0 + e) * (HEAD_NC * 9) + co * 9 + t] = acc[t][e];
 }
 
-static int head_ppb(long P) {
-  long ppb = (P + 2047) / 2048;
-  if (ppb < 16) ppb = 16;
-  return (int)ppb;
+// grad[ci][co][ky][kx] = tmp[(co*9+t)][ci]
+__global__ void head_wfinish_kernel(const float* __restrict__ tmp, float* __restrict__ grad, int Cin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cin * HEAD_NC * 9) return;
+  const int ci = i / (HEAD_NC * 9), j = i % (HEAD_NC * 9);
+  grad[i] = tmp[(size_t)j * Cin + ci];
 }
+
+// ------------------------------------------------------------------------------------------------- input layout
+// NCHW fp32 (the reference's batch layout) -> NHWC T.  One thread per (pixel, 16-byte channel group): the per-channel
+// reads are coalesced along W, the write is one vector.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ out, int ldo, int N, int Cc, long HW) {
+  constexpr int KPV = Elem<T>::kPerVec;
+  const int ngroups = Cc / KPV;
+  const long total = (long)N * HW * ngroups;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i % (N * HW);          // pixel fastest: neighbouring lanes read neighbouring W positions
+    const int cg = (int)(i / (N * HW));
+    const long n = pix / HW, p = pix % HW;
+    float f[KPV];
+#pragma unroll
+    for (int e = 0; e < KPV; ++e) f[e] = x[((size_t)n * Cc + cg * KPV + e) * HW + p];
+    vec16 v;
+    pack(v, f, T());
+    stg16(out + (size_t)pix * ldo + cg * KPV, v);
+  }
+}
+
 static int stem_ppb(long P) {
   long ppb = (P + 1023) / 1024;
   ppb = (ppb + 63) / 64 * 64;
@@ -375,59 +337,87 @@ extern "C" int dc_stem_wgrad(int dtype, int N, int Cin, int H, int W, const floa
   return 0;
 }
 
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct HeadWs {
+  float* P; void* dP; void* wf; void* wb; float* tmp; void* slabs; size_t slab_bytes; size_t total;
+};
+static HeadWs head_ws(int dtype, int N, int Cin, int Hi, int Wi, void* base) {
+  const size_t es = dtype == DC_BF16 ? 2 : 4;
+  const size_t M = (size_t)N * Hi * Wi;
+  dc_conv_desc d{dtype, 1, 1, 0, 1, 0, Cin, HEAD_NP};
+  HeadWs w;
+  char* p = (char*)base;
+  size_t off = 0;
+  w.P = (float*)(p + off); off += align256(M * HEAD_NP * 4);
+  w.dP = p + off; off += align256(M * HEAD_NP * es);
+  w.wf = p + off; off += align256((size_t)HEAD_NP * Cin * es);
+  w.wb = p + off; off += align256((size_t)HEAD_NP * Cin * es);
+  w.tmp = (float*)(p + off); off += align256((size_t)HEAD_NP * Cin * 4);
+  w.slabs = p + off;
+  w.slab_bytes = dc_conv_wgrad_workspace(&d, N, Hi, Wi);
+  off += align256(w.slab_bytes);
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t dc_head_workspace(int dtype, int N, int Cin, int Hi, int Wi) { return head_ws(dtype, N, Cin, Hi, Wi, nullptr).total; }
+
 extern "C" int dc_head_fwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* w,
-                           float* logits_nchw, void* stream) {
+                           float* logits_nchw, void* workspace, void* stream) {
   if (int e = dc_check_view(x, ldx, Cin, dtype, "dc_head_fwd x")) return e;
-  DC_REQUIRE(w && logits_nchw && N > 0, "dc_head_fwd: bad argument");
-  DC_REQUIRE(((uintptr_t)logits_nchw & 7) == 0, "dc_head_fwd: logits not 8-byte aligned");
-  const long P = (long)N * Hi * Wi;
+  DC_REQUIRE(w && logits_nchw && workspace && N > 0, "dc_head_fwd: bad argument");
+  DC_REQUIRE(((uintptr_t)logits_nchw & 7) == 0 && ((uintptr_t)workspace & 255) == 0, "dc_head_fwd: logits / workspace alignment");
+  HeadWs ws = head_ws(dtype, N, Cin, Hi, Wi, workspace);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DC_BF16)
-    hipLaunchKernelGGL(head_fwd_kernel<bf16>, dim3(cdiv(P, 256)), dim3(256), 0, st, (const bf16*)x, ldx, w, logits_nchw, N, Cin, Hi, Wi);
-  else
-    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(cdiv(P, 256)), dim3(256), 0, st, (const float*)x, ldx, w, logits_nchw, N, Cin, Hi, Wi);
+  const int np = HEAD_NP * Cin;
+  if (dtype == DC_BF16) hipLaunchKernelGGL(head_pack_kernel<bf16>, dim3(cdiv(np, 256)), dim3(256), 0, st, w, (bf16*)ws.wf, (bf16*)ws.wb, Cin);
+  else hipLaunchKernelGGL(head_pack_kernel<float>, dim3(cdiv(np, 256)), dim3(256), 0, st, w, (float*)ws.wf, (float*)ws.wb, Cin);
+  DC_CHECK_LAUNCH();
+  dc_conv_desc d{dtype, 1, 1, 0, 1, 0, Cin, HEAD_NP};
+  if (int e = dc_conv_fwd_f32out(&d, N, Hi, Wi, x, ldx, ws.wf, ws.P, HEAD_NP, stream)) return e;
+  const long P = (long)N * Hi * Wi;
+  hipLaunchKernelGGL(head_combine_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, (const float*)ws.P, logits_nchw, N, Hi, Wi);
   DC_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int dc_head_dgrad(int dtype, int N, int Cin, int Hi, int Wi, const float* dlogits_nchw, const float* w,
-                             void* dx, int lddx, void* stream) {
-  if (int e = dc_check_view(dx, lddx, Cin, dtype, "dc_head_dgrad dx")) return e;
-  DC_REQUIRE(w && dlogits_nchw && N > 0, "dc_head_dgrad: bad argument");
+extern "C" int dc_head_bwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
+                           const float* w, void* dx, int lddx, float* grad_w, void* workspace, void* stream) {
+  if (int e = dc_check_view(x, ldx, Cin, dtype, "dc_head_bwd x")) return e;
+  if (int e = dc_check_view(dx, lddx, Cin, dtype, "dc_head_bwd dx")) return e;
+  DC_REQUIRE(w && dlogits_nchw && grad_w && workspace && N > 0, "dc_head_bwd: bad argument");
+  DC_REQUIRE(((uintptr_t)workspace & 255) == 0, "dc_head_bwd: workspace must be 256-byte aligned");
+  HeadWs ws = head_ws(dtype, N, Cin, Hi, Wi, workspace);
+  hipStream_t st = (hipStream_t)stream;
+  const long P = (long)N * Hi * Wi;
+  const int np = HEAD_NP * Cin;
+  // (the packed weights are rebuilt here too: backward may follow a forward that ran in another engine / workspace)
+  if (dtype == DC_BF16) {
+    hipLaunchKernelGGL(head_pack_kernel<bf16>, dim3(cdiv(np, 256)), dim3(256), 0, st, w, (bf16*)ws.wf, (bf16*)ws.wb, Cin);
+    hipLaunchKernelGGL(head_gather_kernel<bf16>, dim3(cdiv(P, 256)), dim3(256), 0, st, dlogits_nchw, (bf16*)ws.dP, N, Hi, Wi);
+  } else {
+    hipLaunchKernelGGL(head_pack_kernel<float>, dim3(cdiv(np, 256)), dim3(256), 0, st, w, (float*)ws.wf, (float*)ws.wb, Cin);
+    hipLaunchKernelGGL(head_gather_kernel<float>, dim3(cdiv(P, 256)), dim3(256), 0, st, dlogits_nchw, (float*)ws.dP, N, Hi, Wi);
+  }
+  DC_CHECK_LAUNCH();
+  dc_conv_desc d{dtype, 1, 1, 0, 1, 0, Cin, HEAD_NP};
+  if (int e = dc_conv_wgrad(&d, N, Hi, Wi, x, ldx, ws.dP, HEAD_NP, ws.slabs, ws.slab_bytes, ws.tmp, stream)) return e;
+  hipLaunchKernelGGL(head_wfinish_kernel, dim3(cdiv(Cin * HEAD_NC * 9, 256)), dim3(256), 0, st, (const float*)ws.tmp, grad_w, Cin);
+  DC_CHECK_LAUNCH();
+  return dc_conv_dgrad(&d, N, Hi, Wi, ws.dP, HEAD_NP, ws.wb, dx, lddx, 0, stream);
+}
+
+extern "C" int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, void* out, int ldo, void* stream) {
+  if (int e = dc_check_view(out, ldo, C, dtype, "dc_nchw_to_nhwc out")) return e;
+  DC_REQUIRE(x_nchw && N > 0 && H > 0 && W > 0, "dc_nchw_to_nhwc: bad argument");
   const int kpv = dtype == DC_BF16 ? 8 : 4;
-  const long total = (long)N * Hi * Wi * (Cin / kpv);
+  const long total = (long)N * H * W * (C / kpv);
   long blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DC_BF16)
-    hipLaunchKernelGGL(head_dgrad_kernel<bf16>, dim3((int)blocks), dim3(256), 0, st, dlogits_nchw, w, (bf16*)dx, lddx, N, Cin, Hi, Wi);
-  else
-    hipLaunchKernelGGL(head_dgrad_kernel<float>, dim3((int)blocks), dim3(256), 0, st, dlogits_nchw, w, (float*)dx, lddx, N, Cin, Hi, Wi);
-  DC_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" size_t dc_head_wgrad_workspace(int N, int Cin, int Hi, int Wi) {
-  const long P = (long)N * Hi * Wi;
-  return (size_t)cdiv(P, head_ppb(P)) * Cin * HEAD_NC * 9 * sizeof(float);
-}
-
-extern "C" int dc_head_wgrad(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx,
-                             const float* dlogits_nchw, void* workspace, float* grad_w, void* stream) {
-  if (int e = dc_check_view(x, ldx, Cin, dtype, "dc_head_wgrad x")) return e;
-  DC_REQUIRE(dlogits_nchw && workspace && grad_w && N > 0, "dc_head_wgrad: bad argument");
-  DC_REQUIRE(Cin == 256, "dc_head_wgrad: Cin must be 256 (64 lanes x 4 channels)");
-  const long P = (long)N * Hi * Wi;
-  const int ppb = head_ppb(P);
-  const int rows = cdiv(P, ppb);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == DC_BF16)
-    hipLaunchKernelGGL((head_wgrad_kernel<bf16, 4>), dim3(rows), dim3(64, 3), 0, st, (const bf16*)x, ldx, dlogits_nchw, (float*)workspace, N, Cin, Hi, Wi, ppb);
-  else
-    hipLaunchKernelGGL((head_wgrad_kernel<float, 4>), dim3(rows), dim3(64, 3), 0, st, (const float*)x, ldx, dlogits_nchw, (float*)workspace, N, Cin, Hi, Wi, ppb);
-  DC_CHECK_LAUNCH();
-  const long n = (long)Cin * HEAD_NC * 9;
-  hipLaunchKernelGGL(slab_rows_reduce_kernel, dim3(cdiv(n, 8)), dim3(256), 0, st, (const float*)workspace, grad_w, rows, n);
+  if (dtype == DC_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3((int)blocks), dim3(256), 0, st, x_nchw, (bf16*)out, ldo, N, C, (long)H * W);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3((int)blocks), dim3(256), 0, st, x_nchw, (float*)out, ldo, N, C, (long)H * W);
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -319,27 +319,41 @@ class Engine:
         lib = L.load()
         B, H, W = self.B, self.H, self.W
         X = "xception_features."
-        # ---- stem: reads NCHW fp32 input directly
-        c1 = Act(self, "stem", B, H // 2, W // 2, 32)
-        srows = lib.dc_stem_stat_rows(B, H, W)
-        sslab = self._f32(2 * srows * 32)
-        self._need_ws(lib.dc_stem_wgrad_workspace(B, self.n_input, H, W))
+        # ---- stem.  16 input channels: one layout pass (NCHW fp32 -> NHWC T) and the 3x3/s2 conv runs on the MFMA kernels
+        #      (forward and weight gradient; the input needs no data gradient).  Other channel counts (--channels subsets)
+        #      use the dedicated direct-convolution kernels that read NCHW in place.
         w1 = X + "conv1.weight"
+        kpv = 8 if self.dtype == torch.bfloat16 else 4
+        if self.n_input % kpv == 0:
+            x0 = Act(self, "x_nhwc", B, H, W, self.n_input)
 
-        def stem_fwd():
-            L.call("dc_stem_fwd", self.dt, B, self.n_input, H, W, L.dptr(self.x_in), self.pptr(w1), c1.ptr, c1.ld, L.dptr(sslab), self._st())
+            def layout_fwd():
+                L.call("dc_nchw_to_nhwc", self.dt, B, self.n_input, H, W, L.dptr(self.x_in), x0.ptr, x0.ld, self._st())
 
-        self.fwd_train.append(stem_fwd)
-        self.fwd_eval.append(stem_fwd)
+            self.fwd_train.append(layout_fwd)
+            self.fwd_eval.append(layout_fwd)
+            self.bwd.append(lambda: ((lambda: None), []))
+            c1, sslab, srows = self._conv(x0, w1, 32, k=3, stride=2, pad=1, name="stem", need_dx=False)
+        else:
+            c1 = Act(self, "stem", B, H // 2, W // 2, 32)
+            srows = lib.dc_stem_stat_rows(B, H, W)
+            sslab = self._f32(2 * srows * 32)
+            self._need_ws(lib.dc_stem_wgrad_workspace(B, self.n_input, H, W))
 
-        def stem_bwd_make():
-            dy = c1.grad
+            def stem_fwd():
+                L.call("dc_stem_fwd", self.dt, B, self.n_input, H, W, L.dptr(self.x_in), self.pptr(w1), c1.ptr, c1.ld, L.dptr(sslab), self._st())
 
-            def bwd():
-                L.call("dc_stem_wgrad", self.dt, B, self.n_input, H, W, L.dptr(self.x_in), dy.ptr, dy.ld, self._wsptr(), self.gptr(w1), self._st())
-            return bwd, [w1]
+            self.fwd_train.append(stem_fwd)
+            self.fwd_eval.append(stem_fwd)
 
-        self.bwd.append(stem_bwd_make)
+            def stem_bwd_make():
+                dy = c1.grad
+
+                def bwd():
+                    L.call("dc_stem_wgrad", self.dt, B, self.n_input, H, W, L.dptr(self.x_in), dy.ptr, dy.ld, self._wsptr(), self.gptr(w1), self._st())
+                return bwd, [w1]
+
+            self.bwd.append(stem_bwd_make)
         x = self._bn(c1, sslab, srows, X + "bn1", True)
         y, slab, rows = self._conv(x, X + "conv2.weight", 64, k=3, pad=1)
         x = self._bn(y, slab, rows, X + "bn2", True)
@@ -435,12 +449,15 @@ class Engine:
         y, slab, rows = self._conv(y, U + "deconv3.0.weight", 256, transposed=True, name="deconv3")
         a = self._bn(y, slab, rows, U + "deconv3.1", True)
 
-        # ---- classifier head -> NCHW fp32 logits
+        # ---- classifier head -> NCHW fp32 logits (GEMM + sub-pixel tap combination, own workspace: P must survive to bwd? no,
+        #      it is recomputed from dlogits; the workspace only has to be private to the head)
         wl = U + "last_deconv.0.weight"
-        self._need_ws(lib.dc_head_wgrad_workspace(B, 256, a.H, a.W))
+        hws = torch.empty(lib.dc_head_workspace(self.dt, B, 256, a.H, a.W) + 256, dtype=torch.uint8, device=self.device)
+        self._keep.append(hws)
+        hptr = C.c_void_p((hws.data_ptr() + 255) // 256 * 256)
 
         def head_fwd():
-            L.call("dc_head_fwd", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, self.pptr(wl), L.dptr(self.logits), self._st())
+            L.call("dc_head_fwd", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, self.pptr(wl), L.dptr(self.logits), hptr, self._st())
 
         self.fwd_train.append(head_fwd)
         self.fwd_eval.append(head_fwd)
@@ -450,8 +467,8 @@ class Engine:
             da = a.grad
 
             def bwd():
-                L.call("dc_head_wgrad", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, L.dptr(self.dlogits), self._wsptr(), self.gptr(wl), self._st())
-                L.call("dc_head_dgrad", self.dt, B, 256, a.H, a.W, L.dptr(self.dlogits), self.pptr(wl), da.ptr, da.ld, self._st())
+                L.call("dc_head_bwd", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, L.dptr(self.dlogits), self.pptr(wl), da.ptr, da.ld,
+                       self.gptr(wl), hptr, self._st())
             return bwd, [wl]
 
         self.bwd.append(head_bwd_make)

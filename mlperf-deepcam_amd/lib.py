@@ -34,6 +34,7 @@ _SIGS = {
     "dc_conv_pack_weights": (I, [CD, P, P, P, P]),
     "dc_conv_stat_rows": (I, [CD, I, I, I]),
     "dc_conv_fwd": (I, [CD, I, I, I, P, I, P, P, P, I, P, I, P]),
+    "dc_conv_fwd_f32out": (I, [CD, I, I, I, P, I, P, P, I, P]),
     "dc_conv_dgrad": (I, [CD, I, I, I, P, I, P, P, I, I, P]),
     "dc_conv_wgrad_workspace": (SZ, [CD, I, I, I]),
     "dc_conv_wgrad": (I, [CD, I, I, I, P, I, P, I, P, SZ, P, P]),
@@ -56,10 +57,10 @@ _SIGS = {
     "dc_stem_fwd": (I, [I, I, I, I, I, P, P, P, I, P, P]),
     "dc_stem_wgrad_workspace": (SZ, [I, I, I, I]),
     "dc_stem_wgrad": (I, [I, I, I, I, I, P, P, I, P, P, P]),
-    "dc_head_fwd": (I, [I, I, I, I, I, P, I, P, P, P]),
-    "dc_head_dgrad": (I, [I, I, I, I, I, P, P, P, I, P]),
-    "dc_head_wgrad_workspace": (SZ, [I, I, I, I]),
-    "dc_head_wgrad": (I, [I, I, I, I, I, P, I, P, P, P, P]),
+    "dc_head_workspace": (SZ, [I, I, I, I, I]),
+    "dc_head_fwd": (I, [I, I, I, I, I, P, I, P, P, P, P]),
+    "dc_head_bwd": (I, [I, I, I, I, I, P, I, P, P, P, I, P, P, P]),
+    "dc_nchw_to_nhwc": (I, [I, I, I, I, I, P, P, I, P]),
     "dc_wce_fused": (I, [I, I, I, P, P, I, P, F, P, P, P, P, P]),
     "dc_confusion_counts": (I, [L, P, P, I, P, P]),
     "dc_avgpool_fwd": (I, [I, I, I, I, P, I, P, P]),
