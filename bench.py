@@ -70,43 +70,42 @@ def cpu_baseline(local_batch, H, W, budget_s=30.0):
 
 
 class KernelTimer:
-    """HIP-event timing of every launch of the dominant kernel family (dense-conv implicit GEMM: dc_conv_fwd and
-    dc_conv_dgrad both launch dc::igemm_kernel<T>) on the stream the kernels run on."""
+    """HIP-event timing of every launch of the two MFMA kernel families on the stream they run on:
+       igemm  dc::igemm_kernel<T>  (dc_conv_fwd + dc_conv_dgrad: dense conv forward and data gradient)
+       wgrad  dc::wgrad_kernel<T>  (+ its slab reduction; dc_conv_wgrad: dense conv weight gradient)"""
+
+    FAMILY = {"dc_conv_fwd": "igemm", "dc_conv_dgrad": "igemm", "dc_conv_wgrad": "wgrad"}
 
     def __init__(self, lib_module):
         self.L = lib_module
-        self.events = []
-        self.flops = 0.0
+        self.events = {"igemm": [], "wgrad": []}
+        self.flops = {"igemm": 0.0, "wgrad": 0.0}
         self._orig = lib_module.call
 
     def __enter__(self):
-        L = self.L
         timer = self
 
         def call(name, *args):
-            if name in ("dc_conv_fwd", "dc_conv_dgrad"):
-                d = args[0]._obj
-                N, Hi, Wi = args[1], args[2], args[3]
-                k = 3 if d.transposed else d.k
-                if d.transposed:
-                    macs = N * Hi * Wi * d.cin * d.cout * 9
-                else:
-                    Ho = (Hi + 2 * d.pad - d.dil * (k - 1) - 1) // d.stride + 1
-                    Wo = (Wi + 2 * d.pad - d.dil * (k - 1) - 1) // d.stride + 1
-                    macs = N * Ho * Wo * d.cin * d.cout * k * k
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                timer._orig(name, *args)
-                e1.record()
-                timer.events.append((e0, e1))
-                timer.flops += 2.0 * macs
+            fam = timer.FAMILY.get(name)
+            if fam is None:
+                return timer._orig(name, *args)
+            d = args[0]._obj
+            N, Hi, Wi = args[1], args[2], args[3]
+            k = 3 if d.transposed else d.k
+            if d.transposed:
+                macs = N * Hi * Wi * d.cin * d.cout * 9
             else:
-                timer._orig(name, *args)
+                Ho = (Hi + 2 * d.pad - d.dil * (k - 1) - 1) // d.stride + 1
+                Wo = (Wi + 2 * d.pad - d.dil * (k - 1) - 1) // d.stride + 1
+                macs = N * Ho * Wo * d.cin * d.cout * k * k
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            timer._orig(name, *args)
+            e1.record()
+            timer.events[fam].append((e0, e1))
+            timer.flops[fam] += 2.0 * macs
 
-        L.call = call
-        import mlperf_deepcam_amd.engine as E
-        import mlperf_deepcam_amd.nn as NN
-        self._mods = (E.L, NN.L)
+        self.L.call = call
         return self
 
     def __exit__(self, *exc):
@@ -114,8 +113,10 @@ class KernelTimer:
 
     def result(self):
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in self.events)
-        return self.flops, ms * 1e-3, len(self.events)
+        out = {}
+        for fam, evs in self.events.items():
+            out[fam] = (self.flops[fam], sum(a.elapsed_time(b) for a, b in evs) * 1e-3, len(evs))
+        return out
 
 
 def main():
@@ -123,9 +124,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--local_batch_size", type=int, default=2)
+    ap.add_argument("--local_batch_size", type=int, default=8, help="per-GPU batch; 8 = BASELINE configs[4] (global 64 on 8 GPUs)")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
-    ap.add_argument("--optimizer", choices=["Adam", "AdamW", "LAMB"], default="AdamW")
+    ap.add_argument("--optimizer", choices=["Adam", "AdamW", "LAMB"], default="LAMB")
     ap.add_argument("--height", type=int, default=768)
     ap.add_argument("--width", type=int, default=1152)
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -161,6 +162,11 @@ def main():
         step.after_backward = reducer.finish
         opt.grad_scale = 1.0 / world
     x, y = synthetic_batch(B, H, W, 1234 + rank, dev)
+    graphed = False
+    if world == 1 and not a.no_graph:
+        step(x, y)
+        step.enable_graph()
+        graphed = True
 
     def barrier():
         if world > 1:
@@ -185,15 +191,25 @@ def main():
     # ---- roofline of the dominant kernel family, timed per launch with HIP events on the launch stream ----------------
     roof = None
     if rank == 0:
+        step.graphed = False                     # per-launch events need eager launches (same kernels, same stream)
         with KernelTimer(L) as kt:
             for _ in range(min(a.steps, 3)):
                 step(x, y)
-            flops, secs, n = kt.result()
+            fams = kt.result()
+        step.graphed = graphed
         peak = PEAK[a.dtype]
-        ach = flops / secs if secs > 0 else 0.0
-        roof = {"bound": "mfma", "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "kernel": f"dc::igemm_kernel<{a.dtype}> (dense conv fwd + dgrad)",
-                "launches_timed": n, "avg_launch_us": round(secs / max(n, 1) * 1e6, 2),
+        names = {"igemm": f"dc::igemm_kernel<{a.dtype}> (dense conv forward + data gradient, gather-form implicit GEMM)",
+                 "wgrad": f"dc::wgrad_kernel<{a.dtype}> + dc::wgrad_reduce_kernel (dense conv weight gradient)"}
+        dom = max(fams, key=lambda f: fams[f][1])
+        def entry(f):
+            fl, secs, n = fams[f]
+            ach = fl / secs if secs > 0 else 0.0
+            return {"kernel": names[f], "achieved": round(ach / 1e12, 2), "frac": round(ach / peak, 4), "launches_timed": n,
+                    "avg_launch_us": round(secs / max(n, 1) * 1e6, 2), "ms_per_step": round(secs / min(a.steps, 3) * 1e3, 3)}
+        e = entry(dom)
+        roof = {"bound": "mfma", "achieved": e["achieved"], "peak": peak / 1e12, "unit": "TFLOP/s", "frac": e["frac"], "traffic": None,
+                "kernel": e["kernel"], "launches_timed": e["launches_timed"], "avg_launch_us": e["avg_launch_us"],
+                "ms_per_step": e["ms_per_step"], "other_mfma_kernel": entry([f for f in fams if f != dom][0]),
                 "whole_step_frac": round(sps / world * FLOP_PER_SAMPLE * (H * W) / (768 * 1152) / peak, 4)}
     if world > 1:
         dist.barrier()
@@ -206,7 +222,7 @@ def main():
                                       f"{' + RCCL grad all-reduce' if world > 1 else ''}), {H}x{W}x16, local_batch={B}, "
                                       f"{a.dtype} activations / fp32 master weights, random-init seed 333",
                           "local_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": a.optimizer,
-                          "hip_graph": False},
+                          "hip_graph": graphed},
                "loss_last_step": round(loss, 6), "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:
             try:

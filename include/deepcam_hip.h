@@ -32,6 +32,8 @@ enum { DC_ADAM = 0, DC_ADAMW = 1, DC_LAMB = 2 };
 
 const char* dc_last_error(void);
 int dc_version(void);
+/* Tuning switches (A/B measurements inside one process).  "igemm_glds": 1 = LDS-DMA operand staging (default), 0 = register staging. */
+int dc_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense convolution family: nn.Conv2d (k=1 or 3, stride 1|2, dilation, zero padding) and

@@ -9,6 +9,8 @@
 //   epilogue  accumulators -> LDS C tile -> fully coalesced 16-B NHWC stores; optional bias, optional
 //             read-modify-write accumulate, optional per-channel sum / sum-of-squares partials of the STORED
 //             values for the following train-mode BatchNorm (deterministic slab, no atomics)
+#include <string.h>
+
 #include <type_traits>
 
 #include "conv_geom.h"
@@ -53,7 +55,16 @@ struct Mma<float> {
 
 __device__ inline int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T, bool OUT32>
+// 16 zero bytes in global memory: the source of every predicated-off LDS-DMA lane (zero fill of halos, K and M tails)
+__device__ __attribute__((aligned(256))) unsigned char dc_zero_page[256];
+
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// GLDS: stage operand tiles with the gfx950 LDS-DMA (global_load_lds_dwordx4: global -> LDS without passing through
+// VGPRs and without ds_write instructions, which at ~79 B/clk/CU were the bottleneck of the register-staged loop).
+// The LDS image is lane-linear per wave instruction, so the XOR swizzle is applied to the per-lane SOURCE address.
+template <typename T, bool OUT32, bool GLDS>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   typedef typename std::conditional<OUT32, float, T>::type TO;   // stored output type
   constexpr int KPV = Elem<T>::kPerVec;      // elements per 16 B
@@ -122,42 +133,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
 
-  vec16 ra[4], rb[4];
-  auto load_step = [&](int tapi, int kc) {
-    const int dy = s_tap[3 * tapi], dx = s_tap[3 * tapi + 1], widx = s_tap[3 * tapi + 2];
-    const int kofs = kc * BK + slot * KPV;
-    const bool kok = kofs < g.Cin;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int iy = riy[i] + dy, ix = rix[i] + dx;
-      const bool ok = kok && rok[i] && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
-      if (ok) {
-        const size_t off = ((size_t)(rowbase[i] + iy) * g.Win + ix) * p.ldx + kofs;
-        rb[i] = ldg16(xg + off);
-      } else {
-        rb[i] = zero16();
-      }
-      const int ch = n0 + (tid >> 3) + 32 * i;
-      if (kok && ch < g.Cout) {
-        const size_t off = ((size_t)widx * g.Cout + ch) * g.Cin + kofs;
-        ra[i] = ldg16(wg + off);
-      } else {
-        ra[i] = zero16();
-      }
-    }
-  };
-  auto store_step = [&](int buf) {
-    char* wa = smem + buf * (2 * OPER_BYTES);
-    char* xb = wa + OPER_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = (tid >> 3) + 32 * i;
-      const int o = swz(r, slot);
-      *reinterpret_cast<vec16*>(wa + o) = ra[i];
-      *reinterpret_cast<vec16*>(xb + o) = rb[i];
-    }
-  };
-
   f32x4 acc[4][4];  // [channel rep][pixel rep]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -167,21 +142,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int wn = wave & 1, wm = wave >> 1;
   const int fr = lane & 15, fg = lane >> 4;
 
-  if (steps > 0) {
-    load_step(0, 0);
-    store_step(0);
-  }
-  __syncthreads();
-  int tapi = 0, kc = 0;
-  for (int s = 0; s < steps; ++s) {
-    int ntapi = tapi, nkc = kc + 1;
-    if (nkc == kchunks) {
-      nkc = 0;
-      ++ntapi;
-    }
-    const bool more = (s + 1) < steps;
-    if (more) load_step(ntapi, nkc);
-    const char* wa = smem + (s & 1) * (2 * OPER_BYTES);
+  auto compute = [&](int buf) {
+    const char* wa = smem + buf * (2 * OPER_BYTES);
     const char* xb = wa + OPER_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -198,10 +160,86 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
     }
-    if (more) store_step((s + 1) & 1);
+  };
+  auto next_step = [&](int& tapi, int& kc) {
+    if (++kc == kchunks) {
+      kc = 0;
+      ++tapi;
+    }
+  };
+
+  if constexpr (GLDS) {
+    // this thread's LDS slot is physical (tid&7) of row (tid>>3)+32i; it holds logical slot (tid&7)^((row>>1)&7),
+    // and ((row>>1)&7) == ((tid>>4)&7) for all four rows
+    const int lslot = (tid & 7) ^ ((tid >> 4) & 7);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    auto issue = [&](int tapi, int kc, int buf) {
+      const int dy = s_tap[3 * tapi], dx = s_tap[3 * tapi + 1], widx = s_tap[3 * tapi + 2];
+      const int kofs = kc * BK + lslot * KPV;
+      const bool kok = kofs < g.Cin;
+      char* wa = smem + buf * (2 * OPER_BYTES);
+      char* xb = wa + OPER_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = riy[i] + dy, ix = rix[i] + dx;
+        const bool ok = kok && rok[i] && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+        const void* srcx = ok ? (const void*)(xg + (((size_t)(rowbase[i] + iy) * g.Win + ix) * p.ldx + kofs)) : (const void*)dc_zero_page;
+        const int ch = n0 + (tid >> 3) + 32 * i;
+        const void* srcw = (kok && ch < g.Cout) ? (const void*)(wg + (((size_t)widx * g.Cout + ch) * g.Cin + kofs)) : (const void*)dc_zero_page;
+        const int rowoff = (32 * i + 8 * wv) * ROWB;   // wave-uniform: this instruction fills 8 rows = 1 KiB
+        __builtin_amdgcn_global_load_lds((gas_ptr)srcw, (lds_ptr)(wa + rowoff), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gas_ptr)srcx, (lds_ptr)(xb + rowoff), 16, 0, 0);
+      }
+    };
+    int tapi = 0, kc = 0;
+    if (steps > 0) issue(0, 0, 0);
+    __syncthreads();   // (waits vmcnt(0): stage 0 has landed for every wave)
+    for (int s = 0; s < steps; ++s) {
+      next_step(tapi, kc);
+      if (s + 1 < steps) issue(tapi, kc, (s + 1) & 1);
+      compute(s & 1);
+      __syncthreads();   // drains this wave's LDS-DMA (vmcnt(0)) and orders it before the next iteration's reads
+    }
+  } else {
+    vec16 ra[4], rb[4];
+    auto load_step = [&](int tapi, int kc) {
+      const int dy = s_tap[3 * tapi], dx = s_tap[3 * tapi + 1], widx = s_tap[3 * tapi + 2];
+      const int kofs = kc * BK + slot * KPV;
+      const bool kok = kofs < g.Cin;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = riy[i] + dy, ix = rix[i] + dx;
+        const bool ok = kok && rok[i] && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+        rb[i] = ok ? ldg16(xg + (((size_t)(rowbase[i] + iy) * g.Win + ix) * p.ldx + kofs)) : zero16();
+        const int ch = n0 + (tid >> 3) + 32 * i;
+        ra[i] = (kok && ch < g.Cout) ? ldg16(wg + (((size_t)widx * g.Cout + ch) * g.Cin + kofs)) : zero16();
+      }
+    };
+    auto store_step = [&](int buf) {
+      char* wa = smem + buf * (2 * OPER_BYTES);
+      char* xb = wa + OPER_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 3) + 32 * i;
+        const int o = swz(r, slot);
+        *reinterpret_cast<vec16*>(wa + o) = ra[i];
+        *reinterpret_cast<vec16*>(xb + o) = rb[i];
+      }
+    };
+    if (steps > 0) {
+      load_step(0, 0);
+      store_step(0);
+    }
     __syncthreads();
-    tapi = ntapi;
-    kc = nkc;
+    int tapi = 0, kc = 0;
+    for (int s = 0; s < steps; ++s) {
+      next_step(tapi, kc);
+      const bool more = (s + 1) < steps;
+      if (more) load_step(tapi, kc);
+      compute(s & 1);
+      if (more) store_step((s + 1) & 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------
@@ -293,19 +331,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 }
 
-template <typename T, bool OUT32>
-static int launch_igemm(const IgemmParams& p, hipStream_t st) {
+static int g_use_glds = 1;
+
+template <typename T, bool OUT32, bool GLDS>
+static int launch_igemm2(const IgemmParams& p, hipStream_t st) {
   constexpr int CROW = BN * (int)(OUT32 ? 4 : sizeof(T)) + 16;
   const size_t lds = ((size_t)(4 * OPER_BYTES) > (size_t)BM * CROW ? (size_t)(4 * OPER_BYTES) : (size_t)BM * CROW) + 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, OUT32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, OUT32, GLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(cdiv(p.g.Cout, BN) * p.mtiles * p.g.os * p.g.os);
-  hipLaunchKernelGGL((igemm_kernel<T, OUT32>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((igemm_kernel<T, OUT32, GLDS>), grid, dim3(256), lds, st, p);
   DC_CHECK_LAUNCH();
   return 0;
+}
+template <typename T, bool OUT32>
+static int launch_igemm(const IgemmParams& p, hipStream_t st) {
+  return g_use_glds ? launch_igemm2<T, OUT32, true>(p, st) : launch_igemm2<T, OUT32, false>(p, st);
 }
 
 static int check_view(const void* ptr, int ld, int c, int dtype, const char* what) {
@@ -365,6 +409,17 @@ __global__ void pack_weights_kernel(const float* __restrict__ master, T* __restr
 }  // namespace dc
 
 using namespace dc;
+
+// Tuning switch for A/B measurements in one process: name "igemm_glds" (1 = LDS-DMA staging, 0 = register staging).
+extern "C" int dc_wgrad_set_target_blocks(int n);
+extern "C" int dc_set_option(const char* name, int value) {
+  if (name != nullptr && strcmp(name, "igemm_glds") == 0) {
+    g_use_glds = value;
+    return 0;
+  }
+  if (name != nullptr && strcmp(name, "wgrad_target_blocks") == 0) return dc_wgrad_set_target_blocks(value);
+  return dc_fail("dc_set_option: unknown option", __FILE__, __LINE__);
+}
 
 extern "C" int dc_conv_out_hw(const dc_conv_desc* d, int Hi, int Wi, int* Ho, int* Wo) {
   DC_REQUIRE(d != nullptr, "dc_conv_out_hw: null descriptor");

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const GatherGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware order (see igemm.hip): workgroups sharing an XCD take consecutive tiles, and consecutive tiles cover all
-  // (ci, co) tiles of ONE (tap, pixel split), so its x / dy pixel panels are pulled into that XCD's L2 once.
+  // (ci, co) tiles and then all taps of ONE pixel split, so its x / dy pixel panels (the 9 taps read the same pixels,
+  // shifted) are pulled into that XCD's L2 once.
   const int nci = (g.Cin + 127) / 128, nco = (g.Cout + 127) / 128;
   const int nwg = gridDim.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   tile /= nci;
   const int co0 = (tile % nco) * 128;
   tile /= nco;
-  const int tapi = tile / p.splits, split = tile % p.splits;
+  const int tapi = tile % g.ntaps, split = tile / g.ntaps;
   const Tap tap = g.taps[tapi];
   const int py = tap.phase / g.os, px = tap.phase % g.os;
   const int mbeg = split * p.chunk;
@@ -201,9 +202,11 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
+static int g_wgrad_target_blocks = 1024;   // ~4 workgroups per CU measured best (profiles/): 256/512/1024/2048 -> 24.5/23.2/20.9/21.7 ms per step
+
 static void plan_splits(const GatherGeom& g, long M, int BP, int* splits, int* chunk) {
   const long tiles = (long)cdiv(g.Cin, 128) * cdiv(g.Cout, 128) * g.ntaps;
-  long want = (1024 + tiles - 1) / tiles;          // aim for ~1024 workgroups
+  long want = (g_wgrad_target_blocks + tiles - 1) / tiles;   // aim for about two workgroups per CU
   const long maxs = (M + 2 * BP - 1) / (2 * BP);   // at least two steps per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -217,6 +220,11 @@ static void plan_splits(const GatherGeom& g, long M, int BP, int* splits, int* c
 }  // namespace dc
 
 using namespace dc;
+
+extern "C" int dc_wgrad_set_target_blocks(int n) {
+  if (n > 0) g_wgrad_target_blocks = n;
+  return 0;
+}
 
 extern "C" size_t dc_conv_wgrad_workspace(const dc_conv_desc* d, int N, int Hi, int Wi) {
   GatherGeom g;

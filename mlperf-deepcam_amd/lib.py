@@ -30,6 +30,7 @@ CD = C.POINTER(ConvDesc)
 _SIGS = {
     "dc_last_error": (C.c_char_p, []),
     "dc_version": (I, []),
+    "dc_set_option": (I, [C.c_char_p, I]),
     "dc_conv_out_hw": (I, [CD, I, I, C.POINTER(I), C.POINTER(I)]),
     "dc_conv_pack_weights": (I, [CD, P, P, P, P]),
     "dc_conv_stat_rows": (I, [CD, I, I, I]),

@@ -470,9 +470,41 @@ class TrainStep:
             self.after_backward()
         self.opt.launch()
 
+    def enable_graph(self) -> None:
+        """Capture the whole step (about 1000 launches) into one hipGraph; later calls copy the batch into static
+        buffers and replay.  Single-process only: the RCCL hand-off of the gradient reducer stays eager."""
+        if self.after_backward is not None or self.eng.on_grad_ready is not None:
+            raise L.DeepcamHipError("hipGraph capture is for the single-GPU step (the all-reduce path launches eagerly)")
+        eng = self.eng
+        self._gx = eng.x_static
+        self._gy = torch.zeros((eng.B, eng.H, eng.W), dtype=torch.int64, device=eng.device)
+        if eng.packed_version != eng.version[0]:
+            eng.pack_weights()
+        # weights change every step: repacking is part of the captured sequence
+        eng.packed_version = -1
+        self._graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.launch(self._gx, self._gy)              # warm-up on the side stream (lazy attribute setup, allocator)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        eng.packed_version = -1
+        with torch.cuda.graph(self._graph):
+            self.launch(self._gx, self._gy)
+        # the warm-up and the capture pass each applied one optimizer update with whatever was in the static buffers:
+        # callers enable the graph before training starts (bench) or accept two extra steps on stale data
+        self.graphed = True
+
     def __call__(self, x: torch.Tensor, labels: torch.Tensor) -> None:
         self.opt.step_count += 1
         self.opt.sync_scalars()
+        if getattr(self, "graphed", False):
+            self._gx.copy_(x, non_blocking=True)
+            self._gy.copy_(labels, non_blocking=True)
+            self._graph.replay()
+            self.eng.version[0] += 1
+            return
         self.launch(x, labels)
 
     def loss(self) -> float:
