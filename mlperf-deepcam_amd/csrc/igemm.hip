@@ -25,14 +25,21 @@ struct IgemmParams {
   float* slab;
   GatherGeom g;
   int N, ldx, ldy;
+  int ldw;     // K stride of a packed weight row: Cin rounded up to 32 elements, so every row starts on a 64-byte boundary
   int M;       // pixels per phase = N*Qh*Qw
   int mtiles;  // tiles per phase
   int accumulate;
 };
 // OUT32: the epilogue stores fp32 regardless of T (used by the classifier head, whose logits must not be rounded to bf16)
 
-constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per LDS row
-constexpr int OPER_BYTES = BM * ROWB;          // 16 KiB per operand tile
+constexpr int BM = 128, BN = 128;
+// staging modes (runtime switch "igemm_mode", A/B-able in one process):
+//   0  register staging, 128-byte K rows, 2 LDS stages              (first working version)
+//   1  LDS-DMA,          128-byte K rows, 2 stages, vmcnt(0)+barrier per step
+//   2  LDS-DMA,           64-byte K rows, 3 stages, counted vmcnt: two stages stay in flight across the barrier; 48 KiB of
+//      LDS and 146 registers -> 3 workgroups per CU, which also lets one workgroup's epilogue overlap another's K loop
+template <int MODE> struct StageCfg { static constexpr int ROWB = 128, NSTAGE = 2; };
+template <> struct StageCfg<2> { static constexpr int ROWB = 64, NSTAGE = 3; };
 
 template <typename T>
 struct Mma;
@@ -53,7 +60,11 @@ struct Mma<float> {
   }
 };
 
-__device__ inline int swz(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
+template <int ROWB>
+__device__ inline int swz(int row, int slot) {
+  if constexpr (ROWB == 128) return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);   // 8 slots per row
+  else return row * 64 + ((slot ^ ((row >> 1) & 3)) << 4);                          // 4 slots per row
+}
 
 // 16 zero bytes in global memory: the source of every predicated-off LDS-DMA lane (zero fill of halos, K and M tails)
 __device__ __attribute__((aligned(256))) unsigned char dc_zero_page[256];
@@ -64,8 +75,15 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 // GLDS: stage operand tiles with the gfx950 LDS-DMA (global_load_lds_dwordx4: global -> LDS without passing through
 // VGPRs and without ds_write instructions, which at ~79 B/clk/CU were the bottleneck of the register-staged loop).
 // The LDS image is lane-linear per wave instruction, so the XOR swizzle is applied to the per-lane SOURCE address.
-template <typename T, bool OUT32, bool GLDS>
+template <typename T, bool OUT32, int MODE>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+  constexpr bool GLDS = MODE != 0;
+  constexpr int ROWB = StageCfg<MODE>::ROWB, NSTAGE = StageCfg<MODE>::NSTAGE;
+  constexpr int OPER_BYTES = BM * ROWB;
+  constexpr int SPR = ROWB / 16;          // 16-byte slots per row
+  constexpr int KSUB = ROWB / 64;         // MFMA K sub-steps per stage (64 bytes of K each)
+  constexpr int LROWS = 256 / SPR;        // rows covered by one pass of the 256 threads
+  constexpr int LPASS = BM / LROWS;       // passes (= LDS-DMA instructions per operand per wave): 4 or 2
   typedef typename std::conditional<OUT32, float, T>::type TO;   // stored output type
   constexpr int KPV = Elem<T>::kPerVec;      // elements per 16 B
   constexpr int KPVO = Elem<TO>::kPerVec;
@@ -73,7 +91,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int CROW = BN * (int)sizeof(TO) + 16;  // padded C-tile row
   // all LDS lives in the one dynamic array (keeps its base 16-byte aligned); the tap list sits behind the tiles
   static_assert(!OUT32 || true, "");
-  constexpr int MAIN_BYTES = (4 * OPER_BYTES) > (BM * CROW) ? (4 * OPER_BYTES) : (BM * CROW);
+  constexpr int MAIN_BYTES = (2 * NSTAGE * OPER_BYTES) > (BM * CROW) ? (2 * NSTAGE * OPER_BYTES) : (BM * CROW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_tap = reinterpret_cast<int*>(smem + MAIN_BYTES);
   int& s_ntap = s_tap[27];
@@ -113,13 +131,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   if (steps == 0 && p.accumulate) return;  // a phase without taps contributes zeros
 
   // ---- per-thread load bookkeeping: 4 rows of each operand, one 16-byte slot -------------------------
-  const int slot = tid & 7;
-  int rowbase[4];   // ((n*Hin + iy0)*Win + ix0) is not enough (taps move iy/ix): keep n, iy0, ix0
-  int riy[4], rix[4];
-  bool rok[4];
+  const int slot = tid % SPR;
+  const int trow = tid / SPR;
+  int rowbase[LPASS];   // ((n*Hin + iy0)*Win + ix0) is not enough (taps move iy/ix): keep n, iy0, ix0
+  int riy[LPASS], rix[LPASS];
+  bool rok[LPASS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (tid >> 3) + 32 * i;
+  for (int i = 0; i < LPASS; ++i) {
+    const int r = trow + LROWS * i;
     const int m = m0 + r;
     rok[i] = m < p.M;
     const int mm = rok[i] ? m : 0;
@@ -146,14 +165,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const char* wa = smem + buf * (2 * OPER_BYTES);
     const char* xb = wa + OPER_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < KSUB; ++kk) {
       vec16 fa[4], fb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ra_ = wn * 64 + i * 16 + fr;
-        fa[i] = *reinterpret_cast<const vec16*>(wa + swz(ra_, kk * 4 + fg));
+        fa[i] = *reinterpret_cast<const vec16*>(wa + swz<ROWB>(ra_, kk * 4 + fg));
         const int rb_ = wm * 64 + i * 16 + fr;
-        fb[i] = *reinterpret_cast<const vec16*>(xb + swz(rb_, kk * 4 + fg));
+        fb[i] = *reinterpret_cast<const vec16*>(xb + swz<ROWB>(rb_, kk * 4 + fg));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -169,9 +188,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   };
 
   if constexpr (GLDS) {
-    // this thread's LDS slot is physical (tid&7) of row (tid>>3)+32i; it holds logical slot (tid&7)^((row>>1)&7),
-    // and ((row>>1)&7) == ((tid>>4)&7) for all four rows
-    const int lslot = (tid & 7) ^ ((tid >> 4) & 7);
+    // this thread fills PHYSICAL slot `slot` of rows trow + LROWS*i; that slot holds logical slot slot ^ f(row), and f(row)
+    // is the same for all of the thread's rows (LROWS/2 is a multiple of the swizzle period)
+    const int lslot = ROWB == 128 ? (slot ^ ((trow >> 1) & 7)) : (slot ^ ((trow >> 1) & 3));
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     auto issue = [&](int tapi, int kc, int buf) {
       const int dy = s_tap[3 * tapi], dx = s_tap[3 * tapi + 1], widx = s_tap[3 * tapi + 2];
@@ -180,48 +199,68 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       char* wa = smem + buf * (2 * OPER_BYTES);
       char* xb = wa + OPER_BYTES;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < LPASS; ++i) {
         const int iy = riy[i] + dy, ix = rix[i] + dx;
         const bool ok = kok && rok[i] && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
         const void* srcx = ok ? (const void*)(xg + (((size_t)(rowbase[i] + iy) * g.Win + ix) * p.ldx + kofs)) : (const void*)dc_zero_page;
-        const int ch = n0 + (tid >> 3) + 32 * i;
-        const void* srcw = (kok && ch < g.Cout) ? (const void*)(wg + (((size_t)widx * g.Cout + ch) * g.Cin + kofs)) : (const void*)dc_zero_page;
-        const int rowoff = (32 * i + 8 * wv) * ROWB;   // wave-uniform: this instruction fills 8 rows = 1 KiB
+        const int ch = n0 + trow + LROWS * i;
+        const void* srcw = (kok && ch < g.Cout) ? (const void*)(wg + (((size_t)widx * g.Cout + ch) * p.ldw + kofs)) : (const void*)dc_zero_page;
+        const int rowoff = (LROWS * i + (64 / SPR) * wv) * ROWB;   // wave-uniform: one instruction fills 1 KiB of rows
         __builtin_amdgcn_global_load_lds((gas_ptr)srcw, (lds_ptr)(wa + rowoff), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gas_ptr)srcx, (lds_ptr)(xb + rowoff), 16, 0, 0);
       }
     };
     int tapi = 0, kc = 0;
-    if (steps > 0) issue(0, 0, 0);
-    __syncthreads();   // (waits vmcnt(0): stage 0 has landed for every wave)
-    for (int s = 0; s < steps; ++s) {
+    if constexpr (NSTAGE == 2) {
+      if (steps > 0) issue(0, 0, 0);
+      __syncthreads();   // (waits vmcnt(0): stage 0 has landed for every wave)
+      for (int s = 0; s < steps; ++s) {
+        next_step(tapi, kc);
+        if (s + 1 < steps) issue(tapi, kc, (s + 1) & 1);
+        compute(s & 1);
+        __syncthreads();   // drains this wave's LDS-DMA (vmcnt(0)) and orders it before the next iteration's reads
+      }
+    } else {
+      // 3-stage ring, counted waits.  Each issue() is 2*LPASS = 4 LDS-DMA instructions per wave, retired in order.
+      // Iteration s: wait until stage s has landed (leave the younger stage in flight), barrier (everybody's stage s is
+      // visible AND everybody has finished reading the buffer of stage s-1, which is the one stage s+2 will overwrite),
+      // issue stage s+2, compute stage s.  Raw s_barrier: __syncthreads() would drain vmcnt to 0.
+      if (steps > 0) issue(0, 0, 0);
       next_step(tapi, kc);
-      if (s + 1 < steps) issue(tapi, kc, (s + 1) & 1);
-      compute(s & 1);
-      __syncthreads();   // drains this wave's LDS-DMA (vmcnt(0)) and orders it before the next iteration's reads
+      if (steps > 1) issue(tapi, kc, 1);
+      for (int s = 0; s < steps; ++s) {
+        if (s + 1 < steps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        next_step(tapi, kc);
+        if (s + 2 < steps) issue(tapi, kc, (s + 2) % 3);
+        compute(s % 3);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // all waves done with the operand ring before the epilogue reuses it as the C tile
     }
   } else {
-    vec16 ra[4], rb[4];
+    vec16 ra[LPASS], rb[LPASS];
     auto load_step = [&](int tapi, int kc) {
       const int dy = s_tap[3 * tapi], dx = s_tap[3 * tapi + 1], widx = s_tap[3 * tapi + 2];
       const int kofs = kc * BK + slot * KPV;
       const bool kok = kofs < g.Cin;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < LPASS; ++i) {
         const int iy = riy[i] + dy, ix = rix[i] + dx;
         const bool ok = kok && rok[i] && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
         rb[i] = ok ? ldg16(xg + (((size_t)(rowbase[i] + iy) * g.Win + ix) * p.ldx + kofs)) : zero16();
-        const int ch = n0 + (tid >> 3) + 32 * i;
-        ra[i] = (kok && ch < g.Cout) ? ldg16(wg + (((size_t)widx * g.Cout + ch) * g.Cin + kofs)) : zero16();
+        const int ch = n0 + trow + LROWS * i;
+        ra[i] = (kok && ch < g.Cout) ? ldg16(wg + (((size_t)widx * g.Cout + ch) * p.ldw + kofs)) : zero16();
       }
     };
     auto store_step = [&](int buf) {
       char* wa = smem + buf * (2 * OPER_BYTES);
       char* xb = wa + OPER_BYTES;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = (tid >> 3) + 32 * i;
-        const int o = swz(r, slot);
+      for (int i = 0; i < LPASS; ++i) {
+        const int r = trow + LROWS * i;
+        const int o = swz<ROWB>(r, slot);
         *reinterpret_cast<vec16*>(wa + o) = ra[i];
         *reinterpret_cast<vec16*>(xb + o) = rb[i];
       }
@@ -331,25 +370,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 }
 
-static int g_use_glds = 1;
+static int g_igemm_mode = 2;
 
-template <typename T, bool OUT32, bool GLDS>
+template <typename T, bool OUT32, int MODE>
 static int launch_igemm2(const IgemmParams& p, hipStream_t st) {
   constexpr int CROW = BN * (int)(OUT32 ? 4 : sizeof(T)) + 16;
-  const size_t lds = ((size_t)(4 * OPER_BYTES) > (size_t)BM * CROW ? (size_t)(4 * OPER_BYTES) : (size_t)BM * CROW) + 128;
+  constexpr size_t RING = (size_t)2 * StageCfg<MODE>::NSTAGE * BM * StageCfg<MODE>::ROWB;
+  const size_t lds = (RING > (size_t)BM * CROW ? RING : (size_t)BM * CROW) + 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, OUT32, GLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, OUT32, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(cdiv(p.g.Cout, BN) * p.mtiles * p.g.os * p.g.os);
-  hipLaunchKernelGGL((igemm_kernel<T, OUT32, GLDS>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((igemm_kernel<T, OUT32, MODE>), grid, dim3(256), lds, st, p);
   DC_CHECK_LAUNCH();
   return 0;
 }
 template <typename T, bool OUT32>
 static int launch_igemm(const IgemmParams& p, hipStream_t st) {
-  return g_use_glds ? launch_igemm2<T, OUT32, true>(p, st) : launch_igemm2<T, OUT32, false>(p, st);
+  if (g_igemm_mode == 2) return launch_igemm2<T, OUT32, 2>(p, st);
+  if (g_igemm_mode == 1) return launch_igemm2<T, OUT32, 1>(p, st);
+  return launch_igemm2<T, OUT32, 0>(p, st);
 }
 
 static int check_view(const void* ptr, int ld, int c, int dtype, const char* what) {
@@ -372,6 +414,7 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   DC_REQUIRE(!(slab != nullptr && accumulate), "dc_conv: statistics and accumulate are exclusive");
   p.x = in; p.w = w; p.y = out; p.bias = bias; p.slab = slab;
   p.N = N; p.ldx = ldin; p.ldy = ldout;
+  p.ldw = (p.g.Cin + 31) / 32 * 32;
   const long M = (long)N * p.g.Qh * p.g.Qw;
   DC_REQUIRE(M < (1L << 31) - BM, "dc_conv: too many pixels for 32-bit indexing");
   p.M = (int)M;
@@ -401,8 +444,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ master, T* __restr
       co = (int)(r / cin);
     }
     const float v = master[i];
-    if (wf) Elem<T>::store(wf + ((size_t)t * cout + co) * cin + ci, v);
-    if (wb) Elem<T>::store(wb + ((size_t)t * cin + ci) * cout + co, v);
+    const int ldf = (cin + 31) / 32 * 32, ldb = (cout + 31) / 32 * 32;   // padded K strides (the pad is never read)
+    if (wf) Elem<T>::store(wf + ((size_t)t * cout + co) * ldf + ci, v);
+    if (wb) Elem<T>::store(wb + ((size_t)t * cin + ci) * ldb + co, v);
   }
 }
 
@@ -410,11 +454,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ master, T* __restr
 
 using namespace dc;
 
-// Tuning switch for A/B measurements in one process: name "igemm_glds" (1 = LDS-DMA staging, 0 = register staging).
+// Tuning switches for A/B measurements in one process: "igemm_mode" (0/1/2, see StageCfg), "wgrad_target_blocks".
 extern "C" int dc_wgrad_set_target_blocks(int n);
 extern "C" int dc_set_option(const char* name, int value) {
-  if (name != nullptr && strcmp(name, "igemm_glds") == 0) {
-    g_use_glds = value;
+  if (name != nullptr && strcmp(name, "igemm_mode") == 0) {
+    if (value < 0 || value > 2) return dc_fail("dc_set_option: igemm_mode must be 0, 1 or 2", __FILE__, __LINE__);
+    g_igemm_mode = value;
     return 0;
   }
   if (name != nullptr && strcmp(name, "wgrad_target_blocks") == 0) return dc_wgrad_set_target_blocks(value);
@@ -449,6 +494,14 @@ extern "C" int dc_conv_fwd_f32out(const dc_conv_desc* d, int N, int Hi, int Wi, 
 extern "C" int dc_conv_dgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy,
                              const void* wb, void* dx, int lddx, int accumulate, void* stream) {
   return run_gather(d, kDgrad, N, Hi, Wi, dy, lddy, wb, nullptr, dx, lddx, nullptr, accumulate, stream);
+}
+
+extern "C" int dc_conv_packed_elems(const dc_conv_desc* d, size_t* wf_elems, size_t* wb_elems) {
+  DC_REQUIRE(d != nullptr, "dc_conv_packed_elems: null descriptor");
+  const size_t k = d->transposed ? 3 : d->k;
+  if (wf_elems) *wf_elems = k * k * d->cout * (size_t)((d->cin + 31) / 32 * 32);
+  if (wb_elems) *wb_elems = k * k * d->cin * (size_t)((d->cout + 31) / 32 * 32);
+  return 0;
 }
 
 extern "C" int dc_conv_pack_weights(const dc_conv_desc* d, const float* master, void* wf, void* wb, void* stream) {

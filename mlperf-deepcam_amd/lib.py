@@ -32,6 +32,7 @@ _SIGS = {
     "dc_version": (I, []),
     "dc_set_option": (I, [C.c_char_p, I]),
     "dc_conv_out_hw": (I, [CD, I, I, C.POINTER(I), C.POINTER(I)]),
+    "dc_conv_packed_elems": (I, [CD, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "dc_conv_pack_weights": (I, [CD, P, P, P, P]),
     "dc_conv_stat_rows": (I, [CD, I, I, I]),
     "dc_conv_fwd": (I, [CD, I, I, I, P, I, P, P, P, I, P, I, P]),

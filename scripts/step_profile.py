@@ -7,7 +7,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 dt = torch.bfloat16 if (len(sys.argv) < 3 or sys.argv[2] == "bf16") else torch.float32
 H, W = 768, 1152
 if os.environ.get('DC_WGB') is not None: L.load().dc_set_option(b'wgrad_target_blocks', int(os.environ['DC_WGB']))
-if os.environ.get('DC_GLDS') is not None: L.load().dc_set_option(b'igemm_glds', int(os.environ['DC_GLDS']))
+if os.environ.get('DC_MODE') is not None: L.load().dc_set_option(b'igemm_mode', int(os.environ['DC_MODE']))
 dev = torch.device("cuda", 0)
 net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=dt, seed=333); net.materialize(B, H, W)
 opt = dnn.make_optimizer("AdamW", net, 1e-3, 1e-8, 1e-2)

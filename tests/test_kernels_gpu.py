@@ -118,8 +118,10 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     # also the weight gradient with unrounded master weights is the same function of (x, gy)
 
     wm = w.to(dev())
-    wf = torch.empty(kk * kk * cout * cin, dtype=dtype, device=dev())
-    wb = torch.empty(kk * kk * cout * cin, dtype=dtype, device=dev())
+    nwf, nwb = C.c_size_t(), C.c_size_t()
+    L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
+    wf = torch.empty(nwf.value, dtype=dtype, device=dev())
+    wb = torch.empty(nwb.value, dtype=dtype, device=dev())
     L.call("dc_conv_pack_weights", C.byref(d), vptr(wm), vptr(wf), vptr(wb), S())
 
     # forward into a channel slice of a wider buffer, with the BN partial statistics
