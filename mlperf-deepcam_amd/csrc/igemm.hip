@@ -67,7 +67,7 @@ __device__ inline int swz(int row, int slot) {
 }
 
 // 16 zero bytes in global memory: the source of every predicated-off LDS-DMA lane (zero fill of halos, K and M tails)
-__device__ __attribute__((aligned(256))) unsigned char dc_zero_page[256];
+static __device__ __attribute__((aligned(256))) unsigned char dc_zero_page[256];   // (each translation unit has its own copy)
 
 typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -456,6 +456,7 @@ using namespace dc;
 
 // Tuning switches for A/B measurements in one process: "igemm_mode" (0/1/2, see StageCfg), "wgrad_target_blocks".
 extern "C" int dc_wgrad_set_target_blocks(int n);
+extern "C" int dc_wgrad_set_mode(int m);
 extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm_mode") == 0) {
     if (value < 0 || value > 2) return dc_fail("dc_set_option: igemm_mode must be 0, 1 or 2", __FILE__, __LINE__);
@@ -463,6 +464,7 @@ extern "C" int dc_set_option(const char* name, int value) {
     return 0;
   }
   if (name != nullptr && strcmp(name, "wgrad_target_blocks") == 0) return dc_wgrad_set_target_blocks(value);
+  if (name != nullptr && strcmp(name, "wgrad_mode") == 0) return dc_wgrad_set_mode(value);
   return dc_fail("dc_set_option: unknown option", __FILE__, __LINE__);
 }
 

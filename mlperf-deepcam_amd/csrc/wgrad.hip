@@ -187,6 +187,184 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA version (default): operands go global -> LDS with global_load_lds_dwordx4 into a 3-stage ring (16 KiB per stage:
+// 32 pixels x 128 channels bf16, or 16 pixels fp32), counted vmcnt so that two stages stay in flight across the raw
+// s_barrier, 48 KiB of LDS -> 3 workgroups per CU.  LDS-DMA writes are lane-linear, so rows cannot be padded; the
+// transposed reads are kept conflict-free by an XOR swizzle of 32-byte chunks (64-byte chunks for fp32) applied to the
+// per-lane SOURCE address and mirrored in the fragment reads.
+static __device__ __attribute__((aligned(256))) unsigned char dc_wg_zero_page[256];
+typedef __attribute__((address_space(1))) const void* wg_gas_ptr;
+typedef __attribute__((address_space(3))) void* wg_lds_ptr;
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p) {
+  constexpr int KPV = Elem<T>::kPerVec;
+  constexpr int ROW = 128 * (int)sizeof(T);        // bytes per LDS row (one pixel, 128 channels)
+  constexpr int SPR = ROW / 16;                    // 16-byte slots per row: 16 / 32
+  constexpr int BP = 8192 / ROW;                   // pixels per stage: 32 / 16
+  constexpr int RPI = 1024 / ROW;                  // rows per LDS-DMA instruction: 4 / 2
+  constexpr int TILE = 8192;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const GatherGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nci = (g.Cin + 127) / 128, nco = (g.Cout + 127) / 128;
+  const int nwg = gridDim.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+  int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + xslot;
+  const int ci0 = (tile % nci) * 128;
+  tile /= nci;
+  const int co0 = (tile % nco) * 128;
+  tile /= nco;
+  const int tapi = tile % g.ntaps, split = tile / g.ntaps;
+  const Tap tap = g.taps[tapi];
+  const int py = tap.phase / g.os, px = tap.phase % g.os;
+  const int mbeg = split * p.chunk;
+  const int mend = min(p.M, mbeg + p.chunk);
+  const int steps = mend > mbeg ? (mend - mbeg + BP - 1) / BP : 0;
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ dg = reinterpret_cast<const T*>(p.dy);
+
+  // lane -> (row within the instruction, physical slot); the swizzle key depends on the row only.
+  // The pixel coordinates (n, qy, qx) of each of the lane's two rows are decomposed ONCE and then advanced by BP pixels per
+  // stage with carries: integer divisions per stage made the first version of this kernel VALU-bound.
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int lrow = lane / SPR, sp = lane % SPR;
+  int rn[2], rqy[2], rqx[2], rlslot[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = RPI * (2 * wv + i) + lrow;
+    if constexpr (sizeof(T) == 2) {
+      const int key = (row & 3) | (((row >> 3) & 1) << 2);
+      rlslot[i] = (((sp >> 1) ^ key) << 1) | (sp & 1);
+    } else {
+      rlslot[i] = (((sp >> 2) ^ (row & 1)) << 2) | (sp & 3);
+    }
+    const int m = mbeg + row;
+    const int mm = m < p.M ? m : 0;
+    rn[i] = mm / (g.Qh * g.Qw);
+    const int rem = mm - rn[i] * (g.Qh * g.Qw);
+    rqy[i] = rem / g.Qw;
+    rqx[i] = rem - rqy[i] * g.Qw;
+  }
+  int next_s = 0;   // issue() is called with s = 0, 1, 2, ... in order
+  auto issue = [&](int s, int buf) {
+    char* q = smem + buf * (2 * TILE);
+    char* pp = q + TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = 2 * wv + i;                    // instruction index within the stage: rows RPI*j ..
+      const int row = RPI * j + lrow;
+      const int lslot = rlslot[i];
+      const int m = mbeg + s * BP + row;
+      const void* srcq = dc_wg_zero_page;
+      const void* srcp = dc_wg_zero_page;
+      if (m < mend) {
+        const int n = rn[i], qy = rqy[i], qx = rqx[i];
+        const int co = co0 + lslot * KPV;
+        if (co < g.Cout) {
+          const int oy = qy * g.os + py, ox = qx * g.os + px;
+          srcq = dg + ((size_t)(n * g.Hout + oy) * g.Wout + ox) * p.lddy + co;
+        }
+        const int ci = ci0 + lslot * KPV;
+        const int iy = qy * g.is + tap.dy, ix = qx * g.is + tap.dx;
+        if (ci < g.Cin && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win)
+          srcp = xg + ((size_t)(n * g.Hin + iy) * g.Win + ix) * p.ldx + ci;
+      }
+      __builtin_amdgcn_global_load_lds((wg_gas_ptr)srcq, (wg_lds_ptr)(q + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((wg_gas_ptr)srcp, (wg_lds_ptr)(pp + j * 1024), 16, 0, 0);
+      // advance this row by BP pixels
+      rqx[i] += BP;
+      while (rqx[i] >= g.Qw) {
+        rqx[i] -= g.Qw;
+        if (++rqy[i] == g.Qh) {
+          rqy[i] = 0;
+          ++rn[i];
+        }
+      }
+    }
+    ++next_s;
+  };
+
+  f32x4 acc[4][4];  // [co rep][ci rep]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wq = wave >> 1, wp = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  auto compute = [&](int buf) {
+    const char* q = smem + buf * (2 * TILE);
+    const char* pp = q + TILE;
+    if constexpr (sizeof(T) == 2) {
+      const int tq = (lane & 15) >> 2, tp = lane & 3;
+      const int prow = 8 * fg + tq;                               // pixels 8fg..8fg+3, then +4
+      const int key0 = (prow & 3) | (((prow >> 3) & 1) << 2);
+      const int key1 = ((prow + 4) & 3) | ((((prow + 4) >> 3) & 1) << 2);
+      vec16 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cq = wq * 4 + i, cp = wp * 4 + i;                // 32-byte chunk = 16 channels
+        typedef __attribute__((address_space(3))) short4v lds_s4;
+        const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(q + prow * ROW + ((cq ^ key0) << 5) + 8 * tp));
+        const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(q + (prow + 4) * ROW + ((cq ^ key1) << 5) + 8 * tp));
+        const short4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pp + prow * ROW + ((cp ^ key0) << 5) + 8 * tp));
+        const short4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pp + (prow + 4) * ROW + ((cp ^ key1) << 5) + 8 * tp));
+        uint2 t0 = __builtin_bit_cast(uint2, a0), t1 = __builtin_bit_cast(uint2, a1);
+        fa[i].w[0] = t0.x; fa[i].w[1] = t0.y; fa[i].w[2] = t1.x; fa[i].w[3] = t1.y;
+        t0 = __builtin_bit_cast(uint2, b0); t1 = __builtin_bit_cast(uint2, b1);
+        fb[i].w[0] = t0.x; fb[i].w[1] = t0.y; fb[i].w[2] = t1.x; fb[i].w[3] = t1.y;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BP / 4; ++ks) {
+        const int prow = ks * 4 + fg;
+        float fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          fa[i] = *reinterpret_cast<const float*>(q + prow * ROW + (((wq * 4 + i) ^ (prow & 1)) << 6) + fr * 4);
+          fb[i] = *reinterpret_cast<const float*>(pp + prow * ROW + (((wp * 4 + i) ^ (prow & 1)) << 6) + fr * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  if (steps > 0) issue(0, 0);
+  if (steps > 1) issue(1, 1);
+  for (int s = 0; s < steps; ++s) {
+    if (s + 1 < steps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < steps) issue(s + 2, (s + 2) % 3);
+    compute(s % 3);
+  }
+
+  float* out = p.slab + ((size_t)split * g.ntaps + tap.widx) * g.Cout * g.Cin;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + wq * 64 + i * 16 + fg * 4 + r;
+      if (co >= g.Cout) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + wp * 64 + j * 16 + fr;
+        if (ci < g.Cin) out[(size_t)co * g.Cin + ci] = acc[i][j][r];
+      }
+    }
+}
+
 // grad[master layout] = sum over splits of slab[split][tap][co][ci]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int splits, int taps,
                                     int Co, int Ci, int transposed) {
@@ -202,15 +380,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
-static int g_wgrad_target_blocks = 1024;   // ~4 workgroups per CU measured best (profiles/): 256/512/1024/2048 -> 24.5/23.2/20.9/21.7 ms per step
+static int g_wgrad_mode = 1;               // 1 = LDS-DMA 3-stage kernel, 0 = register-staged kernel
+static int g_wgrad_target_blocks = 768;    // resident capacity: 256 CUs x 3 workgroups (48 KiB LDS, 146 registers)
 
 static void plan_splits(const GatherGeom& g, long M, int BP, int* splits, int* chunk) {
   const long tiles = (long)cdiv(g.Cin, 128) * cdiv(g.Cout, 128) * g.ntaps;
-  long want = (g_wgrad_target_blocks + tiles - 1) / tiles;   // aim for about two workgroups per CU
+  long want = g_wgrad_target_blocks / tiles;   // FLOOR: all workgroups must be co-resident (3 per CU), a second partial wave costs more than it buys
   const long maxs = (M + 2 * BP - 1) / (2 * BP);   // at least two steps per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
-  if (want > 64) want = 64;
+  if (want > 1024) want = 1024;
   long c = (M + want - 1) / want;
   c = (c + BP - 1) / BP * BP;
   *chunk = (int)c;
@@ -220,6 +399,11 @@ static void plan_splits(const GatherGeom& g, long M, int BP, int* splits, int* c
 }  // namespace dc
 
 using namespace dc;
+
+extern "C" int dc_wgrad_set_mode(int m) {
+  g_wgrad_mode = m ? 1 : 0;
+  return 0;
+}
 
 extern "C" int dc_wgrad_set_target_blocks(int n) {
   if (n > 0) g_wgrad_target_blocks = n;
@@ -243,7 +427,7 @@ extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const
   if (int e = dc_check_view(dy, lddy, p.g.Cout, d->dtype, "dc_conv_wgrad dy")) return e;
   const long M = (long)N * p.g.Qh * p.g.Qw;
   DC_REQUIRE(M < (1L << 31) - 256, "dc_conv_wgrad: too many pixels for 32-bit indexing");
-  const int BP = d->dtype == DC_BF16 ? 64 : 32;
+  const int BP = d->dtype == DC_BF16 ? 64 : 32;    // chunk granularity (a multiple of both kernels' pixels per stage)
   plan_splits(p.g, M, BP, &p.splits, &p.chunk);
   const size_t need = (size_t)p.splits * p.g.ntaps * p.g.Cout * p.g.Cin * sizeof(float);
   DC_REQUIRE(workspace_bytes >= need, "dc_conv_wgrad: workspace too small");
@@ -251,7 +435,17 @@ extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const
   p.N = N; p.ldx = ldx; p.lddy = lddy; p.M = (int)M;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(p.g.Cin, 128) * cdiv(p.g.Cout, 128) * p.g.ntaps * p.splits);
-  if (d->dtype == DC_BF16) {
+  if (g_wgrad_mode == 1) {
+    const size_t lds = 3 * 2 * 8192;
+    static bool once_b = false, once_f = false;
+    if (d->dtype == DC_BF16) {
+      if (!once_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once_b = true; }
+      hipLaunchKernelGGL(wgrad_dma_kernel<bf16>, grid, dim3(256), lds, st, p);
+    } else {
+      if (!once_f) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once_f = true; }
+      hipLaunchKernelGGL(wgrad_dma_kernel<float>, grid, dim3(256), lds, st, p);
+    }
+  } else if (d->dtype == DC_BF16) {
     const size_t lds = 4 * (size_t)WgTraits<bf16>::BP * WgTraits<bf16>::ROW;
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
