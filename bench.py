@@ -130,7 +130,8 @@ def main():
     ap.add_argument("--height", type=int, default=768)
     ap.add_argument("--width", type=int, default=1152)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--no_graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (default: eager launches, which "
+                    "measured faster once weight gradients moved to a side stream: 55.3 vs 59.5 ms at B=8)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -163,7 +164,7 @@ def main():
         opt.grad_scale = 1.0 / world
     x, y = synthetic_batch(B, H, W, 1234 + rank, dev)
     graphed = False
-    if world == 1 and not a.no_graph:
+    if world == 1 and a.graph:
         step(x, y)
         step.enable_graph()
         graphed = True

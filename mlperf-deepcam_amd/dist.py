@@ -123,8 +123,17 @@ class GradReducer:
             b = self.of[n]
             b.remaining -= 1
             if b.remaining == 0:
-                # the process group's stream waits for everything enqueued so far on the current stream, then reduces
-                b.work = dist.all_reduce(self.eng.grads[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                # the process group's stream waits for everything enqueued so far on the launching stream, then reduces.
+                # Weight gradients are produced on the engine's side stream, the BatchNorm ones on the main stream: the
+                # launch happens on the side stream after it has been ordered behind the main stream's current position,
+                # so it covers both without stalling backward.
+                side = getattr(self.eng, "side", None) if getattr(self.eng, "use_side_stream", False) else None
+                if side is not None:
+                    side.wait_event(torch.cuda.current_stream().record_event())
+                    with torch.cuda.stream(side):
+                        b.work = dist.all_reduce(self.eng.grads[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                else:
+                    b.work = dist.all_reduce(self.eng.grads[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self.launched += 1
 
     def finish(self) -> None:

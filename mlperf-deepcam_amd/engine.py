@@ -135,6 +135,12 @@ class Engine:
         self.dlogits = torch.empty_like(self.logits)
         self._build()
         self.workspace = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=self.device)
+        # Weight gradients are off the critical path of backward (nothing downstream reads them until the optimizer) and
+        # are MFMA-bound, while the chain they branch off (BN backward, depthwise data gradient) is HBM-bound: they run
+        # on a side HIP stream with a private workspace and overlap it.  backward() joins the streams at the end.
+        self.side = torch.cuda.Stream(device=self.device)
+        self.workspace2 = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=self.device)
+        self.use_side_stream = True
         self.on_grad_ready: Optional[Callable[[List[str]], None]] = None
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -166,6 +172,15 @@ class Engine:
 
     def _wsptr(self) -> C.c_void_p:
         return C.c_void_p(self.workspace.data_ptr())
+
+    def _on_side(self, fn: Callable[[C.c_void_p], None]) -> None:
+        """Run fn(workspace_ptr) on the side stream, ordered after everything enqueued so far on the current stream."""
+        if not self.use_side_stream:
+            fn(self._wsptr())
+            return
+        self.side.wait_event(torch.cuda.current_stream().record_event())
+        with torch.cuda.stream(self.side):
+            fn(C.c_void_p(self.workspace2.data_ptr()))
 
     @staticmethod
     def _st():
@@ -217,7 +232,7 @@ class Engine:
             def bwd():
                 if bias:
                     L.call("dc_colsum", dt, y.M, cout, dy.ptr, dy.ld, self.gptr(bias), self._wsptr(), self._st())
-                L.call("dc_conv_wgrad", C.byref(d), N, H, W, x.ptr, x.ld, dy.ptr, dy.ld, self._wsptr(), wsb, gw, self._st())
+                self._on_side(lambda ws: L.call("dc_conv_wgrad", C.byref(d), N, H, W, x.ptr, x.ld, dy.ptr, dy.ld, ws, wsb, gw, self._st()))
                 if need_dx:
                     L.call("dc_conv_dgrad", C.byref(d), N, H, W, dy.ptr, dy.ld, L.dptr(wb), dx.ptr, dx.ld, mode, self._st())
             return bwd, ready
@@ -249,7 +264,7 @@ class Engine:
             dx = x.grad
 
             def bwd():
-                L.call("dc_dwconv_wgrad", self.dt, Cc, stride, dil, N, H, W, x.ptr, x.ld, dy.ptr, dy.ld, self._wsptr(), gw, self._st())
+                self._on_side(lambda ws: L.call("dc_dwconv_wgrad", self.dt, Cc, stride, dil, N, H, W, x.ptr, x.ld, dy.ptr, dy.ld, ws, gw, self._st()))
                 L.call("dc_dwconv_dgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
                        dx.ptr, dx.ld, self._st())
             return bwd, [wname]
@@ -521,3 +536,5 @@ class Engine:
             op()
             if cb is not None and ready:
                 cb(ready)
+        if self.use_side_stream:
+            torch.cuda.current_stream().wait_stream(self.side)
