@@ -136,14 +136,18 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("DC_DIST_BACKEND", "nccl")      # "nccl" is RCCL; gloo only for single-GPU testing of the N>1 path
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from mlperf_deepcam_amd import lib as L, nn as dnn
     from mlperf_deepcam_amd import dist as ddist
@@ -191,13 +195,20 @@ def main():
 
     # ---- roofline of the dominant kernel family, timed per launch with HIP events on the launch stream ----------------
     roof = None
+    # every rank runs these extra steps (they contain the gradient collectives); only rank 0 brackets its launches with events
+    step.graphed = False                         # per-launch events need eager launches (same kernels, same streams)
+    nroof = min(a.steps, 3)
     if rank == 0:
-        step.graphed = False                     # per-launch events need eager launches (same kernels, same stream)
         with KernelTimer(L) as kt:
-            for _ in range(min(a.steps, 3)):
+            for _ in range(nroof):
                 step(x, y)
             fams = kt.result()
-        step.graphed = graphed
+    else:
+        for _ in range(nroof):
+            step(x, y)
+    step.graphed = graphed
+    barrier()
+    if rank == 0:
         peak = PEAK[a.dtype]
         names = {"igemm": f"dc::igemm_kernel<{a.dtype}> (dense conv forward + data gradient, gather-form implicit GEMM)",
                  "wgrad": f"dc::wgrad_kernel<{a.dtype}> + dc::wgrad_reduce_kernel (dense conv weight gradient)"}

@@ -38,8 +38,13 @@ constexpr int BM = 128, BN = 128;
 //   1  LDS-DMA,          128-byte K rows, 2 stages, vmcnt(0)+barrier per step
 //   2  LDS-DMA,           64-byte K rows, 3 stages, counted vmcnt: two stages stay in flight across the barrier; 48 KiB of
 //      LDS and 146 registers -> 3 workgroups per CU, which also lets one workgroup's epilogue overlap another's K loop
+//   3/4  as 2 with a 4- / 5-stage ring (64 / 80 KiB, 2 workgroups per CU): deeper prefetch.  PMC on the 728-channel GEMM shows a 90 %
+//      L2 hit rate, i.e. practically every 16 KiB stage contains a few lines that come from the Infinity Cache / HBM, and the
+//      stage is only usable when its slowest line has landed: prefetch distance, not bandwidth, bounds the K loop.
 template <int MODE> struct StageCfg { static constexpr int ROWB = 128, NSTAGE = 2; };
 template <> struct StageCfg<2> { static constexpr int ROWB = 64, NSTAGE = 3; };
+template <> struct StageCfg<3> { static constexpr int ROWB = 64, NSTAGE = 4; };
+template <> struct StageCfg<4> { static constexpr int ROWB = 64, NSTAGE = 5; };
 
 template <typename T>
 struct Mma;
@@ -192,19 +197,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     // is the same for all of the thread's rows (LROWS/2 is a multiple of the swizzle period)
     const int lslot = ROWB == 128 ? (slot ^ ((trow >> 1) & 7)) : (slot ^ ((trow >> 1) & 3));
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    // Source addresses are strength-reduced: PMC showed the first LDS-DMA version VALU-bound on 64-bit address arithmetic
+    // (36 % of wave cycles issuing, MFMA pipe ~20 % busy).  Per tap each row's base pointer and validity are computed
+    // once; per K step only a channel offset is added.
+    const T* xrow[LPASS];
+    const T* wrow[LPASS];
+    bool xok[LPASS], wok[LPASS];
+    int cur_tap = -1;
     auto issue = [&](int tapi, int kc, int buf) {
-      const int dy = s_tap[3 * tapi], dx = s_tap[3 * tapi + 1], widx = s_tap[3 * tapi + 2];
-      const int kofs = kc * BK + lslot * KPV;
-      const bool kok = kofs < g.Cin;
+      if (tapi != cur_tap) {
+        cur_tap = tapi;
+        const int dy = s_tap[3 * tapi], dx = s_tap[3 * tapi + 1], widx = s_tap[3 * tapi + 2];
+#pragma unroll
+        for (int i = 0; i < LPASS; ++i) {
+          const int iy = riy[i] + dy, ix = rix[i] + dx;
+          xok[i] = rok[i] && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+          xrow[i] = xg + (((size_t)(rowbase[i] + (xok[i] ? iy : 0)) * g.Win + (xok[i] ? ix : 0)) * p.ldx + lslot * KPV);
+          const int ch = n0 + trow + LROWS * i;
+          wok[i] = ch < g.Cout;
+          wrow[i] = wg + (((size_t)widx * g.Cout + (wok[i] ? ch : 0)) * p.ldw + lslot * KPV);
+        }
+      }
+      const int kofs = kc * BK;
+      const bool kok = kofs + lslot * KPV < g.Cin;
       char* wa = smem + buf * (2 * OPER_BYTES);
       char* xb = wa + OPER_BYTES;
 #pragma unroll
       for (int i = 0; i < LPASS; ++i) {
-        const int iy = riy[i] + dy, ix = rix[i] + dx;
-        const bool ok = kok && rok[i] && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
-        const void* srcx = ok ? (const void*)(xg + (((size_t)(rowbase[i] + iy) * g.Win + ix) * p.ldx + kofs)) : (const void*)dc_zero_page;
-        const int ch = n0 + trow + LROWS * i;
-        const void* srcw = (kok && ch < g.Cout) ? (const void*)(wg + (((size_t)widx * g.Cout + ch) * p.ldw + kofs)) : (const void*)dc_zero_page;
+        const void* srcx = (kok && xok[i]) ? (const void*)(xrow[i] + kofs) : (const void*)dc_zero_page;
+        const void* srcw = (kok && wok[i]) ? (const void*)(wrow[i] + kofs) : (const void*)dc_zero_page;
         const int rowoff = (LROWS * i + (64 / SPR) * wv) * ROWB;   // wave-uniform: one instruction fills 1 KiB of rows
         __builtin_amdgcn_global_load_lds((gas_ptr)srcw, (lds_ptr)(wa + rowoff), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gas_ptr)srcx, (lds_ptr)(xb + rowoff), 16, 0, 0);
@@ -225,16 +246,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       // Iteration s: wait until stage s has landed (leave the younger stage in flight), barrier (everybody's stage s is
       // visible AND everybody has finished reading the buffer of stage s-1, which is the one stage s+2 will overwrite),
       // issue stage s+2, compute stage s.  Raw s_barrier: __syncthreads() would drain vmcnt to 0.
-      if (steps > 0) issue(0, 0, 0);
-      next_step(tapi, kc);
-      if (steps > 1) issue(tapi, kc, 1);
+      // prologue: NSTAGE-1 stages in flight
+#pragma unroll
+      for (int q = 0; q < NSTAGE - 1; ++q) {
+        if (q < steps) issue(tapi, kc, q);
+        next_step(tapi, kc);
+      }
       for (int s = 0; s < steps; ++s) {
-        if (s + 1 < steps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // stage s must have landed; up to NSTAGE-2 younger stages (4 LDS-DMA instructions each) may stay in flight
+        const int younger = min(NSTAGE - 2, steps - 1 - s);
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (s + NSTAGE - 1 < steps) issue(tapi, kc, (s + NSTAGE - 1) % NSTAGE);
         next_step(tapi, kc);
-        if (s + 2 < steps) issue(tapi, kc, (s + 2) % 3);
-        compute(s % 3);
+        compute(s % NSTAGE);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // all waves done with the operand ring before the epilogue reuses it as the C tile
@@ -389,6 +417,8 @@ static int launch_igemm2(const IgemmParams& p, hipStream_t st) {
 }
 template <typename T, bool OUT32>
 static int launch_igemm(const IgemmParams& p, hipStream_t st) {
+  if (g_igemm_mode == 4) return launch_igemm2<T, OUT32, 4>(p, st);
+  if (g_igemm_mode == 3) return launch_igemm2<T, OUT32, 3>(p, st);
   if (g_igemm_mode == 2) return launch_igemm2<T, OUT32, 2>(p, st);
   if (g_igemm_mode == 1) return launch_igemm2<T, OUT32, 1>(p, st);
   return launch_igemm2<T, OUT32, 0>(p, st);
@@ -459,7 +489,7 @@ extern "C" int dc_wgrad_set_target_blocks(int n);
 extern "C" int dc_wgrad_set_mode(int m);
 extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm_mode") == 0) {
-    if (value < 0 || value > 2) return dc_fail("dc_set_option: igemm_mode must be 0, 1 or 2", __FILE__, __LINE__);
+    if (value < 0 || value > 4) return dc_fail("dc_set_option: igemm_mode must be 0..4", __FILE__, __LINE__);
     g_igemm_mode = value;
     return 0;
   }

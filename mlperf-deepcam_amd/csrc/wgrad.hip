@@ -248,7 +248,24 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p) {
     rqy[i] = rem / g.Qw;
     rqx[i] = rem - rqy[i] * g.Qw;
   }
-  int next_s = 0;   // issue() is called with s = 0, 1, 2, ... in order
+  // running element offsets of the lane's two rows into dy and x (recomputed only when the pixel walk wraps a row)
+  size_t offq[2], offp[2];
+  bool cq_ok[2], cp_ok[2];
+  auto recompute = [&](int i) {
+    const int n = rn[i], qy = rqy[i], qx = rqx[i];
+    const int oy = qy * g.os + py, ox = qx * g.os + px;
+    offq[i] = ((size_t)(n * g.Hout + oy) * g.Wout + ox) * p.lddy + co0 + rlslot[i] * KPV;
+    const int iy = qy * g.is + tap.dy, ix = qx * g.is + tap.dx;
+    // (the x offset may be "out of the image" for halo taps: it is only dereferenced when the bounds test passes)
+    offp[i] = (size_t)((long)((long)(n * g.Hin + iy) * g.Win + ix) * p.ldx + ci0 + rlslot[i] * KPV);
+  };
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    cq_ok[i] = co0 + rlslot[i] * KPV < g.Cout;
+    cp_ok[i] = ci0 + rlslot[i] * KPV < g.Cin;
+    recompute(i);
+  }
+  const size_t stepq = (size_t)BP * g.os * p.lddy, stepp = (size_t)BP * g.is * p.ldx;
   auto issue = [&](int s, int buf) {
     char* q = smem + buf * (2 * TILE);
     char* pp = q + TILE;
@@ -256,35 +273,30 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p) {
     for (int i = 0; i < 2; ++i) {
       const int j = 2 * wv + i;                    // instruction index within the stage: rows RPI*j ..
       const int row = RPI * j + lrow;
-      const int lslot = rlslot[i];
       const int m = mbeg + s * BP + row;
-      const void* srcq = dc_wg_zero_page;
-      const void* srcp = dc_wg_zero_page;
-      if (m < mend) {
-        const int n = rn[i], qy = rqy[i], qx = rqx[i];
-        const int co = co0 + lslot * KPV;
-        if (co < g.Cout) {
-          const int oy = qy * g.os + py, ox = qx * g.os + px;
-          srcq = dg + ((size_t)(n * g.Hout + oy) * g.Wout + ox) * p.lddy + co;
-        }
-        const int ci = ci0 + lslot * KPV;
-        const int iy = qy * g.is + tap.dy, ix = qx * g.is + tap.dx;
-        if (ci < g.Cin && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win)
-          srcp = xg + ((size_t)(n * g.Hin + iy) * g.Win + ix) * p.ldx + ci;
-      }
+      const bool mok = m < mend;
+      const int iy = rqy[i] * g.is + tap.dy, ix = rqx[i] * g.is + tap.dx;
+      const bool pok = mok && cp_ok[i] && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+      const void* srcq = (mok && cq_ok[i]) ? (const void*)(dg + offq[i]) : (const void*)dc_wg_zero_page;
+      const void* srcp = pok ? (const void*)(xg + offp[i]) : (const void*)dc_wg_zero_page;
       __builtin_amdgcn_global_load_lds((wg_gas_ptr)srcq, (wg_lds_ptr)(q + j * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((wg_gas_ptr)srcp, (wg_lds_ptr)(pp + j * 1024), 16, 0, 0);
       // advance this row by BP pixels
       rqx[i] += BP;
-      while (rqx[i] >= g.Qw) {
-        rqx[i] -= g.Qw;
-        if (++rqy[i] == g.Qh) {
-          rqy[i] = 0;
-          ++rn[i];
+      if (rqx[i] < g.Qw) {
+        offq[i] += stepq;
+        offp[i] += stepp;
+      } else {
+        while (rqx[i] >= g.Qw) {
+          rqx[i] -= g.Qw;
+          if (++rqy[i] == g.Qh) {
+            rqy[i] = 0;
+            ++rn[i];
+          }
         }
+        recompute(i);
       }
     }
-    ++next_s;
   };
 
   f32x4 acc[4][4];  // [co rep][ci rep]
