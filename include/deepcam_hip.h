@@ -98,14 +98,17 @@ size_t dc_colsum_workspace(long M, int C);
  * fp32 [9][C] (`wp`, from dc_dwconv_pack_weights); the weight gradient comes back in the master layout [C][1][3][3].
  * ------------------------------------------------------------------------------------------------ */
 int dc_dwconv_pack_weights(int C, const float* master, float* packed, void* stream);
+/* pscale/pshift (both or neither; fp32[C]) fuse the PRECEDING BatchNorm (+ReLU when prelu != 0) into the load: x is then the
+ * raw conv output and every in-bounds element is read as act(x*pscale[c] + pshift[c]); padding stays zero. */
 int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
-                  const float* wp, void* y, int ldy, void* stream);
+                  const float* wp, void* y, int ldy, const float* pscale, const float* pshift, int prelu, void* stream);
 /* dx = dw_backward_data(dy) [+ addend]  (addend: same shape as dx, e.g. the residual branch's gradient) */
 int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
                     const float* wp, const void* addend, int ldadd, void* dx, int lddx, void* stream);
 size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int stride);
 int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
-                    const void* dy, int lddy, void* workspace, float* grad_w, void* stream);
+                    const void* dy, int lddy, void* workspace, float* grad_w, const float* pscale, const float* pshift,
+                    int prelu, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d (train and eval) fused with ReLU and the residual add: deeplab_xception.py:86,92,97,
@@ -125,17 +128,19 @@ int dc_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float*
 /* out = act(y*scale + shift [+ residual]),  act = ReLU when relu != 0 */
 int dc_bn_apply(int dtype, long M, int C, const void* y, int ldy, const float* scale, const float* shift,
                 const void* residual, int ldr, int relu, void* out, int ldo, void* stream);
-/* backward, step 1: g = dout * (out > 0 if relu), partial sums of g and g*xhat -> slab[2][rows][C] */
+/* backward, step 1: g = dout * (out > 0 if relu), partial sums of g and g*xhat -> slab[2][rows][C].
+ * relu == 2: the activation was fused into its consumer and never stored; the mask is recomputed as
+ * y*mscale[c] + mshift[c] > 0 (the forward scale/shift vectors), `out` is ignored. */
 int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int lddo, const void* y, int ldy,
                      const void* out, int ldout, int relu, const float* save_mean, const float* save_invstd,
-                     float* slab, void* stream);
+                     float* slab, const float* mscale, const float* mshift, void* stream);
 /* step 2: dgamma, dbeta (fp32, written to the gradient arena) */
 int dc_bn_bwd_finalize(int C, const float* slab, int rows, float* dgamma, float* dbeta, void* stream);
 /* step 3: dy = gamma*invstd*(g - dbeta/count - xhat*dgamma/count);  g is also stored when g_out != NULL */
 int dc_bn_bwd_apply(int dtype, long M, int C, long count, const void* dout, int lddo, const void* y, int ldy,
                     const void* out, int ldout, int relu, const float* gamma, const float* save_mean,
                     const float* save_invstd, const float* dgamma, const float* dbeta, void* dy, int lddy,
-                    void* g_out, int ldg, void* stream);
+                    void* g_out, int ldg, const float* mscale, const float* mshift, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Entry stem: Conv2d(16->32, k3, s2, p1) reading the caller's NCHW fp32 batch directly

@@ -16,10 +16,13 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colred_kernel(long M, int C, const T* __restrict__ p0, int ld0,
                                                      const T* __restrict__ p1, int ld1, const T* __restrict__ p2,
                                                      int ld2, int relu, const float* __restrict__ mean,
-                                                     const float* __restrict__ invstd, float* __restrict__ slab) {
+                                                     const float* __restrict__ invstd, float* __restrict__ slab,
+                                                     const float* __restrict__ mscale, const float* __restrict__ mshift) {
   // MODE 0: stats of p0            -> (sum x, sum x^2)
   // MODE 1: BN backward, p0 = dout, p1 = y (pre-BN), p2 = out (post activation; only read when relu)
   //                                -> (sum g, sum g*xhat),  g = dout * (out > 0)
+  //         relu == 2: the activation was never stored (it was fused into the consuming depthwise conv); the mask is
+  //         recomputed as y*mscale + mshift > 0, the very expression the consumer evaluated
   // MODE 2: column sum of p0       -> (sum x, 0)
   constexpr int KPV = Elem<T>::kPerVec;
   __shared__ float red[2][16][RED_CG * KPV];
@@ -52,7 +55,10 @@ __global__ __launch_bounds__(256) void colred_kernel(long M, int C, const T* __r
       } else {
         float y[KPV];
         unpack(ldg16(p1 + (size_t)r * ld1 + c0), y, T());
-        if (relu) {
+        if (relu == 2) {
+#pragma unroll
+          for (int e = 0; e < KPV; ++e) x[e] = fmaf(y[e], mscale[c0 + e], mshift[c0 + e]) > 0.f ? x[e] : 0.f;
+        } else if (relu) {
           float o[KPV];
           unpack(ldg16(p2 + (size_t)r * ld2 + c0), o, T());
 #pragma unroll
@@ -201,7 +207,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, float 
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                           T* __restrict__ dy, int lddy, T* __restrict__ gout, int ldg) {
+                                                           T* __restrict__ dy, int lddy, T* __restrict__ gout, int ldg,
+                                                           const float* __restrict__ mscale, const float* __restrict__ mshift) {
   constexpr int KPV = Elem<T>::kPerVec;
   const int ngroups = C / KPV;
   const long total = M * ngroups;
@@ -212,7 +219,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, float 
     float g[KPV], x[KPV];
     unpack(ldg16(dout + (size_t)r * lddo + c0), g, T());
     unpack(ldg16(y + (size_t)r * ldy + c0), x, T());
-    if (relu) {
+    if (relu == 2) {
+#pragma unroll
+      for (int e = 0; e < KPV; ++e) g[e] = fmaf(x[e], mscale[c0 + e], mshift[c0 + e]) > 0.f ? g[e] : 0.f;
+    } else if (relu) {
       float o[KPV];
       unpack(ldg16(out + (size_t)r * ldout + c0), o, T());
 #pragma unroll
@@ -245,10 +255,11 @@ static int ew_blocks(long total) {
 
 template <typename T, int MODE>
 static int launch_colred(long M, int C, const void* p0, int ld0, const void* p1, int ld1, const void* p2, int ld2,
-                         int relu, const float* mean, const float* invstd, float* slab, hipStream_t st) {
+                         int relu, const float* mean, const float* invstd, float* slab, hipStream_t st,
+                         const float* mscale = nullptr, const float* mshift = nullptr) {
   dim3 grid(cdiv(C / Elem<T>::kPerVec, RED_CG), cdiv(M, RED_ROWS));
   hipLaunchKernelGGL((colred_kernel<T, MODE>), grid, dim3(256), 0, st, M, C, (const T*)p0, ld0, (const T*)p1, ld1,
-                     (const T*)p2, ld2, relu, mean, invstd, slab);
+                     (const T*)p2, ld2, relu, mean, invstd, slab, mscale, mshift);
   DC_CHECK_LAUNCH();
   return 0;
 }
@@ -327,15 +338,16 @@ extern "C" int dc_bn_apply(int dtype, long M, int C, const void* y, int ldy, con
 
 extern "C" int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int lddo, const void* y, int ldy,
                                 const void* out, int ldout, int relu, const float* save_mean, const float* save_invstd,
-                                float* slab, void* stream) {
+                                float* slab, const float* mscale, const float* mshift, void* stream) {
   if (int e = dc_check_view(dout, lddo, C, dtype, "dc_bn_bwd_reduce dout")) return e;
   if (int e = dc_check_view(y, ldy, C, dtype, "dc_bn_bwd_reduce y")) return e;
-  if (relu)
+  if (relu == 1)
     if (int e = dc_check_view(out, ldout, C, dtype, "dc_bn_bwd_reduce out")) return e;
+  DC_REQUIRE(relu != 2 || (mscale && mshift), "dc_bn_bwd_reduce: relu == 2 needs the forward scale / shift vectors");
   DC_REQUIRE(save_mean && save_invstd && slab && M > 0, "dc_bn_bwd_reduce: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  return dtype == DC_BF16 ? launch_colred<bf16, 1>(M, C, dout, lddo, y, ldy, out, ldout, relu, save_mean, save_invstd, slab, st)
-                          : launch_colred<float, 1>(M, C, dout, lddo, y, ldy, out, ldout, relu, save_mean, save_invstd, slab, st);
+  return dtype == DC_BF16 ? launch_colred<bf16, 1>(M, C, dout, lddo, y, ldy, out, ldout, relu, save_mean, save_invstd, slab, st, mscale, mshift)
+                          : launch_colred<float, 1>(M, C, dout, lddo, y, ldy, out, ldout, relu, save_mean, save_invstd, slab, st, mscale, mshift);
 }
 
 extern "C" int dc_bn_bwd_finalize(int C, const float* slab, int rows, float* dgamma, float* dbeta, void* stream) {
@@ -348,12 +360,13 @@ extern "C" int dc_bn_bwd_finalize(int C, const float* slab, int rows, float* dga
 extern "C" int dc_bn_bwd_apply(int dtype, long M, int C, long count, const void* dout, int lddo, const void* y, int ldy,
                                const void* out, int ldout, int relu, const float* gamma, const float* save_mean,
                                const float* save_invstd, const float* dgamma, const float* dbeta, void* dy, int lddy,
-                               void* g_out, int ldg, void* stream) {
+                               void* g_out, int ldg, const float* mscale, const float* mshift, void* stream) {
   if (int e = dc_check_view(dout, lddo, C, dtype, "dc_bn_bwd_apply dout")) return e;
   if (int e = dc_check_view(y, ldy, C, dtype, "dc_bn_bwd_apply y")) return e;
   if (int e = dc_check_view(dy, lddy, C, dtype, "dc_bn_bwd_apply dy")) return e;
-  if (relu)
+  if (relu == 1)
     if (int e = dc_check_view(out, ldout, C, dtype, "dc_bn_bwd_apply out")) return e;
+  DC_REQUIRE(relu != 2 || (mscale && mshift), "dc_bn_bwd_apply: relu == 2 needs the forward scale / shift vectors");
   if (g_out)
     if (int e = dc_check_view(g_out, ldg, C, dtype, "dc_bn_bwd_apply g_out")) return e;
   DC_REQUIRE(gamma && save_mean && save_invstd && dgamma && dbeta && M > 0 && count > 0, "dc_bn_bwd_apply: bad argument");
@@ -362,9 +375,9 @@ extern "C" int dc_bn_bwd_apply(int dtype, long M, int C, long count, const void*
   const int blocks = ew_blocks(M * (C / kpv));
   const float inv = 1.0f / (float)count;
   if (dtype == DC_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(blocks), dim3(256), 0, st, M, C, inv, (const bf16*)dout, lddo, (const bf16*)y, ldy, (const bf16*)out, ldout, relu, gamma, save_mean, save_invstd, dgamma, dbeta, (bf16*)dy, lddy, (bf16*)g_out, ldg);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(blocks), dim3(256), 0, st, M, C, inv, (const bf16*)dout, lddo, (const bf16*)y, ldy, (const bf16*)out, ldout, relu, gamma, save_mean, save_invstd, dgamma, dbeta, (bf16*)dy, lddy, (bf16*)g_out, ldg, mscale, mshift);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, M, C, inv, (const float*)dout, lddo, (const float*)y, ldy, (const float*)out, ldout, relu, gamma, save_mean, save_invstd, dgamma, dbeta, (float*)dy, lddy, (float*)g_out, ldg);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, M, C, inv, (const float*)dout, lddo, (const float*)y, ldy, (const float*)out, ldout, relu, gamma, save_mean, save_invstd, dgamma, dbeta, (float*)dy, lddy, (float*)g_out, ldg, mscale, mshift);
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -23,6 +23,18 @@ __device__ inline void load_w9(const float* __restrict__ wp, int c0, int C, floa
   }
 }
 
+// Fused producer: when pscale != nullptr the depthwise input is the RAW (pre-BatchNorm) conv output and the kernel applies
+// v = x*scale[c] + shift[c] (and ReLU) to every in-bounds element as it is loaded; the zero padding stays zero.  The
+// normalised activation is then never materialised in HBM.
+template <int KPV>
+__device__ inline void dw_prologue(float (&f)[KPV], const float* __restrict__ pscale, const float* __restrict__ pshift, int prelu, int c0) {
+#pragma unroll
+  for (int e = 0; e < KPV; ++e) {
+    float v = fmaf(f[e], pscale[c0 + e], pshift[c0 + e]);
+    f[e] = prelu ? fmaxf(v, 0.f) : v;
+  }
+}
+
 __global__ void dw_pack_kernel(const float* __restrict__ master, float* __restrict__ packed, int C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 9 * C) return;
@@ -36,7 +48,8 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void dw_kernel(const T* __restrict__ in, int ldin, const float* __restrict__ w,
                                                  const T* __restrict__ addend, int ldadd, T* __restrict__ out,
                                                  int ldout, int N, int Hin, int Win, int Hout, int Wout, int C,
-                                                 int stride, int dil) {
+                                                 int stride, int dil, const float* __restrict__ pscale,
+                                                 const float* __restrict__ pshift, int prelu) {
   constexpr int KPV = Elem<T>::kPerVec;
   const int ngroups = C / KPV;
   const int wq = (Wout + DW_PX - 1) / DW_PX;
@@ -88,6 +101,7 @@ __global__ __launch_bounds__(256) void dw_kernel(const T* __restrict__ in, int l
           if (!xok) continue;
           float f[KPV];
           unpack(ldg16(in + ((size_t)(n * Hin + iy) * Win + ix) * ldin + c0), f, T());
+          if (MODE == 0 && pscale != nullptr) dw_prologue<KPV>(f, pscale, pshift, prelu, c0);
 #pragma unroll
           for (int e = 0; e < KPV; ++e) acc[e] = fmaf(f[e], wr[ky * 3 + kx][e], acc[e]);
         }
@@ -114,7 +128,8 @@ __global__ __launch_bounds__(256) void dw_kernel(const T* __restrict__ in, int l
 template <typename T, int DIL, bool FLIP>
 __global__ __launch_bounds__(256) void dw_s1_kernel(const T* __restrict__ in, int ldin, const float* __restrict__ wp,
                                                     const T* __restrict__ addend, int ldadd, T* __restrict__ out, int ldout,
-                                                    int N, int H, int W, int C) {
+                                                    int N, int H, int W, int C, const float* __restrict__ pscale,
+                                                    const float* __restrict__ pshift, int prelu) {
   constexpr int KPV = Elem<T>::kPerVec;
   constexpr int WC = DW_PX + 2 * DIL;  // window columns
   const int ngroups = C / KPV;
@@ -131,6 +146,7 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(const T* __restrict__ in, in
   const int c0 = cg * KPV;
   const int x0 = xq * DW_PX;
   vec16 win[3][WC];
+  unsigned inb = 0;   // bit (ky*WC + c): window element is inside the image
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = oy - DIL + ky * DIL;
@@ -139,7 +155,9 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(const T* __restrict__ in, in
 #pragma unroll
     for (int c = 0; c < WC; ++c) {
       const int ix = x0 - DIL + c;
-      win[ky][c] = (yok && (unsigned)ix < (unsigned)W) ? ldg16(rowp + (size_t)ix * ldin) : zero16();
+      const bool ok = yok && (unsigned)ix < (unsigned)W;
+      win[ky][c] = ok ? ldg16(rowp + (size_t)ix * ldin) : zero16();
+      inb |= (ok ? 1u : 0u) << (ky * WC + c);
     }
   }
   float acc[DW_PX][KPV];
@@ -164,6 +182,7 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(const T* __restrict__ in, in
     for (int c = 0; c < WC; ++c) {
       float f[KPV];
       unpack(win[ky][c], f, T());
+      if (!FLIP && pscale != nullptr && ((inb >> (ky * WC + c)) & 1u)) dw_prologue<KPV>(f, pscale, pshift, prelu, c0);
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int j = c - kx * DIL;          // output pixel that sees window column c through tap kx
@@ -198,7 +217,8 @@ __global__ __launch_bounds__(256) void dw_s1_kernel(const T* __restrict__ in, in
 template <typename T, int DIL>
 __global__ __launch_bounds__(256) void dw_s1_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
                                                           float* __restrict__ slab, int N, int H, int W, int C, int strips_per_block,
-                                                          int cgw) {
+                                                          int cgw, const float* __restrict__ pscale,
+                                                          const float* __restrict__ pshift, int prelu) {
   constexpr int KPV = Elem<T>::kPerVec;
   constexpr int WC = DW_PX + 2 * DIL;
   extern __shared__ __attribute__((aligned(16))) float red[];   // [256/cgw][9][cgw]
@@ -225,6 +245,7 @@ __global__ __launch_bounds__(256) void dw_s1_wgrad_kernel(const T* __restrict__ 
       const int n = r / H;
       const int x0 = xq * DW_PX;
       vec16 g[DW_PX], win[3][WC];
+      unsigned inb = 0;
 #pragma unroll
       for (int j = 0; j < DW_PX; ++j)
         g[j] = (x0 + j < W) ? ldg16(dy + ((size_t)(n * H + oy) * W + x0 + j) * lddy + c0) : zero16();
@@ -236,7 +257,9 @@ __global__ __launch_bounds__(256) void dw_s1_wgrad_kernel(const T* __restrict__ 
 #pragma unroll
         for (int c = 0; c < WC; ++c) {
           const int ix = x0 - DIL + c;
-          win[ky][c] = (yok && (unsigned)ix < (unsigned)W) ? ldg16(rowp + (size_t)ix * ldx) : zero16();
+          const bool ok = yok && (unsigned)ix < (unsigned)W;
+          win[ky][c] = ok ? ldg16(rowp + (size_t)ix * ldx) : zero16();
+          inb |= (ok ? 1u : 0u) << (ky * WC + c);
         }
       }
       float gf[DW_PX][KPV];
@@ -248,6 +271,7 @@ __global__ __launch_bounds__(256) void dw_s1_wgrad_kernel(const T* __restrict__ 
         for (int c = 0; c < WC; ++c) {
           float f[KPV];
           unpack(win[ky][c], f, T());
+          if (pscale != nullptr && ((inb >> (ky * WC + c)) & 1u)) dw_prologue<KPV>(f, pscale, pshift, prelu, c0);
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             const int j = c - kx * DIL;
@@ -285,7 +309,9 @@ __global__ __launch_bounds__(256) void dw_s1_wgrad_kernel(const T* __restrict__ 
 template <typename T, int CGW>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy,
                                                        int lddy, float* __restrict__ slab, int N, int Hi, int Wi,
-                                                       int Ho, int Wo, int C, int stride, int dil, int pix_per_block) {
+                                                       int Ho, int Wo, int C, int stride, int dil, int pix_per_block,
+                                                       const float* __restrict__ pscale, const float* __restrict__ pshift,
+                                                       int prelu) {
   constexpr int KPV = Elem<T>::kPerVec;
   constexpr int PPW = 64 / CGW;
   __shared__ float red[4][9][CGW];
@@ -320,6 +346,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, 
           if ((unsigned)ix >= (unsigned)Wi) continue;
           float f[KPV];
           unpack(ldg16(x + ((size_t)(n * Hi + iy) * Wi + ix) * ldx + c0), f, T());
+          if (pscale != nullptr) dw_prologue<KPV>(f, pscale, pshift, prelu, c0);
 #pragma unroll
           for (int e = 0; e < KPV; ++e) acc[ky * 3 + kx][e] = fmaf(g[e], f[e], acc[ky * 3 + kx][e]);
         }
@@ -393,23 +420,25 @@ using namespace dc;
 
 template <typename T, int MODE>
 static int launch_dw(const void* in, int ldin, const float* w, const void* addend, int ldadd, void* out, int ldout,
-                     int N, int Hin, int Win, int Hout, int Wout, int C, int stride, int dil, hipStream_t st) {
+                     int N, int Hin, int Win, int Hout, int Wout, int C, int stride, int dil, hipStream_t st,
+                     const float* pscale = nullptr, const float* pshift = nullptr, int prelu = 0) {
   const long total = (long)N * Hout * ((Wout + DW_PX - 1) / DW_PX) * (C / Elem<T>::kPerVec);
   long blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL((dw_kernel<T, MODE>), dim3((int)blocks), dim3(256), 0, st, (const T*)in, ldin, w,
-                     (const T*)addend, ldadd, (T*)out, ldout, N, Hin, Win, Hout, Wout, C, stride, dil);
+                     (const T*)addend, ldadd, (T*)out, ldout, N, Hin, Win, Hout, Wout, C, stride, dil, pscale, pshift, prelu);
   DC_CHECK_LAUNCH();
   return 0;
 }
 
 static int launch_dw_s1(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
-                        void* out, int ldout, int N, int H, int W, int C, hipStream_t st) {
+                        void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale = nullptr,
+                        const float* pshift = nullptr, int prelu = 0) {
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const long total = (long)N * H * ((W + DW_PX - 1) / DW_PX) * (C / kpv);
   DC_REQUIRE(total < (1L << 31), "dc_dwconv: tensor too large for the stride-1 fast path");
   dim3 grid((unsigned)((total + 255) / 256));
-#define DW_S1(TT, D, F) hipLaunchKernelGGL((dw_s1_kernel<TT, D, F>), grid, dim3(256), 0, st, (const TT*)in, ldin, wp, (const TT*)addend, ldadd, (TT*)out, ldout, N, H, W, C)
+#define DW_S1(TT, D, F) hipLaunchKernelGGL((dw_s1_kernel<TT, D, F>), grid, dim3(256), 0, st, (const TT*)in, ldin, wp, (const TT*)addend, ldadd, (TT*)out, ldout, N, H, W, C, pscale, pshift, prelu)
   if (dtype == DC_BF16) {
     if (dil == 1) { if (flip) DW_S1(bf16, 1, true); else DW_S1(bf16, 1, false); }
     else          { if (flip) DW_S1(bf16, 2, true); else DW_S1(bf16, 2, false); }
@@ -438,16 +467,18 @@ extern "C" int dc_dwconv_pack_weights(int C, const float* master, float* packed,
 }
 
 extern "C" int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
-                             const float* w, void* y, int ldy, void* stream) {
+                             const float* w, void* y, int ldy, const float* pscale, const float* pshift, int prelu,
+                             void* stream) {
   if (int e = dw_check(dtype, C, stride, dil, N, Hi, Wi)) return e;
   if (int e = dc_check_view(x, ldx, C, dtype, "dc_dwconv_fwd x")) return e;
   if (int e = dc_check_view(y, ldy, C, dtype, "dc_dwconv_fwd y")) return e;
   DC_REQUIRE(w != nullptr, "dc_dwconv_fwd: null weights");
   const int Ho = dw_out(Hi, stride, dil), Wo = dw_out(Wi, stride, dil);
   hipStream_t st = (hipStream_t)stream;
-  if (stride == 1 && (dil == 1 || dil == 2)) return launch_dw_s1(dtype, dil, false, x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, C, st);
-  return dtype == DC_BF16 ? launch_dw<bf16, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st)
-                          : launch_dw<float, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st);
+  DC_REQUIRE((pscale == nullptr) == (pshift == nullptr), "dc_dwconv_fwd: pscale and pshift go together");
+  if (stride == 1 && (dil == 1 || dil == 2)) return launch_dw_s1(dtype, dil, false, x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, C, st, pscale, pshift, prelu);
+  return dtype == DC_BF16 ? launch_dw<bf16, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st, pscale, pshift, prelu)
+                          : launch_dw<float, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st, pscale, pshift, prelu);
 }
 
 extern "C" int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
@@ -476,7 +507,8 @@ extern "C" size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int st
 }
 
 extern "C" int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
-                               const void* dy, int lddy, void* workspace, float* grad_w, void* stream) {
+                               const void* dy, int lddy, void* workspace, float* grad_w, const float* pscale,
+                               const float* pshift, int prelu, void* stream) {
   if (int e = dw_check(dtype, C, stride, dil, N, Hi, Wi)) return e;
   if (int e = dc_check_view(x, ldx, C, dtype, "dc_dwconv_wgrad x")) return e;
   if (int e = dc_check_view(dy, lddy, C, dtype, "dc_dwconv_wgrad dy")) return e;
@@ -497,7 +529,7 @@ extern "C" int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int
     const int frows = cdiv(nstrips, spb);
     dim3 fgrid(cdiv(C / kpv, cgw), frows);
     const size_t lds = (size_t)256 * 9 * sizeof(float);
-#define DW_WS1(TT, D) hipLaunchKernelGGL((dw_s1_wgrad_kernel<TT, D>), fgrid, dim3(256), lds, st, (const TT*)x, ldx, (const TT*)dy, lddy, (float*)workspace, N, Hi, Wi, C, spb, cgw)
+#define DW_WS1(TT, D) hipLaunchKernelGGL((dw_s1_wgrad_kernel<TT, D>), fgrid, dim3(256), lds, st, (const TT*)x, ldx, (const TT*)dy, lddy, (float*)workspace, N, Hi, Wi, C, spb, cgw, pscale, pshift, prelu)
     if (dtype == DC_BF16) { if (dil == 1) DW_WS1(bf16, 1); else DW_WS1(bf16, 2); }
     else                  { if (dil == 1) DW_WS1(float, 1); else DW_WS1(float, 2); }
 #undef DW_WS1
@@ -507,7 +539,7 @@ extern "C" int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int
     return 0;
   }
   dim3 grid(cdiv(C / kpv, cgw), rows);
-#define DW_WG(TT, W) hipLaunchKernelGGL((dw_wgrad_kernel<TT, W>), grid, dim3(256), 0, st, (const TT*)x, ldx, (const TT*)dy, lddy, (float*)workspace, N, Hi, Wi, Ho, Wo, C, stride, dil, ppb)
+#define DW_WG(TT, W) hipLaunchKernelGGL((dw_wgrad_kernel<TT, W>), grid, dim3(256), 0, st, (const TT*)x, ldx, (const TT*)dy, lddy, (float*)workspace, N, Hi, Wi, Ho, Wo, C, stride, dil, ppb, pscale, pshift, prelu)
   if (dtype == DC_BF16) {
     if (cgw == 64) DW_WG(bf16, 64); else if (cgw == 32) DW_WG(bf16, 32); else if (cgw == 16) DW_WG(bf16, 16); else DW_WG(bf16, 8);
   } else {

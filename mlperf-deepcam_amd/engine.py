@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -85,6 +86,32 @@ class Act:
         return 1 if init else 0
 
 
+class LazyAct:
+    """A BatchNorm(+ReLU) output that is never stored: its only consumer is a depthwise conv, which applies
+    act(y*scale + shift) while loading the raw conv output y.  Only the GRADIENT w.r.t. this activation is a real buffer."""
+
+    def __init__(self, y: Act, scale: torch.Tensor, shift: torch.Tensor, relu: bool, name: str):
+        self.y, self.scale, self.shift, self.relu, self.name = y, scale, shift, relu, name
+        self.N, self.H, self.W, self.C = y.N, y.H, y.W, y.C
+        self._grad: Optional[Act] = None
+        self.grad_init = False
+
+    @property
+    def M(self) -> int:
+        return self.y.M
+
+    @property
+    def grad(self) -> Act:
+        if self._grad is None:
+            self._grad = Act(self.y.eng, "d" + self.name, self.N, self.H, self.W, self.C, dtype=self.y.buf.dtype)
+        return self._grad
+
+    def take_grad_mode(self) -> int:
+        mode = 1 if self.grad_init else 0
+        self.grad_init = True
+        return mode
+
+
 class Engine:
     def __init__(self, batch: int, height: int, width: int, dtype=torch.bfloat16, device=None, n_input: int = 16,
                  n_classes: int = 3, seed: Optional[int] = 333, share_from: "Engine" = None):
@@ -120,6 +147,10 @@ class Engine:
             self.version = [0]          # bumped whenever the master weights change (optimizer step, load_state_dict)
         self.packed_version = -1
         self._keep: List[torch.Tensor] = []
+        # Fusing the BatchNorm(+ReLU) into the consuming depthwise conv is implemented and tested, but measured slower at B=8
+        # (55.0 vs 53.8 ms/step: the 9-tap stencil becomes VALU-heavy), so it is off by default.
+        self.fuse_bn_into_dw = os.environ.get("DC_FUSE_BN_DW", "0") != "0"
+        self.mask_from_y = os.environ.get("DC_MASK_FROM_Y", "1") != "0"
 
         # ---- program containers -----------------------------------------------------------------------------
         self.fwd_train: List[Callable[[], None]] = []
@@ -240,8 +271,16 @@ class Engine:
         self.bwd.append(make_bwd)
         return y, slab, rows
 
-    def _dw(self, x: Act, wname: str, stride: int, dil: int, name: str) -> Act:
+    def _dw(self, x, wname: str, stride: int, dil: int, name: str) -> Act:
+        """Depthwise 3x3.  x is an Act, or a LazyAct (then the preceding BatchNorm+ReLU is applied on load)."""
         lib = L.load()
+        lazy = isinstance(x, LazyAct)
+        src = x.y if lazy else x                       # tensor actually read
+        ps = L.dptr(x.scale) if lazy else None
+        psh = L.dptr(x.shift) if lazy else None
+        prelu = (1 if x.relu else 0) if lazy else 0
+        if lazy:
+            self._keep += [x.scale, x.shift]
         Ho, Wo = (x.H - 1) // stride + 1, (x.W - 1) // stride + 1
         y = Act(self, name, x.N, Ho, Wo, x.C)
         N, H, W, Cc = x.N, x.H, x.W, x.C
@@ -253,7 +292,7 @@ class Engine:
         self._need_ws(lib.dc_dwconv_wgrad_workspace(Cc, N, H, W, stride))
 
         def fwd():
-            L.call("dc_dwconv_fwd", self.dt, Cc, stride, dil, N, H, W, x.ptr, x.ld, pw, y.ptr, y.ld, self._st())
+            L.call("dc_dwconv_fwd", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, pw, y.ptr, y.ld, ps, psh, prelu, self._st())
 
         self.fwd_train.append(fwd)
         self.fwd_eval.append(fwd)
@@ -264,7 +303,8 @@ class Engine:
             dx = x.grad
 
             def bwd():
-                self._on_side(lambda ws: L.call("dc_dwconv_wgrad", self.dt, Cc, stride, dil, N, H, W, x.ptr, x.ld, dy.ptr, dy.ld, ws, gw, self._st()))
+                self._on_side(lambda ws: L.call("dc_dwconv_wgrad", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, dy.ptr, dy.ld, ws, gw,
+                                                ps, psh, prelu, self._st()))
                 L.call("dc_dwconv_dgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
                        dx.ptr, dx.ld, self._st())
             return bwd, [wname]
@@ -273,12 +313,17 @@ class Engine:
         return y
 
     def _bn(self, y: Act, slab: torch.Tensor, rows: int, bname: str, relu: bool, residual: Act = None, out: Act = None,
-            name: str = None) -> Act:
+            name: str = None, lazy: bool = False):
+        """BatchNorm (+residual) (+ReLU).  lazy=True: do not store the result; return a LazyAct for a depthwise consumer."""
         lib = L.load()
         Cc, M = y.C, y.M
-        o = out or Act(self, name or bname, y.N, y.H, y.W, Cc, dtype=y.buf.dtype)
+        assert not (lazy and (residual is not None or out is not None))
         bdt = L.dtype_code(y.buf.dtype)
-        assert o.buf.dtype == y.buf.dtype
+        if lazy:
+            o = None
+        else:
+            o = out or Act(self, name or bname, y.N, y.H, y.W, Cc, dtype=y.buf.dtype)
+            assert o.buf.dtype == y.buf.dtype
         scale, shift, mean, invstd = (self._f32(Cc) for _ in range(4))
         gam, bet = self.pptr(bname + ".weight"), self.pptr(bname + ".bias")
         rm, rv = self.bptr(bname + ".running_mean"), self.bptr(bname + ".running_var")
@@ -290,11 +335,15 @@ class Engine:
         def fwd_train():
             L.call("dc_bn_finalize", Cc, M, L.dptr(slab), rows, gam, bet, rm, rv, nbt, BN_MOMENTUM, BN_EPS, L.dptr(scale),
                    L.dptr(shift), L.dptr(mean), L.dptr(invstd), self._st())
-            L.call("dc_bn_apply", bdt, M, Cc, y.ptr, y.ld, L.dptr(scale), L.dptr(shift), rptr(), rld, relu_i, o.ptr, o.ld, self._st())
+            if not lazy:
+                L.call("dc_bn_apply", bdt, M, Cc, y.ptr, y.ld, L.dptr(scale), L.dptr(shift), rptr(), rld, relu_i, o.ptr, o.ld, self._st())
 
         def fwd_eval():
             L.call("dc_bn_eval_coeffs", Cc, gam, bet, rm, rv, BN_EPS, L.dptr(scale), L.dptr(shift), self._st())
-            L.call("dc_bn_apply", bdt, M, Cc, y.ptr, y.ld, L.dptr(scale), L.dptr(shift), rptr(), rld, relu_i, o.ptr, o.ld, self._st())
+            if not lazy:
+                L.call("dc_bn_apply", bdt, M, Cc, y.ptr, y.ld, L.dptr(scale), L.dptr(shift), rptr(), rld, relu_i, o.ptr, o.ld, self._st())
+
+        lz = LazyAct(y, scale, shift, relu, (name or bname) + ".lazy") if lazy else None
 
         self.fwd_train.append(fwd_train)
         self.fwd_eval.append(fwd_eval)
@@ -302,7 +351,7 @@ class Engine:
         bslab = self._f32(2 * brows * Cc)
 
         def make_bwd():
-            do = o.grad
+            do = lz.grad if lazy else o.grad
             assert y.take_grad_mode() == 0, "a conv output feeds exactly one BatchNorm"
             dy = y.grad
             g_out = None
@@ -310,27 +359,34 @@ class Engine:
                 assert residual.take_grad_mode() == 0, f"{bname}: residual gradient must be first written here"
                 g_out = residual.grad
             dgam, dbet = self.gptr(bname + ".weight"), self.gptr(bname + ".bias")
+            # ReLU mask: recomputed from y with the forward scale / shift whenever there is no residual (one tensor read less
+            # in both backward kernels, which run at the HBM roofline); from the stored output when a residual was added
+            from_y = lazy or (relu and residual is None and self.mask_from_y)
+            mrelu = (2 if relu else 0) if from_y else relu_i
+            optr = (lambda: None) if from_y else (lambda: o.ptr)
+            old_ = 0 if from_y else o.ld
 
             def bwd():
-                L.call("dc_bn_bwd_reduce", bdt, M, Cc, do.ptr, do.ld, y.ptr, y.ld, o.ptr, o.ld, relu_i, L.dptr(mean),
-                       L.dptr(invstd), L.dptr(bslab), self._st())
+                L.call("dc_bn_bwd_reduce", bdt, M, Cc, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, L.dptr(mean),
+                       L.dptr(invstd), L.dptr(bslab), L.dptr(scale), L.dptr(shift), self._st())
                 L.call("dc_bn_bwd_finalize", Cc, L.dptr(bslab), brows, dgam, dbet, self._st())
-                L.call("dc_bn_bwd_apply", bdt, M, Cc, M, do.ptr, do.ld, y.ptr, y.ld, o.ptr, o.ld, relu_i, gam, L.dptr(mean),
+                L.call("dc_bn_bwd_apply", bdt, M, Cc, M, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, gam, L.dptr(mean),
                        L.dptr(invstd), dgam, dbet, dy.ptr, dy.ld, g_out.ptr if g_out is not None else None,
-                       g_out.ld if g_out is not None else 0, self._st())
+                       g_out.ld if g_out is not None else 0, L.dptr(scale), L.dptr(shift), self._st())
             return bwd, [bname + ".weight", bname + ".bias"]
 
         self.bwd.append(make_bwd)
-        return o
+        return lz if lazy else o
 
-    def _sep(self, x: Act, s: S.SepSpec, residual: Act = None, relu_override: Optional[bool] = None, tag: str = "") -> Act:
-        """depthwise 3x3 -> pointwise 1x1 [-> BN (+residual) (+ReLU)]"""
+    def _sep(self, x, s: S.SepSpec, residual: Act = None, relu_override: Optional[bool] = None, lazy: bool = False):
+        """depthwise 3x3 -> pointwise 1x1 [-> BN (+residual) (+ReLU)].  lazy: the BN output feeds only the next
+        depthwise conv and is fused into it instead of being stored."""
         d = self._dw(x, s.prefix + ".conv1.weight", s.stride, s.dil, s.prefix + ".dw")
         y, slab, rows = self._conv(d, s.prefix + ".pointwise.weight", s.cout, stats=bool(s.bn), name=s.prefix + ".pw")
         if not s.bn:
             return y
         relu = s.relu_after if relu_override is None else relu_override
-        return self._bn(y, slab, rows, s.bn, relu, residual=residual, name=s.bn + ".out")
+        return self._bn(y, slab, rows, s.bn, relu, residual=residual, name=s.bn + ".out", lazy=lazy and self.fuse_bn_into_dw)
 
     # ------------------------------------------------------------------------------------------------ network
     def _build(self) -> None:
@@ -388,15 +444,16 @@ class Engine:
                     # identity shortcut: out = relu(bn(pw(dw(t))) + z)   (x += skip, then the next block's in-place ReLU)
                     t = self._sep(t, s, residual=z, relu_override=True)
                 else:
-                    t = self._sep(t, s)
+                    # a BatchNorm between two separable convs is consumed by the next depthwise conv only
+                    t = self._sep(t, s, lazy=bool(s.bn) and not last)
             if blk.skip:
                 ys, slab, rows = self._conv(z, f"{X}{blk.name}.skip.weight", blk.cout, stride=blk.stride, name=blk.name + ".skip")
                 t = self._bn(ys, slab, rows, f"{X}{blk.name}.skipbn", blk.relu_out, residual=t, name=blk.name + ".out")
             x = t
             if blk.name == "block1":
                 low = x            # low_level_feat, after block2's in-place ReLU has hit it
-        for s in S.EXIT_SEPS:
-            x = self._sep(x, s)
+        for i, s in enumerate(S.EXIT_SEPS):
+            x = self._sep(x, s, lazy=i + 1 < len(S.EXIT_SEPS))
         e = x
         h16, w16 = e.H, e.W
 

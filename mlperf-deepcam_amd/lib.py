@@ -43,18 +43,18 @@ _SIGS = {
     "dc_colsum": (I, [I, L, I, P, I, P, P, P]),
     "dc_colsum_workspace": (SZ, [L, I]),
     "dc_dwconv_pack_weights": (I, [I, P, P, P]),
-    "dc_dwconv_fwd": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P]),
+    "dc_dwconv_fwd": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, P, I, P]),
     "dc_dwconv_dgrad": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P]),
     "dc_dwconv_wgrad_workspace": (SZ, [I, I, I, I, I]),
-    "dc_dwconv_wgrad": (I, [I, I, I, I, I, I, I, P, I, P, I, P, P, P]),
+    "dc_dwconv_wgrad": (I, [I, I, I, I, I, I, I, P, I, P, I, P, P, P, P, I, P]),
     "dc_bn_stat_rows": (I, [L]),
     "dc_bn_stats": (I, [I, L, I, P, I, P, P]),
     "dc_bn_finalize": (I, [I, L, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),
     "dc_bn_eval_coeffs": (I, [I, P, P, P, P, F, P, P, P]),
     "dc_bn_apply": (I, [I, L, I, P, I, P, P, P, I, I, P, I, P]),
-    "dc_bn_bwd_reduce": (I, [I, L, I, P, I, P, I, P, I, I, P, P, P, P]),
+    "dc_bn_bwd_reduce": (I, [I, L, I, P, I, P, I, P, I, I, P, P, P, P, P, P]),
     "dc_bn_bwd_finalize": (I, [I, P, I, P, P, P]),
-    "dc_bn_bwd_apply": (I, [I, L, I, L, P, I, P, I, P, I, I, P, P, P, P, P, P, I, P, I, P]),
+    "dc_bn_bwd_apply": (I, [I, L, I, L, P, I, P, I, P, I, I, P, P, P, P, P, P, I, P, I, P, P, P]),
     "dc_stem_stat_rows": (I, [I, I, I]),
     "dc_stem_fwd": (I, [I, I, I, I, I, P, P, P, I, P, P]),
     "dc_stem_wgrad_workspace": (SZ, [I, I, I, I]),

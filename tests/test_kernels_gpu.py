@@ -204,7 +204,7 @@ def test_depthwise(case, dtype):
     L.call("dc_dwconv_pack_weights", Cc, vptr(wm), vptr(wd), S())
     _, xv = to_nhwc(x, dtype, ld=Cc + 8)
     _, yv = empty_nhwc(N, Ho, Wo, Cc, dtype)
-    L.call("dc_dwconv_fwd", dt, Cc, stride, dil, N, H, W, vptr(xv), Cc + 8, vptr(wd), vptr(yv), Cc, S())
+    L.call("dc_dwconv_fwd", dt, Cc, stride, dil, N, H, W, vptr(xv), Cc + 8, vptr(wd), vptr(yv), Cc, None, None, 0, S())
     torch.cuda.synchronize()
     assert_close(from_nhwc(yv), yref.detach(), dtype, bf16=1e-2)
     _, gyv = to_nhwc(gy, dtype)
@@ -220,9 +220,73 @@ def test_depthwise(case, dtype):
     wsb = L.load().dc_dwconv_wgrad_workspace(Cc, N, H, W, stride)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
     gw = torch.full((Cc, 1, 3, 3), float("nan"), device=dev())
-    L.call("dc_dwconv_wgrad", dt, Cc, stride, dil, N, H, W, vptr(xv), Cc + 8, vptr(gyv), Cc, vptr(ws), vptr(gw), S())
+    L.call("dc_dwconv_wgrad", dt, Cc, stride, dil, N, H, W, vptr(xv), Cc + 8, vptr(gyv), Cc, vptr(ws), vptr(gw), None, None, 0, S())
     torch.cuda.synchronize()
     assert_close(gw.cpu(), gw_ref, dtype, f32=2e-4, bf16=2e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", DW_CASES, ids=[c[0] for c in DW_CASES])
+@pytest.mark.parametrize("prelu", [1, 0])
+def test_depthwise_with_fused_bn_prologue(case, dtype, prelu):
+    """dw(act(y*scale+shift)) with the BatchNorm(+ReLU) applied on load == dw of the materialised activation; and the BN
+    backward that recomputes the ReLU mask from y (relu=2) == the one that reads the stored activation (relu=1)."""
+    _, Cc, stride, dil, N, H, W = case
+    dt = L.dtype_code(dtype)
+    y = q(rnd(N, Cc, H, W, seed=1), dtype)
+    scale = torch.rand(Cc, generator=torch.Generator().manual_seed(2)) + 0.5
+    shift = rnd(Cc, seed=3, scale=0.3)
+    a = y * scale[None, :, None, None] + shift[None, :, None, None]
+    if prelu:
+        a = F.relu(a)
+    w = rnd(Cc, 1, 3, 3, seed=4, scale=1 / 3)
+    ar, wr = a.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    oref = F.conv2d(F.pad(ar, (dil, dil, dil, dil)), wr, None, stride, 0, dil, groups=Cc)
+    go = q(rnd(*oref.shape, seed=5), dtype)
+    _, gw_ref = torch.autograd.grad(oref, (ar, wr), go)
+    wm = w.to(dev()); wd = torch.empty(9 * Cc, device=dev())
+    L.call("dc_dwconv_pack_weights", Cc, vptr(wm), vptr(wd), S())
+    sc, sh = scale.to(dev()), shift.to(dev())
+    _, yv = to_nhwc(y, dtype)
+    Ho, Wo = oref.shape[2:]
+    _, ov = empty_nhwc(N, Ho, Wo, Cc, dtype)
+    L.call("dc_dwconv_fwd", dt, Cc, stride, dil, N, H, W, vptr(yv), Cc, vptr(wd), vptr(ov), Cc, vptr(sc), vptr(sh), prelu, S())
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(ov), oref.detach(), dtype, bf16=1e-2)
+    _, gov = to_nhwc(go, dtype)
+    wsb = L.load().dc_dwconv_wgrad_workspace(Cc, N, H, W, stride)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    gw = torch.full((Cc, 1, 3, 3), float("nan"), device=dev())
+    L.call("dc_dwconv_wgrad", dt, Cc, stride, dil, N, H, W, vptr(yv), Cc, vptr(gov), Cc, vptr(ws), vptr(gw), vptr(sc), vptr(sh), prelu, S())
+    torch.cuda.synchronize()
+    assert_close(gw.cpu(), gw_ref, dtype, f32=2e-4, bf16=3e-3)
+    if prelu:
+        # BN backward: mask recomputed from y vs mask read from the stored activation must give identical results
+        M = N * H * W
+        _, av = to_nhwc(a, dtype)
+        da = q(rnd(N, Cc, H, W, seed=6), dtype)
+        _, dav = to_nhwc(da, dtype)
+        mean, inv = rnd(Cc, seed=7, scale=0.1).to(dev()), (torch.rand(Cc) + 0.5).to(dev())
+        rows = L.load().dc_bn_stat_rows(M)
+        res = []
+        for relu_mode, outp in ((1, vptr(av)), (2, None)):
+            slab = torch.empty(2, rows, Cc, device=dev())
+            L.call("dc_bn_bwd_reduce", dt, M, Cc, vptr(dav), Cc, vptr(yv), Cc, outp, Cc, relu_mode, vptr(mean), vptr(inv), vptr(slab), vptr(sc), vptr(sh), S())
+            dg, db = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
+            L.call("dc_bn_bwd_finalize", Cc, vptr(slab), rows, vptr(dg), vptr(db), S())
+            _, dyv = empty_nhwc(N, H, W, Cc, dtype)
+            L.call("dc_bn_bwd_apply", dt, M, Cc, M, vptr(dav), Cc, vptr(yv), Cc, outp, Cc, relu_mode, vptr(sc), vptr(mean), vptr(inv), vptr(dg), vptr(db),
+                   vptr(dyv), Cc, None, 0, vptr(sc), vptr(sh), S())
+            torch.cuda.synchronize()
+            res.append((dg.cpu(), db.cpu(), from_nhwc(dyv)))
+        if dtype == torch.float32:
+            for u, v in zip(res[0], res[1]):
+                assert torch.equal(u, v)
+        else:
+            # bf16: the stored activation was rounded, so elements with 0 < a < 2^-133 do not exist; masks agree except where
+            # y*scale+shift rounds to exactly zero in bf16 (measure zero for random data)
+            for u, v in zip(res[0], res[1]):
+                assert_close(u, v, dtype, bf16=1e-3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
@@ -273,13 +337,13 @@ def test_batchnorm_train_fwd_bwd(shape, dtype, relu, use_res):
     # backward
     _, gov = to_nhwc(go, dtype)
     slab2 = torch.empty(2, rows, Cc, device=dev())
-    L.call("dc_bn_bwd_reduce", dt, M, Cc, vptr(gov), Cc, vptr(yv), Cc + 8, vptr(ov), Cc + 16, relu, vptr(smean), vptr(sinv), vptr(slab2), S())
+    L.call("dc_bn_bwd_reduce", dt, M, Cc, vptr(gov), Cc, vptr(yv), Cc + 8, vptr(ov), Cc + 16, relu, vptr(smean), vptr(sinv), vptr(slab2), None, None, S())
     dgamma, dbeta = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
     L.call("dc_bn_bwd_finalize", Cc, vptr(slab2), rows, vptr(dgamma), vptr(dbeta), S())
     _, dyv = empty_nhwc(N, H, W, Cc, dtype)
     _, gv = empty_nhwc(N, H, W, Cc, dtype)
     L.call("dc_bn_bwd_apply", dt, M, Cc, M, vptr(gov), Cc, vptr(yv), Cc + 8, vptr(ov), Cc + 16, relu, vptr(g_d), vptr(smean),
-           vptr(sinv), vptr(dgamma), vptr(dbeta), vptr(dyv), Cc, vptr(gv), Cc, S())
+           vptr(sinv), vptr(dgamma), vptr(dbeta), vptr(dyv), Cc, vptr(gv), Cc, None, None, S())
     torch.cuda.synchronize()
     # with bf16 storage the ReLU mask is taken from the ROUNDED output; compare against a reference using that mask
     if M > 2:  # (a 2-sample BN has |xhat| == 1: dgamma/dy are cancellation-dominated, checked loosely below)
