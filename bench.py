@@ -219,7 +219,16 @@ def main():
             return {"kernel": names[f], "achieved": round(ach / 1e12, 2), "frac": round(ach / peak, 4), "launches_timed": n,
                     "avg_launch_us": round(secs / max(n, 1) * 1e6, 2), "ms_per_step": round(secs / min(a.steps, 3) * 1e3, 3)}
         e = entry(dom)
-        roof = {"bound": "mfma", "achieved": e["achieved"], "peak": peak / 1e12, "unit": "TFLOP/s", "frac": e["frac"], "traffic": None,
+        # HBM bytes per launch come from PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs of this very command) that
+        # cannot be taken from inside the process; the committed measurement is attached when it matches this configuration.
+        traffic = None
+        try:
+            if (B, a.dtype, H, W) == (8, "bf16", 768, 1152):
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                    traffic = round(json.load(f)["kernels"][dom]["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
+        roof = {"bound": "mfma", "achieved": e["achieved"], "peak": peak / 1e12, "unit": "TFLOP/s", "frac": e["frac"], "traffic": traffic,
                 "kernel": e["kernel"], "launches_timed": e["launches_timed"], "avg_launch_us": e["avg_launch_us"],
                 "ms_per_step": e["ms_per_step"], "other_mfma_kernel": entry([f for f in fams if f != dom][0]),
                 "whole_step_frac": round(sps / world * FLOP_PER_SAMPLE * (H * W) / (768 * 1152) / peak, 4)}
