@@ -169,6 +169,12 @@ int dc_head_bwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ld
 /* NCHW fp32 (the layout train_hdf5_ddp.py:348 hands over) -> NHWC `dtype`: the one layout pass of the step. */
 int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, void* out, int ldo, void* stream);
 
+/* Input pipeline (data/cam_hdf5_dataset.py:96-102,122-129): the dataset files are HWC fp32, already channels-last.
+ * out[p][j] = scale[j] * (x_hwc[p][channels[j]] - shift[j])  (channels == NULL: identity), written as NHWC `dtype`.
+ * Replaces the reference's numpy transpose + normalise on the host; with it the step has no layout pass at all. */
+int dc_input_normalize_hwc(int dtype, long npix, int Cfile, int C, const int* channels, const float* x_hwc,
+                           const float* shift, const float* scale, void* out, int ldo, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Loss and metric: utils/losses.py:28-52 (fp_loss == plain mean of weighted CE), torch.max(.,1)[1]
  * (train_hdf5_ddp.py:406,458) and utils/utils.py:32-60 (compute_score) in one pass over the logits.

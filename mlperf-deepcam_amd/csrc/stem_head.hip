@@ -337,6 +337,32 @@ extern "C" int dc_stem_wgrad(int dtype, int N, int Cin, int H, int W, const floa
   return 0;
 }
 
+// Input pipeline (reference data/cam_hdf5_dataset.py:122-129): the files hold HWC fp32 fields, i.e. they are ALREADY channels-last.
+// out[p][j] = scale[j] * (x[p][channels[j]] - shift[j]) selects the requested channels, applies the min/max normalisation and
+// converts to the activation dtype in one pass over the freshly copied batch; no NCHW transpose exists on this path.
+template <typename T>
+__global__ __launch_bounds__(256) void input_normalize_kernel(long npix, int Cfile, int Cc, const int* __restrict__ channels,
+                                                              const float* __restrict__ x, const float* __restrict__ shift,
+                                                              const float* __restrict__ scale, T* __restrict__ out, int ldo) {
+  constexpr int KPV = Elem<T>::kPerVec;
+  const int ngroups = Cc / KPV;
+  const long total = npix * ngroups;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % ngroups);
+    const long p = i / ngroups;
+    float f[KPV];
+#pragma unroll
+    for (int e = 0; e < KPV; ++e) {
+      const int j = cg * KPV + e;
+      const int src = channels != nullptr ? channels[j] : j;
+      f[e] = scale[j] * (x[(size_t)p * Cfile + src] - shift[j]);
+    }
+    vec16 v;
+    pack(v, f, T());
+    stg16(out + (size_t)p * ldo + cg * KPV, v);
+  }
+}
+
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct HeadWs {
@@ -418,6 +444,20 @@ extern "C" int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const floa
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DC_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3((int)blocks), dim3(256), 0, st, x_nchw, (bf16*)out, ldo, N, C, (long)H * W);
   else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3((int)blocks), dim3(256), 0, st, x_nchw, (float*)out, ldo, N, C, (long)H * W);
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dc_input_normalize_hwc(int dtype, long npix, int Cfile, int C, const int* channels, const float* x_hwc,
+                                      const float* shift, const float* scale, void* out, int ldo, void* stream) {
+  if (int e = dc_check_view(out, ldo, C, dtype, "dc_input_normalize_hwc out")) return e;
+  DC_REQUIRE(x_hwc && shift && scale && npix > 0 && Cfile >= C, "dc_input_normalize_hwc: bad argument");
+  const int kpv = dtype == DC_BF16 ? 8 : 4;
+  long blocks = (npix * (C / kpv) + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DC_BF16) hipLaunchKernelGGL(input_normalize_kernel<bf16>, dim3((int)blocks), dim3(256), 0, st, npix, Cfile, C, channels, x_hwc, shift, scale, (bf16*)out, ldo);
+  else hipLaunchKernelGGL(input_normalize_kernel<float>, dim3((int)blocks), dim3(256), 0, st, npix, Cfile, C, channels, x_hwc, shift, scale, (float*)out, ldo);
   DC_CHECK_LAUNCH();
   return 0;
 }
