@@ -3,8 +3,9 @@
 Same command line as the reference (src/deepCam/train_hdf5_ddp.py:548-578, flag for flag), same step order (:345-371),
 same logging-frequency reductions (:398-414), validation averaging (:423-512: mean of per-sample IoUs at batch 1),
 checkpoint dictionary (:515-527: step, epoch, model with 'module.'-prefixed keys, optimizer) and ``:::MLLOG`` event keys
-(utils/mlperf_log_utils.py).  Out of scope by SURVEY section 8: W&B, Basemap plots (flags accepted, ignored) and the HDF5
-reader (section 8f, next): without h5py the driver runs on synthetic batches (``--synthetic_samples``).
+(utils/mlperf_log_utils.py).  Out of scope by SURVEY section 8: W&B and Basemap plots (flags accepted, ignored).
+Input: data.InputPipeline over the HDF5 files when h5py is importable, or over
+synthetic HWC fields with ``--synthetic_samples N`` (this image has no h5py).
 
 Extra flags (not in the reference): --wireup_method env|single, --dtype, --synthetic_samples, --height/--width, --max_steps.
 """
@@ -20,6 +21,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import data as ddata
 from . import dist as comm
 from . import nn as dnn
 
@@ -73,33 +75,6 @@ class MLLogger:
 
     def log_event(self, key, value=None, metadata=None, sync=False):
         self._emit("POINT_IN_TIME", key, value, metadata, sync)
-
-
-class SyntheticSet:
-    """Stand-in for CamDataset (data/cam_hdf5_dataset.py) with the same sharding rule (:43-62): `global_size` samples,
-    rank r owns a contiguous slice; samples are seeded by their global index so every rank count sees the same data."""
-
-    def __init__(self, global_size, H, W, comm_size, comm_rank, allow_uneven, base_seed):
-        self.global_size, self.H, self.W = global_size, H, W
-        n = global_size // comm_size
-        if allow_uneven and comm_rank == comm_size - 1:
-            self.start, self.local_size = n * comm_rank, global_size - n * comm_rank
-        else:
-            self.start, self.local_size = n * comm_rank, n
-        self.base_seed = base_seed
-
-    def batch(self, first, count, device):
-        xs, ys, names = [], [], []
-        for i in range(first, first + count):
-            g = torch.Generator().manual_seed(self.base_seed + self.start + i)
-            xs.append(torch.rand(16, self.H, self.W, generator=g))
-            ys.append(torch.multinomial(torch.tensor(dnn.CLASS_FREQ), self.H * self.W, replacement=True, generator=g).view(self.H, self.W))
-            names.append(f"data-synthetic-{self.start + i:06d}.h5")
-        return torch.stack(xs).to(device, non_blocking=True), torch.stack(ys).to(device, non_blocking=True), names
-
-    def loader(self, batch_size, device):
-        for b in range(self.local_size // batch_size):                 # drop_last=True (train_hdf5_ddp.py:289,306)
-            yield self.batch(b * batch_size, batch_size, device)
 
 
 def build_parser():
@@ -201,16 +176,24 @@ def main(pargs):
         dist.broadcast(steptens, src=0)
         start_step, start_epoch = int(steptens[0]), int(steptens[1])
 
-    if pargs.synthetic_samples <= 0:
-        try:
-            import h5py  # noqa: F401
-        except ImportError:
-            raise RuntimeError("the HDF5 reader (SURVEY section 8f, next) needs h5py, which this image lacks: "
-                               "use --synthetic_samples N") from None
-        raise NotImplementedError("HDF5 input pipeline is the next scope row (SURVEY section 8f)")
-    train_set = SyntheticSet(pargs.synthetic_samples, H, W, size, rank, False, base_seed=12345)
-    n_val = max(size, pargs.synthetic_samples // 8)
-    validation_set = SyntheticSet(n_val, H, W, size, rank, True, base_seed=54321)
+    # ---- data feeder (train_hdf5_ddp.py:274-306): HDF5 files when h5py and a data directory exist, else synthetic HWC fields.
+    #      Both go through the same pipeline: pinned staging -> async copy stream -> fused normalise kernel -> NHWC activations.
+    root_dir = os.path.join(pargs.data_dir_prefix)
+    if pargs.synthetic_samples > 0:
+        train_set = ddata.SyntheticHWC(pargs.synthetic_samples, H, W, channels=pargs.channels, allow_uneven_distribution=False,
+                                       shuffle=True, comm_size=size, comm_rank=rank)
+        n_val = max(size, pargs.synthetic_samples // 8)
+        validation_set = ddata.SyntheticHWC(n_val, H, W, channels=pargs.channels, allow_uneven_distribution=True,
+                                            shuffle=(pargs.max_validation_steps is not None), comm_size=size, comm_rank=rank, seed=54321)
+    else:
+        train_set = ddata.CamDataset(os.path.join(root_dir, "train"), os.path.join(root_dir, "stats.h5"), pargs.channels,
+                                     allow_uneven_distribution=False, shuffle=True, preprocess=True, comm_size=size, comm_rank=rank)
+        validation_set = ddata.CamDataset(os.path.join(root_dir, "validation"), os.path.join(root_dir, "stats.h5"), pargs.channels,
+                                          allow_uneven_distribution=True, shuffle=(pargs.max_validation_steps is not None),
+                                          preprocess=True, comm_size=size, comm_rank=rank)
+        assert tuple(train_set.data_shape[:2]) == (H, W), "pass --height/--width matching the files"
+    train_loader = ddata.InputPipeline(train_set, B, dtype=dtype, device=device)
+    validation_loader = ddata.InputPipeline(validation_set, 1, dtype=dtype, device=device)
     logger.log_event(key="train_samples", value=train_set.global_size)
     val_size = validation_set.global_size if pargs.max_validation_steps is None else \
         min([validation_set.global_size, pargs.max_validation_steps * B * size])
@@ -230,7 +213,7 @@ def main(pargs):
 
     while True:
         logger.log_start(key="epoch_start", metadata={"epoch_num": epoch + 1, "step_num": step}, sync=True)
-        for inputs, label, filename in train_set.loader(B, device):
+        for inputs, label, filename in train_loader:
             train_step(inputs, label)                          # forward, loss, backward (+all-reduce), optimizer.step
             step += 1
             if scheduler is not None:
@@ -251,8 +234,8 @@ def main(pargs):
                 sums = torch.zeros(3, dtype=torch.float64, device=device)            # count, loss, iou
                 with torch.no_grad():
                     step_val = 0
-                    for inputs_val, label_val, _ in validation_set.loader(1, device):
-                        outputs_val = net.forward(inputs_val)
+                    for inputs_val, label_val, _ in validation_loader:
+                        outputs_val = net.engine_for(shape=(1, len(pargs.channels), H, W)).forward(inputs_val, train=False)
                         counts = torch.zeros(9, dtype=torch.int64, device=device)
                         ls = dnn.wce_fused(outputs_val, label_val, class_weights, counts=counts)
                         sums[0] += 1.0
