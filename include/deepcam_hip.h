@@ -65,6 +65,11 @@ int dc_conv_out_hw(const dc_conv_desc* d, int Hi, int Wi, int* Ho, int* Wo);
 int dc_conv_packed_elems(const dc_conv_desc* d, size_t* wf_elems, size_t* wb_elems);
 int dc_conv_pack_weights(const dc_conv_desc* d, const float* master, void* wf, void* wb, void* stream);
 
+/* All layers in one launch.  table_dev: device array of `nentries` records {const float* master; void* wf; void* wb; int cin, cout,
+ * taps, kind;} (40 bytes, natural alignment); kind 0 = conv, 1 = transposed conv (both as dc_conv_pack_weights), 2 = depthwise
+ * (as dc_dwconv_pack_weights: cout = C, wf = fp32 [9][C]).  Dense entries are packed in `dtype`. */
+int dc_pack_all(int dtype, const void* table_dev, int nentries, void* stream);
+
 /* Rows of the per-tile BatchNorm partial-statistics slab that dc_conv_fwd writes when stat_slab != NULL:
  * slab is float[2][rows][cout] (sum, sum of squares of the STORED outputs). */
 int dc_conv_stat_rows(const dc_conv_desc* d, int N, int Hi, int Wi);

@@ -480,9 +480,58 @@ __global__ void pack_weights_kernel(const float* __restrict__ master, T* __restr
   }
 }
 
+// One launch repacks EVERY layer's weights (dense conv fwd/dgrad operands and depthwise [9][C]): the per-layer pack kernels
+// were ~145 launches of ~10 us each, i.e. pure launch-boundary time between the optimizer and the next forward.
+struct PackEntry {
+  const float* master;
+  void* wf;
+  void* wb;
+  int cin, cout, taps, kind;   // kind 0: conv [cout][cin][t], 1: transposed conv [cin][cout][t], 2: depthwise [C][9] -> fp32 [9][C]
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackEntry* __restrict__ table) {
+  const PackEntry e = table[blockIdx.y];
+  if (e.kind == 2) {
+    const int n = 9 * e.cout;
+    float* out = reinterpret_cast<float*>(e.wf);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[(size_t)(i % 9) * e.cout + i / 9] = e.master[i];
+    return;
+  }
+  const long total = (long)e.cin * e.cout * e.taps;
+  const int ldf = (e.cin + 31) / 32 * 32, ldb = (e.cout + 31) / 32 * 32;
+  T* wf = reinterpret_cast<T*>(e.wf);
+  T* wb = reinterpret_cast<T*>(e.wb);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % e.taps);
+    const long r = i / e.taps;
+    int co, ci;
+    if (e.kind == 1) {
+      co = (int)(r % e.cout);
+      ci = (int)(r / e.cout);
+    } else {
+      ci = (int)(r % e.cin);
+      co = (int)(r / e.cin);
+    }
+    const float v = e.master[i];
+    if (wf) Elem<T>::store(wf + ((size_t)t * e.cout + co) * ldf + ci, v);
+    if (wb) Elem<T>::store(wb + ((size_t)t * e.cin + ci) * ldb + co, v);
+  }
+}
+
 }  // namespace dc
 
 using namespace dc;
+
+extern "C" int dc_pack_all(int dtype, const void* table_dev, int nentries, void* stream) {
+  DC_REQUIRE(table_dev != nullptr && nentries > 0, "dc_pack_all: bad argument");
+  DC_REQUIRE(sizeof(PackEntry) == 40, "dc_pack_all: entry layout changed");
+  dim3 grid(128, nentries);
+  if (dtype == DC_BF16) hipLaunchKernelGGL(pack_all_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev);
+  else hipLaunchKernelGGL(pack_all_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev);
+  DC_CHECK_LAUNCH();
+  return 0;
+}
 
 // Tuning switches for A/B measurements in one process: "igemm_mode" (0/1/2, see StageCfg), "wgrad_target_blocks".
 extern "C" int dc_wgrad_set_target_blocks(int n);

@@ -157,6 +157,7 @@ class Engine:
         self.fwd_eval: List[Callable[[], None]] = []
         self.bwd: List[Callable[[], None]] = []      # appended in forward order, executed reversed
         self.pack_ops: List[Callable[[], None]] = []
+        self._pack_entries: List[L.PackEntry] = []
         self.grad_ready: List[List[str]] = []        # per bwd entry: parameter names whose gradient is final after it
         self.ws_bytes = 0
         self._ws_users: List[Callable[[], int]] = []
@@ -167,12 +168,18 @@ class Engine:
         self.dlogits = torch.empty_like(self.logits)
         self._build()
         self.workspace = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=self.device)
+        # one device table -> one launch repacks every layer's weights (dc_pack_all)
+        arr = (L.PackEntry * len(self._pack_entries))(*self._pack_entries)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+        self._pack_table = raw.to(self.device)
+        npk = len(self._pack_entries)
+        self.pack_ops.append(lambda: L.call("dc_pack_all", self.dt, L.dptr(self._pack_table), npk, self._st()))
         # Weight gradients are off the critical path of backward (nothing downstream reads them until the optimizer) and
         # are MFMA-bound, while the chain they branch off (BN backward, depthwise data gradient) is HBM-bound: they run
         # on a side HIP stream with a private workspace and overlap it.  backward() joins the streams at the end.
         self.side = torch.cuda.Stream(device=self.device)
         self.workspace2 = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=self.device)
-        self.use_side_stream = True
+        self.use_side_stream = os.environ.get("DC_SIDE_STREAM", "1") != "0"
         self.on_grad_ready: Optional[Callable[[List[str]], None]] = None
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -244,7 +251,13 @@ class Engine:
         N, H, W = x.N, x.H, x.W
         pw, gw = self.pptr(wname), self.gptr(wname)
         pb = self.pptr(bias) if bias else None
-        self.pack_ops.append(lambda: L.call("dc_conv_pack_weights", C.byref(d), pw, L.dptr(wf), L.dptr(wb), self._st()))
+        if f32 and self.dt != L.DC_F32:
+            # the fp32 island of a bf16 engine (image-pool conv) keeps its own pack call: dc_pack_all packs one dtype
+            self.pack_ops.append(lambda: L.call("dc_conv_pack_weights", C.byref(d), pw, L.dptr(wf), L.dptr(wb), self._st()))
+        else:
+            self._pack_entries.append(L.PackEntry(pw.value, wf.data_ptr(), wb.data_ptr() if wb is not None else None, x.C, cout,
+                                                  d.k * d.k, 1 if transposed else 0))
+            self._keep += [wf] + ([wb] if wb is not None else [])
 
         def fwd(train: bool):
             L.call("dc_conv_fwd", C.byref(d), N, H, W, x.ptr, x.ld, L.dptr(wf), pb, y.ptr, y.ld,
@@ -289,7 +302,7 @@ class Engine:
         wpk = self._f32(9 * Cc)
         self._keep.append(wpk)             # closures below hold only the raw pointer
         pw = L.dptr(wpk)
-        self.pack_ops.append(lambda: L.call("dc_dwconv_pack_weights", Cc, pm, pw, self._st()))
+        self._pack_entries.append(L.PackEntry(pm.value, wpk.data_ptr(), None, Cc, Cc, 9, 2))
         self._need_ws(lib.dc_dwconv_wgrad_workspace(Cc, N, H, W, stride))
 
         def fwd():

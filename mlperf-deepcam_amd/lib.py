@@ -23,6 +23,11 @@ class ConvDesc(C.Structure):
                 ("transposed", C.c_int), ("cin", C.c_int), ("cout", C.c_int)]
 
 
+class PackEntry(C.Structure):
+    _fields_ = [("master", C.c_void_p), ("wf", C.c_void_p), ("wb", C.c_void_p), ("cin", C.c_int), ("cout", C.c_int),
+                ("taps", C.c_int), ("kind", C.c_int)]
+
+
 P, I, L, F, SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 CD = C.POINTER(ConvDesc)
 
@@ -34,6 +39,7 @@ _SIGS = {
     "dc_conv_out_hw": (I, [CD, I, I, C.POINTER(I), C.POINTER(I)]),
     "dc_conv_packed_elems": (I, [CD, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "dc_conv_pack_weights": (I, [CD, P, P, P, P]),
+    "dc_pack_all": (I, [I, P, I, P]),
     "dc_conv_stat_rows": (I, [CD, I, I, I]),
     "dc_conv_fwd": (I, [CD, I, I, I, P, I, P, P, P, I, P, I, P]),
     "dc_conv_fwd_f32out": (I, [CD, I, I, I, P, I, P, P, I, P]),
