@@ -2,9 +2,14 @@
 // One lane owns one 16-byte channel group (8 bf16 / 4 f32 channels) so every global access is a full vector and
 // a wave covers up to 1 KiB of contiguous channels; each thread walks PX output pixels along W with the nine
 // per-channel weights held in registers.  Forward / data-gradient read the weights repacked as [9][C] fp32.
+#include <string.h>
+
 #include "common.h"
+#include "dwtile.h"
 
 namespace dc {
+
+static int g_dw_tile = 1;   // 1: LDS-tiled stride-1 kernels (dwtile.hip); 0: the register-window kernels below
 
 constexpr int DW_PX = 4;  // output pixels per thread (along W)
 
@@ -434,6 +439,7 @@ static int launch_dw(const void* in, int ldin, const float* w, const void* adden
 static int launch_dw_s1(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
                         void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale = nullptr,
                         const float* pshift = nullptr, int prelu = 0) {
+  if (g_dw_tile && pscale == nullptr) return launch_dw_tile(dtype, dil, flip, in, ldin, wp, addend, ldadd, out, ldout, N, H, W, C, st);
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const long total = (long)N * H * ((W + DW_PX - 1) / DW_PX) * (C / kpv);
   DC_REQUIRE(total < (1L << 31), "dc_dwconv: tensor too large for the stride-1 fast path");
@@ -456,6 +462,12 @@ static int dw_check(int dtype, int C, int stride, int dil, int N, int Hi, int Wi
   DC_REQUIRE(stride == 1 || stride == 2, "dc_dwconv: stride must be 1 or 2");
   DC_REQUIRE(dil >= 1 && C > 0 && N > 0 && Hi > 0 && Wi > 0, "dc_dwconv: bad shape");
   return 0;
+}
+
+extern "C" int dc_dw_set_option(const char* name, int value) {
+  if (strcmp(name, "dw_tile") == 0) { g_dw_tile = value != 0; return 0; }
+  if (strcmp(name, "dw_wgrad_tpb") == 0) { dw_tile_set_tpb(value); return 0; }
+  return -1;
 }
 
 extern "C" int dc_dwconv_pack_weights(int C, const float* master, float* packed, void* stream) {
@@ -502,8 +514,13 @@ extern "C" size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int st
   const long P = (long)N * Ho * Wo;
   const int ppb = dw_pix_per_block(P);
   int rows = (int)((P + ppb - 1) / ppb);
-  if (rows < 256) rows = 256;            // the stride-1 fast path uses up to 256 slab rows
-  return (size_t)rows * 9 * C * sizeof(float);
+  if (rows < 256) rows = 256;            // the stride-1 register-window path uses up to 256 slab rows
+  size_t bytes = (size_t)rows * 9 * C * sizeof(float);
+  if (stride == 1) {
+    const size_t tb = dw_tile_wgrad_workspace(C, N, Hi, Wi);
+    if (tb > bytes) bytes = tb;
+  }
+  return bytes;
 }
 
 extern "C" int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
@@ -520,6 +537,8 @@ extern "C" int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int
   hipStream_t st = (hipStream_t)stream;
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const int cgw = dw_pick_cgw(C / kpv);
+  if (stride == 1 && (dil == 1 || dil == 2) && g_dw_tile && pscale == nullptr)
+    return launch_dw_tile_wgrad(dtype, dil, x, ldx, dy, lddy, (float*)workspace, grad_w, N, Hi, Wi, C, st);
   if (stride == 1 && (dil == 1 || dil == 2)) {
     const int nstrips = N * Hi * ((Wi + DW_PX - 1) / DW_PX);
     const int nsl = 256 / cgw;

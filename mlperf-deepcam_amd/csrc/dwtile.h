@@ -1,0 +1,17 @@
+// LDS-tiled stride-1 depthwise kernels (dwtile.hip), called from the C ABI in dwconv.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace dc {
+
+constexpr int DWT_MAX_ROWS = 2048;   // most partial rows the weight-gradient slab may hold
+
+int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
+                   void* out, int ldout, int N, int H, int W, int C, hipStream_t st);
+int launch_dw_tile_wgrad(int dtype, int dil, const void* x, int ldx, const void* dy, int lddy, float* slab, float* grad_w, int N,
+                         int H, int W, int C, hipStream_t st);
+size_t dw_tile_wgrad_workspace(int C, int N, int H, int W);
+void dw_tile_set_tpb(int v);
+
+}  // namespace dc

@@ -1,0 +1,448 @@
+// LDS-tiled stride-1 depthwise 3x3 (forward, data gradient, weight gradient): 60 of the 63 depthwise layers.
+//
+// The register-window kernels in dwconv.hip pull every input element through the vector L1 4.5 times (plus as many weight
+// loads) and measured 2.4 TB/s where a plain copy of the same tensors reaches 4.9 TB/s.  Here a 256-thread workgroup owns
+// CG channel groups (16 bytes each) x an 8 x TW pixel tile:
+//   * the (8+2d) x (TW+2d) halo tile is brought in ONCE by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction,
+//     no VGPRs, no ds_write); out-of-image and out-of-range lanes read a zero page, so the padding costs no branches;
+//   * the nine taps of a thread's channels sit in registers for its whole life (they were re-loaded per strip before);
+//   * a thread computes two 4-pixel strips, reading the 3 x (4+2d) window of each from LDS (ds_read_b128, lanes =
+//     consecutive channel groups = consecutive 16-byte slots: conflict-free);
+//   * workgroups that share an XCD (equal id mod 8) take consecutive tiles, so the halo a tile shares with its neighbours is
+//     served by that XCD's L2 instead of travelling over the fabric again.
+// Tile width follows the channel count so that thin layers still fill the workgroup: CG = 32 / 16 / 8 groups with
+// TW = 8 / 16 / 32 pixels.
+#include "common.h"
+#include "dwtile.h"
+
+namespace dc {
+
+constexpr int DT_PX = 4;   // pixels per strip
+#ifndef DT_TH_VALUE
+#define DT_TH_VALUE 8
+#endif
+constexpr int DT_TH = DT_TH_VALUE;   // tile rows
+
+template <int DIL, int CG>
+struct TileCfg {
+  static constexpr int TH = DT_TH, TW = 8 * (32 / CG);
+  static constexpr int HH = TH + 2 * DIL, HW = TW + 2 * DIL, HP = HH * HW;
+  static constexpr int ITER = (HP * CG + 255) / 256;     // LDS-DMA instructions per wave
+  static constexpr int LDS_BYTES = ITER * 256 * 16;
+  static constexpr int NSL = 128 / CG;                    // strip lanes (a thread owns half a channel group)
+  static constexpr int SPR = TW / DT_PX;                  // strips per tile row
+  static constexpr int SPT = TH * SPR / NSL;              // strips per thread (= 4)
+  static_assert(SPT * NSL == TH * SPR, "tile does not divide into strips");
+};
+
+static __device__ __attribute__((aligned(256))) unsigned char dwt_zero_page[256];
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// XCD-aware bijective remap of the 1-D grid (see igemm.hip), then tile id -> (channel block fastest, tx, ty, n)
+__device__ inline int xcd_remap(int bid, int nwg) {
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+}
+
+template <typename T, int DIL, int CG>
+__device__ inline void stage_halo(char* smem, const T* __restrict__ in, int ldin, int n, int y0, int x0, int cg0, int ngroups, int H,
+                                  int W) {
+  typedef TileCfg<DIL, CG> K;
+  constexpr int KPV = Elem<T>::kPerVec;
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = tid % CG;
+  const bool gok = cg0 + g < ngroups;
+  const T* base = in + (size_t)n * H * W * ldin + (size_t)(cg0 + g) * KPV;
+#pragma unroll
+  for (int it = 0; it < K::ITER; ++it) {
+    const int hp = (it * 256 + tid) / CG;
+    const int hy = hp / K::HW, hx = hp - hy * K::HW;
+    const int iy = y0 - DIL + hy, ix = x0 - DIL + hx;
+    const bool ok = gok && hp < K::HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const void* src = ok ? (const void*)(base + ((size_t)iy * W + ix) * ldin) : (const void*)dwt_zero_page;
+    __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(smem + (it * 256 + wv * 64) * 16), 16, 0, 0);
+  }
+}
+
+// A thread computes on HALF a channel group (8 bytes: 4 bf16 / 2 f32 channels): its nine taps then take 36 (18) registers
+// instead of 72, which is what decides the occupancy of these kernels; LDS is read with ds_read_b64 (same bytes per clock as
+// b128), global memory is still filled / written in full 512-byte runs per pixel.
+struct alignas(8) vec8 {
+  uint32_t w[2];
+};
+__device__ inline void unpack8(const vec8& v, float (&f)[2], float) {
+  f[0] = __uint_as_float(v.w[0]);
+  f[1] = __uint_as_float(v.w[1]);
+}
+__device__ inline void unpack8(const vec8& v, float (&f)[4], bf16) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f[2 * i] = __uint_as_float(v.w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v.w[i] & 0xffff0000u);
+  }
+}
+__device__ inline void pack8(vec8& v, const float (&f)[2], float) {
+  v.w[0] = __float_as_uint(f[0]);
+  v.w[1] = __float_as_uint(f[1]);
+}
+__device__ inline void pack8(vec8& v, const float (&f)[4], bf16) {
+  v.w[0] = pack2_bf16(f[0], f[1]);
+  v.w[1] = pack2_bf16(f[2], f[3]);
+}
+
+template <int KH>
+__device__ inline void load_taps(const float* __restrict__ wp, int ch0, int C, bool flip, float (&wk)[9][KH]) {
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float* src = wp + (size_t)(flip ? 8 - t : t) * C + ch0;
+    if constexpr (KH == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src);
+      wk[t][0] = v.x; wk[t][1] = v.y; wk[t][2] = v.z; wk[t][3] = v.w;
+    } else {
+      const float2 v = *reinterpret_cast<const float2*>(src);
+      wk[t][0] = v.x; wk[t][1] = v.y;
+    }
+  }
+}
+
+// forward (FLIP = false) and data gradient (FLIP = true: the same stencil with the taps reversed, plus an optional addend)
+template <typename T, int DIL, bool FLIP, int CG>
+__global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int ldin, const float* __restrict__ wp,
+                                                  const T* __restrict__ addend, int ldadd, T* __restrict__ out, int ldout, int H, int W,
+                                                  int C, int ncgb, int ntx, int nty) {
+  typedef TileCfg<DIL, CG> K;
+  constexpr int KPV = Elem<T>::kPerVec, KH = KPV / 2;
+  constexpr int WC = DT_PX + 2 * DIL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int cgb = t % ncgb;
+  int r = t / ncgb;
+  const int tx = r % ntx;
+  r /= ntx;
+  const int ty = r % nty, n = r / nty;
+  const int ngroups = C / KPV;
+  const int cg0 = cgb * CG, y0 = ty * K::TH, x0 = tx * K::TW;
+  stage_halo<T, DIL, CG>(smem, in, ldin, n, y0, x0, cg0, ngroups, H, W);
+
+  const int h = threadIdx.x % (2 * CG), sl = threadIdx.x / (2 * CG);   // half-group, strip lane
+  const bool cok = cg0 + (h >> 1) < ngroups;
+  const int ch0 = cok ? cg0 * KPV + h * KH : 0;                          // first of this thread's channels
+  float wk[9][KH];
+  load_taps<KH>(wp, ch0, C, FLIP, wk);
+  __syncthreads();   // vmcnt(0) + barrier: the whole halo tile has landed
+  if (!cok) return;
+
+  const char* tile = smem + h * 8;
+#pragma unroll 1
+  for (int k = 0; k < K::SPT; ++k) {
+    const int q = sl + K::NSL * k;
+    const int row = q / K::SPR, xs = (q % K::SPR) * DT_PX;
+    const int oy = y0 + row;
+    // the addend (gradient already accumulated in dx by another consumer) is requested before the stencil so that its latency
+    // hides behind the arithmetic
+    vec8 av[DT_PX];
+    if (FLIP && addend != nullptr) {
+#pragma unroll
+      for (int j = 0; j < DT_PX; ++j) {
+        const int ox = x0 + xs + j;
+        vec8 z;
+        z.w[0] = z.w[1] = 0u;
+        av[j] = (oy < H && ox < W) ? *reinterpret_cast<const vec8*>(addend + (((size_t)n * H + oy) * W + ox) * ldadd + ch0) : z;
+      }
+    }
+    float acc[DT_PX][KH];
+#pragma unroll
+    for (int j = 0; j < DT_PX; ++j)
+#pragma unroll
+      for (int e = 0; e < KH; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int c = 0; c < WC; ++c) {
+        float f[KH];
+        unpack8(*reinterpret_cast<const vec8*>(tile + ((row + ky * DIL) * K::HW + xs + c) * (CG * 16)), f, T());
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int j = c - kx * DIL;   // output pixel that sees window column c through tap kx
+          if (j >= 0 && j < DT_PX) {
+#pragma unroll
+            for (int e = 0; e < KH; ++e) acc[j][e] = fmaf(f[e], wk[ky * 3 + kx][e], acc[j][e]);
+          }
+        }
+      }
+    }
+    if (oy < H) {
+#pragma unroll
+      for (int j = 0; j < DT_PX; ++j) {
+        const int ox = x0 + xs + j;
+        if (ox < W) {
+          const size_t opix = ((size_t)n * H + oy) * W + ox;
+          if (FLIP && addend != nullptr) {
+            float a[KH];
+            unpack8(av[j], a, T());
+#pragma unroll
+            for (int e = 0; e < KH; ++e) acc[j][e] += a[e];
+          }
+          vec8 v;
+          pack8(v, acc[j], T());
+          *reinterpret_cast<vec8*>(out + opix * ldout + ch0) = v;
+        }
+      }
+    }
+  }
+}
+
+// Weight gradient.  A workgroup walks `tpb` consecutive tiles of one channel block, accumulating 9 x KH products per thread in
+// registers; the strip lanes are folded through LDS and the block leaves ONE row in slab[row][9][C] with fully coalesced
+// stores.  A second kernel adds the rows in a fixed order in fp64.
+template <typename T, int DIL, int CG>
+__global__ __launch_bounds__(256) void dwt_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                        float* __restrict__ slab, int H, int W, int C, int ncgb, int ntx, int nty,
+                                                        int ntiles, int tpb) {
+  typedef TileCfg<DIL, CG> K;
+  constexpr int KPV = Elem<T>::kPerVec, KH = KPV / 2;
+  constexpr int WC = DT_PX + 2 * DIL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int cgb = t % ncgb, srow = t / ncgb;
+  const int ngroups = C / KPV;
+  const int cg0 = cgb * CG;
+  const int h = threadIdx.x % (2 * CG), sl = threadIdx.x / (2 * CG);
+  const bool cok = cg0 + (h >> 1) < ngroups;
+  const int ch0 = cok ? cg0 * KPV + h * KH : 0;
+  float acc[9][KH];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int e = 0; e < KH; ++e) acc[tp][e] = 0.f;
+
+  const int tbeg = srow * tpb, tend = min(ntiles, tbeg + tpb);
+  const char* tile = smem + h * 8;
+  for (int ti = tbeg; ti < tend; ++ti) {
+    const int tx = ti % ntx;
+    int r = ti / ntx;
+    const int ty = r % nty, n = r / nty;
+    const int y0 = ty * K::TH, x0 = tx * K::TW;
+    if (ti != tbeg) __syncthreads();   // everybody is done reading the previous tile
+    stage_halo<T, DIL, CG>(smem, x, ldx, n, y0, x0, cg0, ngroups, H, W);
+    // this thread's dy strips come straight from global memory (each element has exactly one consumer).  The first strip is
+    // requested before the wait so that it travels together with the halo; strip k+1 is requested while strip k is computed.
+    auto load_dy = [&](int k, vec8 (&gv)[DT_PX]) {
+      const int q = sl + K::NSL * k;
+      const int row = q / K::SPR, xs = (q % K::SPR) * DT_PX;
+      const int oy = y0 + row;
+#pragma unroll
+      for (int j = 0; j < DT_PX; ++j) {
+        const int ox = x0 + xs + j;
+        const bool ok = cok && oy < H && ox < W;
+        vec8 z;
+        z.w[0] = z.w[1] = 0u;
+        gv[j] = ok ? *reinterpret_cast<const vec8*>(dy + (((size_t)n * H + oy) * W + ox) * lddy + ch0) : z;
+      }
+    };
+    vec8 gcur[DT_PX], gnext[DT_PX];
+    load_dy(0, gcur);
+    __syncthreads();   // vmcnt(0) + barrier
+    if (cok) {
+#pragma unroll 1
+      for (int k = 0; k < K::SPT; ++k) {
+        if (k + 1 < K::SPT) load_dy(k + 1, gnext);
+        const int q = sl + K::NSL * k;
+        const int row = q / K::SPR, xs = (q % K::SPR) * DT_PX;
+        float gf[DT_PX][KH];
+#pragma unroll
+        for (int j = 0; j < DT_PX; ++j) unpack8(gcur[j], gf[j], T());
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int c = 0; c < WC; ++c) {
+            float f[KH];
+            unpack8(*reinterpret_cast<const vec8*>(tile + ((row + ky * DIL) * K::HW + xs + c) * (CG * 16)), f, T());
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const int j = c - kx * DIL;
+              if (j >= 0 && j < DT_PX) {
+#pragma unroll
+                for (int e = 0; e < KH; ++e) acc[ky * 3 + kx][e] = fmaf(gf[j][e], f[e], acc[ky * 3 + kx][e]);
+              }
+            }
+          }
+#pragma unroll
+        for (int j = 0; j < DT_PX; ++j) gcur[j] = gnext[j];
+      }
+    }
+  }
+  // fold the strip lanes: red[sl][9][CW], CW = channels per block
+  __syncthreads();   // tile reads finished; reuse the LDS
+  float* red = reinterpret_cast<float*>(smem);
+  constexpr int CW = CG * KPV;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int e = 0; e < KH; ++e) red[(sl * 9 + tp) * CW + h * KH + e] = acc[tp][e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * CW; i += 256) {
+    const int tp = i / CW, cl = i % CW;
+    const int c = cg0 * KPV + cl;
+    if (c < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < K::NSL; ++q) s += red[(q * 9 + tp) * CW + cl];
+      slab[((size_t)srow * 9 + tp) * C + c] = s;
+    }
+  }
+}
+
+// grad[c][t] = sum over rows of slab[row][t][c]: 16 columns x 16 row-lanes per block (64-byte segments), fp64, fixed order
+__global__ __launch_bounds__(256) void dwt_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int rows, int C) {
+  __shared__ double red[16][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = 9 * C;
+  const int i = blockIdx.x * 16 + cl;
+  double a0 = 0.0, a1 = 0.0;
+  if (i < n) {
+    int r = rl;
+    for (; r + 16 < rows; r += 32) {
+      a0 += (double)slab[(size_t)r * n + i];
+      a1 += (double)slab[(size_t)(r + 16) * n + i];
+    }
+    if (r < rows) a0 += (double)slab[(size_t)r * n + i];
+  }
+  red[rl][cl] = a0 + a1;
+  __syncthreads();
+  if (threadIdx.x < 16 && blockIdx.x * 16 + threadIdx.x < n) {
+    const int j = blockIdx.x * 16 + threadIdx.x;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][threadIdx.x];
+    const int tp = j / C, c = j % C;
+    grad[(size_t)c * 9 + tp] = (float)s;
+  }
+}
+
+static int g_dw_tpb = 0;   // tiles per workgroup of the weight gradient; 0 = planner
+void dw_tile_set_tpb(int v) { g_dw_tpb = v < 0 ? 0 : v; }
+
+static int pick_cg(int ngroups) { return ngroups <= 8 ? 8 : ngroups <= 16 ? 16 : 32; }
+
+struct TileGrid {
+  int cg, ncgb, ntx, nty, ntiles;
+};
+static TileGrid tile_grid(int ngroups, int N, int H, int W) {
+  TileGrid t;
+  t.cg = pick_cg(ngroups);
+  const int tw = 8 * (32 / t.cg);
+  t.ncgb = cdiv(ngroups, t.cg);
+  t.ntx = cdiv(W, tw);
+  t.nty = cdiv(H, DT_TH);
+  t.ntiles = N * t.ntx * t.nty;
+  return t;
+}
+
+static int wgrad_tpb(const TileGrid& t) {
+  if (g_dw_tpb > 0) return g_dw_tpb;
+  // about 512 workgroups (2 per CU) of about 3 tiles each measured best on the 728-, 256- and 128-channel layers: fewer,
+  // longer workgroups amortise the fold and keep the slab (written once, read once by the reduction) small
+  long tpb = ((long)t.ntiles * t.ncgb + 256) / 512;
+  if (tpb < 1) tpb = 1;
+  while (cdiv(t.ntiles, tpb) > DWT_MAX_ROWS) ++tpb;
+  return (int)tpb;
+}
+
+size_t dw_tile_wgrad_workspace(int C, int N, int H, int W) {
+  size_t best = 0;
+  for (int kpv = 4; kpv <= 8; kpv += 4) {
+    if (C % kpv) continue;
+    const TileGrid t = tile_grid(C / kpv, N, H, W);
+    const int rows = t.ntiles < DWT_MAX_ROWS ? t.ntiles : DWT_MAX_ROWS;
+    const size_t b = (size_t)rows * 9 * C * sizeof(float);
+    if (b > best) best = b;
+  }
+  return best;
+}
+
+template <typename T, int DIL, bool FLIP, int CG>
+static void launch_fwd1(const TileGrid& t, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out,
+                        int ldout, int H, int W, int C, hipStream_t st) {
+  constexpr int LDS = TileCfg<DIL, CG>::LDS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, FLIP, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dwt_kernel<T, DIL, FLIP, CG>), dim3(t.ntiles * t.ncgb), dim3(256), LDS, st, (const T*)in, ldin, wp,
+                     (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty);
+}
+
+template <typename T, int DIL, bool FLIP>
+static void launch_fwd2(const TileGrid& t, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out,
+                        int ldout, int H, int W, int C, hipStream_t st) {
+  if (t.cg == 32) launch_fwd1<T, DIL, FLIP, 32>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st);
+  else if (t.cg == 16) launch_fwd1<T, DIL, FLIP, 16>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st);
+  else launch_fwd1<T, DIL, FLIP, 8>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st);
+}
+
+int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
+                   void* out, int ldout, int N, int H, int W, int C, hipStream_t st) {
+  const int kpv = dtype == DC_BF16 ? 8 : 4;
+  const TileGrid t = tile_grid(C / kpv, N, H, W);
+  DC_REQUIRE((long)t.ntiles * t.ncgb < (1L << 31) && (long)N * H * W < (1L << 31), "dc_dwconv: tensor too large for the tiled path");
+#define DWT(TT, D, F) launch_fwd2<TT, D, F>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st)
+  if (dtype == DC_BF16) {
+    if (dil == 1) { if (flip) DWT(bf16, 1, true); else DWT(bf16, 1, false); }
+    else          { if (flip) DWT(bf16, 2, true); else DWT(bf16, 2, false); }
+  } else {
+    if (dil == 1) { if (flip) DWT(float, 1, true); else DWT(float, 1, false); }
+    else          { if (flip) DWT(float, 2, true); else DWT(float, 2, false); }
+  }
+#undef DWT
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int DIL, int CG>
+static void launch_wg1(const TileGrid& t, int tpb, int rows, const void* x, int ldx, const void* dy, int lddy, float* slab, int H,
+                       int W, int C, hipStream_t st) {
+  constexpr int FOLD = TileCfg<DIL, CG>::NSL * 9 * CG * Elem<T>::kPerVec * (int)sizeof(float);   // red[strip lane][9][channels]
+  constexpr int LDS = TileCfg<DIL, CG>::LDS_BYTES > FOLD ? TileCfg<DIL, CG>::LDS_BYTES : FOLD;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_wgrad_kernel<T, DIL, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dwt_wgrad_kernel<T, DIL, CG>), dim3(rows * t.ncgb), dim3(256), LDS, st, (const T*)x, ldx, (const T*)dy, lddy,
+                     slab, H, W, C, t.ncgb, t.ntx, t.nty, t.ntiles, tpb);
+}
+
+template <typename T, int DIL>
+static void launch_wg2(const TileGrid& t, int tpb, int rows, const void* x, int ldx, const void* dy, int lddy, float* slab, int H,
+                       int W, int C, hipStream_t st) {
+  if (t.cg == 32) launch_wg1<T, DIL, 32>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
+  else if (t.cg == 16) launch_wg1<T, DIL, 16>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
+  else launch_wg1<T, DIL, 8>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
+}
+
+int launch_dw_tile_wgrad(int dtype, int dil, const void* x, int ldx, const void* dy, int lddy, float* slab, float* grad_w, int N,
+                         int H, int W, int C, hipStream_t st) {
+  const int kpv = dtype == DC_BF16 ? 8 : 4;
+  const TileGrid t = tile_grid(C / kpv, N, H, W);
+  const int tpb = wgrad_tpb(t);
+  const int rows = cdiv(t.ntiles, tpb);
+  DC_REQUIRE(rows <= DWT_MAX_ROWS, "dc_dwconv_wgrad: tiles-per-workgroup override needs more slab rows than the workspace holds");
+  DC_REQUIRE((long)N * H * W < (1L << 31), "dc_dwconv_wgrad: tensor too large for the tiled path");
+  if (dtype == DC_BF16) {
+    if (dil == 1) launch_wg2<bf16, 1>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
+    else launch_wg2<bf16, 2>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
+  } else {
+    if (dil == 1) launch_wg2<float, 1>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
+    else launch_wg2<float, 2>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
+  }
+  DC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dwt_reduce_kernel, dim3(cdiv(9 * C, 16)), dim3(256), 0, st, (const float*)slab, grad_w, rows, C);
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace dc

@@ -11,7 +11,7 @@ import subprocess
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdeepcam_hip.so")
+LIB_PATH = os.environ.get("DEEPCAM_HIP_LIB") or os.path.join(_HERE, "libdeepcam_hip.so")   # env: an alternative build (A/B runs)
 CSRC = os.path.join(_HERE, "csrc")
 
 DC_F32, DC_BF16 = 0, 1

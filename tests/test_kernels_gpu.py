@@ -183,7 +183,9 @@ def test_conv_rejects_bad_arguments():
         L.call("dc_conv_dgrad", C.byref(d), 1, 5, 5, vptr(x), 64, vptr(x), vptr(x), 64, 0, S())
 
 
-DW_CASES = [("s1", 728, 1, 1, 2, 12, 10), ("s2", 128, 2, 1, 2, 16, 12), ("d2", 1024, 1, 2, 1, 10, 14), ("odd", 64, 2, 1, 1, 9, 11)]
+DW_CASES = [("s1", 728, 1, 1, 2, 12, 10), ("s2", 128, 2, 1, 2, 16, 12), ("d2", 1024, 1, 2, 1, 10, 14), ("odd", 64, 2, 1, 1, 9, 11),
+            # stride-1 tiled path with thin layers (16 / 8 channel groups -> 16 / 32 pixel wide tiles), several tiles, ragged edges
+            ("thin128", 128, 1, 1, 1, 17, 37), ("thin64", 64, 1, 1, 2, 9, 40), ("thin32d2", 32, 1, 2, 1, 11, 35)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
@@ -223,6 +225,38 @@ def test_depthwise(case, dtype):
     L.call("dc_dwconv_wgrad", dt, Cc, stride, dil, N, H, W, vptr(xv), Cc + 8, vptr(gyv), Cc, vptr(ws), vptr(gw), None, None, 0, S())
     torch.cuda.synchronize()
     assert_close(gw.cpu(), gw_ref, dtype, f32=2e-4, bf16=2e-3)
+
+
+@pytest.mark.parametrize("tpb", [3, 50])
+def test_depthwise_wgrad_several_tiles_per_workgroup(tpb):
+    """The weight-gradient planner gives a workgroup several tiles only on large layers; force it on a small one."""
+    L.call("dc_set_option", b"dw_wgrad_tpb", tpb)
+    try:
+        test_depthwise(("s1", 728, 1, 1, 2, 12, 10), torch.bfloat16)
+        test_depthwise(("thin64", 64, 1, 1, 2, 9, 40), torch.float32)
+    finally:
+        L.call("dc_set_option", b"dw_wgrad_tpb", 0)
+
+
+def test_depthwise_tiled_matches_register_window_path():
+    """A/B switch: both stride-1 implementations give the same forward / data gradient bit for bit (same fp32 tap order)."""
+    Cc, N, H, W = 728, 2, 20, 19
+    x = q(rnd(N, Cc, H, W, seed=11), torch.bfloat16)
+    wm = rnd(Cc, 1, 3, 3, seed=12, scale=1 / 3).to(dev())
+    wd = torch.empty(9 * Cc, device=dev())
+    L.call("dc_dwconv_pack_weights", Cc, vptr(wm), vptr(wd), S())
+    _, xv = to_nhwc(x, torch.bfloat16)
+    outs = []
+    for mode in (1, 0):
+        L.call("dc_set_option", b"dw_tile", mode)
+        _, yv = empty_nhwc(N, H, W, Cc, torch.bfloat16)
+        _, gv = empty_nhwc(N, H, W, Cc, torch.bfloat16)
+        L.call("dc_dwconv_fwd", L.DC_BF16, Cc, 1, 1, N, H, W, vptr(xv), Cc, vptr(wd), vptr(yv), Cc, None, None, 0, S())
+        L.call("dc_dwconv_dgrad", L.DC_BF16, Cc, 1, 1, N, H, W, vptr(xv), Cc, vptr(wd), None, 0, vptr(gv), Cc, S())
+        torch.cuda.synchronize()
+        outs.append((yv.clone(), gv.clone()))
+    L.call("dc_set_option", b"dw_tile", 1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
