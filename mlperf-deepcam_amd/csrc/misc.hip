@@ -137,17 +137,48 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* __restr
   if (threadIdx.x == 0) atomicAdd(out, s[0] + s[1] + s[2] + s[3]);
 }
 
-constexpr int LAMB_SLICES = 32;
+// LAMB works on fixed-size chunks that never straddle a tensor: a tensor of n elements owns ceil(n / LAMB_CHUNK) consecutive
+// workgroups, so the 4.7 M-element ASPP kernels and the 728-element BatchNorm vectors get work in proportion (the first version
+// gave every tensor 32 workgroups: the kernel lasted as long as the largest tensor took on 32 of the chip's 256 CUs).
+constexpr int LAMB_CHUNK = 4096;
+
+// chunk_prefix[t] = number of chunks of tensors 0..t-1 (ntensors + 1 entries), one thread: ~300 tensors
+__global__ void lamb_plan_kernel(const int64_t* __restrict__ offs, int ntensors, int* __restrict__ chunk_prefix) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int acc = 0;
+  for (int t = 0; t < ntensors; ++t) {
+    chunk_prefix[t] = acc;
+    acc += (int)((offs[t + 1] - offs[t] + LAMB_CHUNK - 1) / LAMB_CHUNK);
+  }
+  chunk_prefix[ntensors] = acc;
+}
+
+// workgroup -> (tensor, element range); false when the workgroup is past the last chunk
+__device__ inline bool lamb_locate(const int64_t* __restrict__ offs, const int* __restrict__ chunk_prefix, int ntensors, int& t,
+                                   long& beg, long& end) {
+  const int b = blockIdx.x;
+  if (b >= chunk_prefix[ntensors]) return false;
+  int lo = 0, hi = ntensors;   // invariant: chunk_prefix[lo] <= b < chunk_prefix[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_prefix[mid] <= b) lo = mid; else hi = mid;
+  }
+  t = lo;
+  beg = offs[t] + (long)(b - chunk_prefix[t]) * LAMB_CHUNK;
+  end = beg + LAMB_CHUNK < offs[t + 1] ? beg + LAMB_CHUNK : offs[t + 1];
+  return true;
+}
 
 // stage 1: moments, update direction u (written over g), per-tensor ||w||^2 and ||u||^2
-__global__ __launch_bounds__(256) void lamb_stage1_kernel(const int64_t* __restrict__ offs, float* __restrict__ p,
-                                                          float* __restrict__ g, float* __restrict__ m,
-                                                          float* __restrict__ v, float beta1, float beta2, float eps,
-                                                          float wd, const int* step_dev, float max_grad_norm,
+__global__ __launch_bounds__(256) void lamb_stage1_kernel(const int64_t* __restrict__ offs, const int* __restrict__ chunk_prefix,
+                                                          int ntensors, float* __restrict__ p, float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, float beta1, float beta2,
+                                                          float eps, float wd, const int* step_dev, float max_grad_norm,
                                                           float grad_scale, float* ws) {
   __shared__ float s[2][4];
-  const int t = blockIdx.x;
-  const long beg = offs[t], end = offs[t + 1];
+  int t;
+  long beg, end;
+  if (!lamb_locate(offs, chunk_prefix, ntensors, t, beg, end)) return;
   const int step = *step_dev;
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
@@ -155,7 +186,7 @@ __global__ __launch_bounds__(256) void lamb_stage1_kernel(const int64_t* __restr
   const float clip = gnorm > max_grad_norm ? gnorm / max_grad_norm : 1.f;
   const float gs = grad_scale / clip;
   float wn = 0.f, un = 0.f;
-  for (long i = beg + blockIdx.y * 256L + threadIdx.x; i < end; i += 256L * LAMB_SLICES) {
+  for (long i = beg + threadIdx.x; i < end; i += 256) {
     const float gr = g[i] * gs;
     const float pv = p[i];
     const float mv = m[i] + (gr - m[i]) * (1.f - beta1);
@@ -180,15 +211,16 @@ __global__ __launch_bounds__(256) void lamb_stage1_kernel(const int64_t* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void lamb_stage2_kernel(const int64_t* __restrict__ offs, float* __restrict__ p,
-                                                          const float* __restrict__ u, const float* lr_dev,
-                                                          const float* __restrict__ ws) {
-  const int t = blockIdx.x;
-  const long beg = offs[t], end = offs[t + 1];
+__global__ __launch_bounds__(256) void lamb_stage2_kernel(const int64_t* __restrict__ offs, const int* __restrict__ chunk_prefix,
+                                                          int ntensors, float* __restrict__ p, const float* __restrict__ u,
+                                                          const float* lr_dev, const float* __restrict__ ws) {
+  int t;
+  long beg, end;
+  if (!lamb_locate(offs, chunk_prefix, ntensors, t, beg, end)) return;
   const float wn = sqrtf(ws[2 + 2 * t]), un = sqrtf(ws[3 + 2 * t]);
   const float ratio = (wn > 0.f && un > 0.f) ? wn / un : 1.f;
   const float a = *lr_dev * ratio;
-  for (long i = beg + blockIdx.y * 256L + threadIdx.x; i < end; i += 256L * LAMB_SLICES) p[i] = fmaf(-a, u[i], p[i]);
+  for (long i = beg + threadIdx.x; i < end; i += 256) p[i] = fmaf(-a, u[i], p[i]);
 }
 
 static int ew_blocks2(long total) {
@@ -288,10 +320,16 @@ extern "C" int dc_lamb_step(int ntensors, const int64_t* offsets_dev, long n, fl
   DC_CHECK_LAUNCH();
   // the update direction is staged in the gradient arena (it is dead after this step)
   float* gw = const_cast<float*>(g);
-  hipLaunchKernelGGL(lamb_stage1_kernel, dim3(ntensors, LAMB_SLICES), dim3(256), 0, st, offsets_dev, p, gw, m, v, beta1, beta2,
-                     eps, weight_decay, step_dev, max_grad_norm, grad_scale, workspace);
+  int* chunk_prefix = reinterpret_cast<int*>(workspace + 2 * (size_t)ntensors + 2);
+  hipLaunchKernelGGL(lamb_plan_kernel, dim3(1), dim3(64), 0, st, offsets_dev, ntensors, chunk_prefix);
   DC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(lamb_stage2_kernel, dim3(ntensors, LAMB_SLICES), dim3(256), 0, st, offsets_dev, p, gw, lr_dev, workspace);
+  const long max_chunks = n / LAMB_CHUNK + ntensors;   // every tensor rounds up by less than one chunk
+  DC_REQUIRE(max_chunks < (1L << 31), "dc_lamb_step: arena too large");
+  hipLaunchKernelGGL(lamb_stage1_kernel, dim3((unsigned)max_chunks), dim3(256), 0, st, offsets_dev, chunk_prefix, ntensors, p, gw, m,
+                     v, beta1, beta2, eps, weight_decay, step_dev, max_grad_norm, grad_scale, workspace);
+  DC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lamb_stage2_kernel, dim3((unsigned)max_chunks), dim3(256), 0, st, offsets_dev, chunk_prefix, ntensors, p, gw,
+                     lr_dev, workspace);
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -542,25 +542,25 @@ def test_adam_matches_torch_optim(kind, wd):
 
 def test_lamb_matches_oracle():
     from oracle.optim import OracleOptimizer
-    sizes = [1000, 7, 4096, 33]
+    sizes = [1000, 7, 4096, 33, 10001]   # one tensor of exactly one chunk, one of 2.4 chunks
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     n = int(offs[-1])
     p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=3.0)
     p0[offs[1]:offs[2]] = 0.0        # a zero-norm tensor -> trust ratio 1
-    cpu_p = [p0[offs[i]:offs[i + 1]].clone() for i in range(4)]
+    cpu_p = [p0[offs[i]:offs[i + 1]].clone() for i in range(len(sizes))]
     ref = OracleOptimizer(cpu_p, "LAMB", lr=1e-2, eps=1e-6, weight_decay=1e-2)
     p = p0.clone().to(dev())
     m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
     lr = torch.tensor([1e-2], device=dev())
     step = torch.zeros(1, dtype=torch.int32, device=dev())
-    ws = torch.empty(2 * 4 + 2, device=dev())
+    ws = torch.empty(3 * len(sizes) + 4, device=dev())
     od = torch.from_numpy(offs).to(dev())
     for s in range(1, 4):
         gs = g / s
-        ref.step([gs[offs[i]:offs[i + 1]] for i in range(4)])
+        ref.step([gs[offs[i]:offs[i + 1]] for i in range(len(sizes))])
         gd = gs.clone().to(dev())
         step.fill_(s)
-        L.call("dc_lamb_step", 4, vptr(od), n, vptr(p), vptr(gd), vptr(m), vptr(v), vptr(lr), 0.9, 0.999, 1e-6, 1e-2, vptr(step),
+        L.call("dc_lamb_step", len(sizes), vptr(od), n, vptr(p), vptr(gd), vptr(m), vptr(v), vptr(lr), 0.9, 0.999, 1e-6, 1e-2, vptr(step),
                1.0, 1.0, vptr(ws), S())
         torch.cuda.synchronize()
         np.testing.assert_allclose(p.cpu().numpy(), torch.cat(cpu_p).numpy(), rtol=2e-5, atol=2e-6)
