@@ -44,6 +44,6 @@ for key, name, fl, e0, e1 in recs:
 print(f"B={B} {dt}: sum of per-call times {tot:.2f} ms over {len(recs)} calls")
 for n, ms in byname.most_common(): print(f"  {n:24s} {ms:8.3f} ms  {100*ms/tot:5.1f}%")
 print("--- top shapes")
-for key, (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+for key, (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("DC_TOP", "45"))]:
     tf = f"{fl/ms/1e9:7.1f} TF/s" if fl else ""
     print(f"{ms:8.3f} ms  x{cnt:<3d} {ms/cnt*1e3:8.1f} us/call  {tf:14s} {key}")

@@ -183,6 +183,49 @@ def test_conv_rejects_bad_arguments():
         L.call("dc_conv_dgrad", C.byref(d), 1, 5, 5, vptr(x), 64, vptr(x), vptr(x), 64, 0, S())
 
 
+PACK_CASES = [(1, 0, 728, 728), (3, 0, 304, 256), (3, 0, 16, 32), (3, 1, 256, 256), (1, 0, 2048, 256), (3, 0, 2048, 64), (1, 0, 48, 130)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_pack_all_matches_per_layer_pack(dtype):
+    """dc_pack_all (one launch, LDS tile transposes) writes exactly what dc_conv_pack_weights writes, layer by layer,
+    including layers for which only one of the two operands is wanted; the depthwise entry gives [9][C]."""
+    table, keep, expect = [], [], []
+    for i, (k, tr, cin, cout) in enumerate(PACK_CASES):
+        d = L.ConvDesc(L.dtype_code(dtype), k, 2 if tr else 1, k // 2, 1, tr, cin, cout)
+        wm = rnd(*((cin, cout, k, k) if tr else (cout, cin, k, k)), seed=20 + i).to(dev())
+        nwf, nwb = C.c_size_t(), C.c_size_t()
+        L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
+        ref_f = torch.zeros(nwf.value, dtype=dtype, device=dev())
+        ref_b = torch.zeros(nwb.value, dtype=dtype, device=dev())
+        L.call("dc_conv_pack_weights", C.byref(d), vptr(wm), vptr(ref_f), vptr(ref_b), S())
+        got_f, got_b = torch.zeros_like(ref_f), torch.zeros_like(ref_b)
+        want_b = i % 3 != 2            # every third layer asks for the forward operand only
+        table.append(L.PackEntry(wm.data_ptr(), got_f.data_ptr(), got_b.data_ptr() if want_b else None, cin, cout, k * k, 1 if tr else 0))
+        keep += [wm, got_f, got_b]
+        expect.append((ref_f, got_f, ref_b if want_b else None, got_b))
+    Cd = 728
+    wdm = rnd(Cd, 1, 3, 3, seed=40).to(dev())
+    ref_d, got_d = torch.empty(9 * Cd, device=dev()), torch.zeros(9 * Cd, device=dev())
+    L.call("dc_dwconv_pack_weights", Cd, vptr(wdm), vptr(ref_d), S())
+    table.append(L.PackEntry(wdm.data_ptr(), got_d.data_ptr(), None, Cd, Cd, 9, 2))
+    raw = bytes(bytearray(b"".join(bytes(e) for e in table)))
+    tdev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev())
+    L.call("dc_pack_all", L.dtype_code(dtype), vptr(tdev), len(table), S())
+    torch.cuda.synchronize()
+    for (ref_f, got_f, ref_b, got_b), case in zip(expect, PACK_CASES):
+        k, tr, cin, cout = case
+        ldf, ldb = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+        # compare the payload (the row padding is never read and may hold anything)
+        f_ref, f_got = ref_f.view(k * k, cout, ldf)[:, :, :cin], got_f.view(k * k, cout, ldf)[:, :, :cin]
+        assert torch.equal(f_ref, f_got), case
+        if ref_b is not None:
+            assert torch.equal(ref_b.view(k * k, cin, ldb)[:, :, :cout], got_b.view(k * k, cin, ldb)[:, :, :cout]), case
+        else:
+            assert not got_b.any()
+    assert torch.equal(ref_d, got_d)
+
+
 DW_CASES = [("s1", 728, 1, 1, 2, 12, 10), ("s2", 128, 2, 1, 2, 16, 12), ("d2", 1024, 1, 2, 1, 10, 14), ("odd", 64, 2, 1, 1, 9, 11),
             # stride-1 tiled path with thin layers (16 / 8 channel groups -> 16 / 32 pixel wide tiles), several tiles, ragged edges
             ("thin128", 128, 1, 1, 1, 17, 37), ("thin64", 64, 1, 1, 2, 9, 40), ("thin32d2", 32, 1, 2, 1, 11, 35)]
