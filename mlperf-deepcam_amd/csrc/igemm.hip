@@ -398,6 +398,59 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 }
 
+// Pointwise convolution on at most 16 pixels (the image-pool branch: 2048 -> 256 on the 1x1 pooled map, M = batch).  The tiled
+// kernel runs one or two workgroups for ~200 us there (64 dependent K steps of latency); this is a plain GEMV bundle instead:
+// one wave per output channel, lanes stride over K in 16-byte vectors, the <= 16 pixel rows are L2-resident.
+constexpr int TINY_M = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void tiny_gemm_kernel(const IgemmParams p) {
+  constexpr int KPV = Elem<T>::kPerVec;
+  const int lane = threadIdx.x & 63;
+  const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (co >= p.g.Cout) return;
+  const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ w = reinterpret_cast<const T*>(p.w) + ((size_t)p.g.taps[0].widx * p.g.Cout + co) * p.ldw;
+  float acc[TINY_M];
+#pragma unroll
+  for (int m = 0; m < TINY_M; ++m) acc[m] = 0.f;
+  for (int k0 = lane * KPV; k0 < p.g.Cin; k0 += 64 * KPV) {
+    float wf[KPV];
+    unpack(ldg16(w + k0), wf, T());
+#pragma unroll
+    for (int m = 0; m < TINY_M; ++m) {
+      if (m < p.M) {
+        float xf[KPV];
+        unpack(ldg16(x + (size_t)m * p.ldx + k0), xf, T());
+#pragma unroll
+        for (int e = 0; e < KPV; ++e) acc[m] = fmaf(xf[e], wf[e], acc[m]);
+      }
+    }
+  }
+  float s = 0.f, q = 0.f;
+  T* __restrict__ y = reinterpret_cast<T*>(p.y);
+#pragma unroll
+  for (int m = 0; m < TINY_M; ++m) {
+    if (m < p.M) {
+      float v = wave_sum(acc[m]);
+      if (p.bias != nullptr) v += p.bias[co];
+      T* dst = y + (size_t)m * p.ldy + co;
+      if (p.accumulate) v += Elem<T>::load(dst);
+      T tv;
+      Elem<T>::store(&tv, v);
+      const float st = Elem<T>::load(&tv);   // the statistics are those of the STORED (rounded) value
+      if (lane == 0) {
+        *dst = tv;
+        s += st;
+        q = fmaf(st, st, q);
+      }
+    }
+  }
+  if (p.slab != nullptr && lane == 0) {
+    p.slab[co] = s;                       // one slab row: [2][1][Cout]
+    p.slab[p.g.Cout + co] = q;
+  }
+}
+
 static int g_igemm_mode = 2;
 
 template <typename T, bool OUT32, int MODE>
@@ -451,6 +504,12 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   p.mtiles = cdiv(M, BM);
   p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
+  if (!out32 && p.M <= TINY_M && p.g.ntaps == 1 && p.g.os == 1 && p.g.is == 1 && p.g.taps[0].dy == 0 && p.g.taps[0].dx == 0) {
+    if (d->dtype == DC_BF16) hipLaunchKernelGGL(tiny_gemm_kernel<bf16>, dim3(cdiv(p.g.Cout, 4)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(tiny_gemm_kernel<float>, dim3(cdiv(p.g.Cout, 4)), dim3(256), 0, st, p);
+    DC_CHECK_LAUNCH();
+    return 0;
+  }
   if (d->dtype == DC_BF16) return out32 ? launch_igemm<bf16, true>(p, st) : launch_igemm<bf16, false>(p, st);
   return launch_igemm<float, false>(p, st);
 }

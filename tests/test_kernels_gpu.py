@@ -85,7 +85,9 @@ CONV_CASES = [
     ("atrous18", 3, 1, 18, 18, 0, 32, 40, 1, 48, 72),
     ("convT", 3, 2, 1, 1, 1, 256, 256, 2, 8, 6),
     ("convT_small", 3, 2, 1, 1, 1, 24, 40, 1, 5, 7),
-    ("gemm_rows2", 1, 1, 0, 1, 0, 2048, 256, 2, 1, 1),
+    ("gemm_rows2", 1, 1, 0, 1, 0, 2048, 256, 2, 1, 1),      # <= 16 pixels: the GEMV path of the image-pool branch
+    ("gemm_rows16", 1, 1, 0, 1, 0, 264, 72, 16, 1, 1),
+    ("gemm_rows17", 1, 1, 0, 1, 0, 264, 72, 17, 1, 1),      # one more pixel: back on the tiled kernel
 ]
 
 
