@@ -14,10 +14,31 @@ struct Tap {
   int dy, dx, widx, phase;
 };
 
+// Division by a launch-invariant divisor without the ~35-instruction integer division sequence: q = mulhi(n, M) >> sh, exact
+// for 0 <= n < 2^31 (M = ceil(2^(31+s) / d), s = ceil(log2 d), sh = s - 1; d == 1 is flagged by M == 0).
+struct FastDiv {
+  unsigned M;
+  int sh;
+  int d;
+};
+inline FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.M = 0; f.sh = 0; return f; }
+  int s = 0;
+  while ((1L << s) < d) ++s;
+  f.M = (unsigned)(((1UL << (31 + s)) + (unsigned long)d - 1) / (unsigned long)d);
+  f.sh = s - 1;
+  return f;
+}
+__device__ inline int fast_div(int n, const FastDiv& f) { return f.M == 0 ? n : (int)(__umulhi((unsigned)n, f.M) >> f.sh); }
+
 struct GatherGeom {
   int os, is;      // output / input stride of the phase grid
   int ntaps;
-  Tap taps[9];
+  Tap taps[9];     // sorted by phase
+  int phase_beg[5];     // taps of phase ph: [phase_beg[ph], phase_beg[ph+1])
+  FastDiv div_hw, div_w;   // by Qh*Qw and by Qw
   int Hin, Win, Cin;    // gathered tensor extents
   int Hout, Wout, Cout; // produced tensor extents
   int Qh, Qw;           // phase grid extents (Hout/os, Wout/os)
@@ -74,6 +95,13 @@ inline bool build_geom(const dc_conv_desc& d, int Hi, int Wi, GatherMode mode, G
   if (g->Hout % g->os != 0 || g->Wout % g->os != 0) return false;
   g->Qh = g->Hout / g->os;
   g->Qw = g->Wout / g->os;
+  for (int ph = 0; ph <= 4; ++ph) {
+    int c = 0;
+    while (c < g->ntaps && g->taps[c].phase < ph) ++c;   // taps are generated in phase order
+    g->phase_beg[ph] = c;
+  }
+  g->div_hw = make_fastdiv(g->Qh * g->Qw);
+  g->div_w = make_fastdiv(g->Qw);
   return true;
 }
 

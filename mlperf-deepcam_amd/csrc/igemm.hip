@@ -65,6 +65,19 @@ struct Mma<float> {
   }
 };
 
+// Diagnostic build only (-DDC_STAMPS, scripts/igemm_stamps.py): per-workgroup s_memtime stamps at the phase boundaries of the
+// kernel, written to a buffer no other code reads.  The product build contains none of this.
+#ifdef DC_STAMPS
+__device__ unsigned long long* dc_stamp_buf = nullptr;
+#define DC_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && dc_stamp_buf != nullptr)                                                  \
+      dc_stamp_buf[(size_t)blockIdx.x * 8 + (k)] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define DC_STAMP(k)
+#endif
+
 template <int ROWB>
 __device__ inline int swz(int row, int slot) {
   if constexpr (ROWB == 128) return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);   // 8 slots per row
@@ -99,10 +112,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int MAIN_BYTES = (2 * NSTAGE * OPER_BYTES) > (BM * CROW) ? (2 * NSTAGE * OPER_BYTES) : (BM * CROW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_tap = reinterpret_cast<int*>(smem + MAIN_BYTES);
-  int& s_ntap = s_tap[27];
 
   const GatherGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  DC_STAMP(0);
+  DC_STAMP(1);
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so the ones that
   // share an XCD (equal id mod 8) are given CONSECUTIVE tiles, and consecutive tiles walk the output-channel tiles of one
   // pixel tile first: the 128-pixel A panel is then fetched into that XCD's L2 once instead of once per channel tile.
@@ -118,19 +132,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int m0 = mtile * BM;
   const int py = phase / g.os, px = phase % g.os;
 
-  if (tid == 0) {
-    int c = 0;
-    for (int t = 0; t < g.ntaps; ++t)
-      if (g.taps[t].phase == phase) {
-        s_tap[3 * c] = g.taps[t].dy;
-        s_tap[3 * c + 1] = g.taps[t].dx;
-        s_tap[3 * c + 2] = g.taps[t].widx;
-        ++c;
-      }
-    s_ntap = c;
+  // this phase's taps -> LDS (one thread per tap; the list is already sorted by phase on the host)
+  const int tap_beg = g.phase_beg[phase], ntap = g.phase_beg[phase + 1] - tap_beg;
+  if (tid < ntap) {
+    const Tap tp = g.taps[tap_beg + tid];
+    s_tap[3 * tid] = tp.dy;
+    s_tap[3 * tid + 1] = tp.dx;
+    s_tap[3 * tid + 2] = tp.widx;
   }
   __syncthreads();
-  const int ntap = s_ntap;
   const int kchunks = (g.Cin + BK - 1) / BK;
   const int steps = ntap * kchunks;
   if (steps == 0 && p.accumulate) return;  // a phase without taps contributes zeros
@@ -147,9 +157,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int m = m0 + r;
     rok[i] = m < p.M;
     const int mm = rok[i] ? m : 0;
-    const int n = mm / (g.Qh * g.Qw);
+    const int n = fast_div(mm, g.div_hw);
     const int rem = mm - n * (g.Qh * g.Qw);
-    const int qy = rem / g.Qw, qx = rem - qy * g.Qw;
+    const int qy = fast_div(rem, g.div_w), qx = rem - qy * g.Qw;
     rowbase[i] = n * g.Hin;
     riy[i] = qy * g.is;
     rix[i] = qx * g.is;
@@ -232,6 +242,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       }
     };
     int tapi = 0, kc = 0;
+    DC_STAMP(2);
     if constexpr (NSTAGE == 2) {
       if (steps > 0) issue(0, 0, 0);
       __syncthreads();   // (waits vmcnt(0): stage 0 has landed for every wave)
@@ -260,6 +271,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef DC_STAMPS
+        if (s == 0) DC_STAMP(3);
+#endif
         if (s + NSTAGE - 1 < steps) issue(tapi, kc, (s + NSTAGE - 1) % NSTAGE);
         next_step(tapi, kc);
         compute(s % NSTAGE);
@@ -310,6 +324,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------
+  DC_STAMP(4);
   char* ct = smem;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -337,6 +352,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
   }
   __syncthreads();
+  DC_STAMP(5);
 
   constexpr int GPR = BN * (int)sizeof(TO) / 16;  // 16-byte groups per C row: 16 (bf16) / 32 (f32)
   constexpr int RPP = 256 / GPR;                  // rows covered per pass: 16 / 8
@@ -353,11 +369,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int row = rsub + ps * RPP;
     const int m = m0 + row;
     if (m < p.M && chok) {
-      const int n = m / (g.Qh * g.Qw);
-      const int rem = m - n * (g.Qh * g.Qw);
-      const int qy = rem / g.Qw, qx = rem - qy * g.Qw;
-      const int oy = qy * g.os + py, ox = qx * g.os + px;
-      TO* dst = yg + ((size_t)(n * g.Hout + oy) * g.Wout + ox) * p.ldy + ch0;
+      size_t opix = (size_t)m;              // os == 1: the phase grid IS the output, pixel index = m
+      if (g.os != 1) {
+        const int n = fast_div(m, g.div_hw);
+        const int rem = m - n * (g.Qh * g.Qw);
+        const int qy = fast_div(rem, g.div_w), qx = rem - qy * g.Qw;
+        opix = (size_t)(n * g.Hout + qy * g.os + py) * g.Wout + qx * g.os + px;
+      }
+      TO* dst = yg + opix * p.ldy + ch0;
       vec16 v = *reinterpret_cast<const vec16*>(ct + row * CROW + grp * 16);
       float f[KPVO];
       unpack(v, f, TO());
@@ -396,6 +415,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       p.slab[((size_t)which * rows + srow) * g.Cout + n0 + c] = a;
     }
   }
+  DC_STAMP(6);
+  DC_STAMP(7);
 }
 
 // Pointwise convolution on at most 16 pixels (the image-pool branch: 2048 -> 256 on the 1x1 pooled map, M = batch).  The tiled
@@ -618,6 +639,13 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackEntry* __restri
 }  // namespace dc
 
 using namespace dc;
+
+#ifdef DC_STAMPS
+extern "C" int dc_debug_stamp_buf(void* buf) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(dc_stamp_buf), &buf, sizeof(buf));
+  return e == hipSuccess ? 0 : dc_set_error(e, __FILE__, __LINE__);
+}
+#endif
 
 extern "C" int dc_pack_all(int dtype, const void* table_dev, int nentries, void* stream) {
   DC_REQUIRE(table_dev != nullptr && nentries > 0, "dc_pack_all: bad argument");
