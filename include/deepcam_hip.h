@@ -33,7 +33,9 @@ enum { DC_ADAM = 0, DC_ADAMW = 1, DC_LAMB = 2 };
 const char* dc_last_error(void);
 int dc_version(void);
 /* Tuning switches (A/B measurements inside one process).  "igemm_mode": 2 = LDS-DMA, 3-stage ring, counted waits (default);
- * 1 = LDS-DMA, 2 stages; 0 = register staging.  "wgrad_target_blocks": workgroups aimed at by the split-K planner. */
+ * 1 = LDS-DMA, 2 stages; 0 = register staging.  "igemm256": 0 = 128 x 128 tiles only, 1 = planner picks per layer (default),
+ * 2 = 256 x 256 eight-wave kernel wherever eligible.  "wgrad_target_blocks": workgroups aimed at by the split-K planner.
+ * "dw_tile" 0/1, "dw_wgrad_tpb", "bn_cgw", "bn_rows": depthwise / BatchNorm kernel variants (see the .hip files). */
 int dc_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------------

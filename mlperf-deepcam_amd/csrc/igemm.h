@@ -1,0 +1,30 @@
+// Shared by the implicit-GEMM kernels (igemm.hip: 128 x 128 tile, 4 waves; igemm256.hip: 256 x 256 tile, 8 waves).
+#pragma once
+#include "conv_geom.h"
+
+namespace dc {
+
+struct IgemmParams {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* bias;
+  float* slab;
+  GatherGeom g;
+  int N, ldx, ldy;
+  int ldw;     // K stride of a packed weight row: Cin rounded up to 32 elements, so every row starts on a 64-byte boundary
+  int M;       // pixels per phase = N*Qh*Qw
+  int mtiles;  // tiles per phase
+  int accumulate;
+  const void* zero_page;   // 256 zero bytes in device memory (set by the 256-tile launcher)
+};
+// OUT32: the epilogue stores fp32 regardless of T (used by the classifier head, whose logits must not be rounded to bf16)
+
+// 256 x 256 tile kernel (bf16 only).  Returns 0 after launching.
+int launch_igemm256(const IgemmParams& p, hipStream_t st);
+// workgroups the 256-tile kernel would launch for this problem
+inline long igemm256_tiles(const IgemmParams& p) {
+  return (long)((p.g.Cout + 255) / 256) * ((p.M + 255) / 256) * p.g.os * p.g.os;
+}
+
+}  // namespace dc

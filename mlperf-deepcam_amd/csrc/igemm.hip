@@ -14,23 +14,9 @@
 #include <type_traits>
 
 #include "conv_geom.h"
+#include "igemm.h"
 
 namespace dc {
-
-struct IgemmParams {
-  const void* x;
-  const void* w;
-  void* y;
-  const float* bias;
-  float* slab;
-  GatherGeom g;
-  int N, ldx, ldy;
-  int ldw;     // K stride of a packed weight row: Cin rounded up to 32 elements, so every row starts on a 64-byte boundary
-  int M;       // pixels per phase = N*Qh*Qw
-  int mtiles;  // tiles per phase
-  int accumulate;
-};
-// OUT32: the epilogue stores fp32 regardless of T (used by the classifier head, whose logits must not be rounded to bf16)
 
 constexpr int BM = 128, BN = 128;
 // staging modes (runtime switch "igemm_mode", A/B-able in one process):
@@ -473,6 +459,7 @@ __global__ __launch_bounds__(256) void tiny_gemm_kernel(const IgemmParams p) {
 }
 
 static int g_igemm_mode = 2;
+static int g_igemm256 = 1;   // 0: never, 1: where the planner expects it to win, 2: whenever eligible (bf16, bf16 output)
 
 template <typename T, bool OUT32, int MODE>
 static int launch_igemm2(const IgemmParams& p, hipStream_t st) {
@@ -496,6 +483,17 @@ static int launch_igemm(const IgemmParams& p, hipStream_t st) {
   if (g_igemm_mode == 2) return launch_igemm2<T, OUT32, 2>(p, st);
   if (g_igemm_mode == 1) return launch_igemm2<T, OUT32, 1>(p, st);
   return launch_igemm2<T, OUT32, 0>(p, st);
+}
+
+// Planner for the tile shape.  Measured (scripts/gemm256_bench.py): one round of 256 x 256 tiles, one per CU, takes as long as
+// one round of 128 x 128 tiles, three per CU -- for 4/3 of the work.  So the 256-tile kernel is chosen when it needs strictly
+// fewer rounds; on a tie, and whenever everything fits one round, the small tile (more workgroups, finer tail) stays.
+static int g_rel256 = 100;   // cost of a 256-tile round relative to a 128-tile round, in percent (tuning switch)
+static bool igemm256_wins(const IgemmParams& p) {
+  const long t128 = (long)cdiv(p.g.Cout, BN) * p.mtiles * p.g.os * p.g.os;
+  const long t256 = igemm256_tiles(p);
+  const long r128 = cdiv(t128, 768), r256 = cdiv(t256, 256);
+  return r256 * g_rel256 < r128 * 100;
 }
 
 static int check_view(const void* ptr, int ld, int c, int dtype, const char* what) {
@@ -530,6 +528,9 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
     else hipLaunchKernelGGL(tiny_gemm_kernel<float>, dim3(cdiv(p.g.Cout, 4)), dim3(256), 0, st, p);
     DC_CHECK_LAUNCH();
     return 0;
+  }
+  if (d->dtype == DC_BF16 && !out32 && g_igemm256 != 0) {
+    if (g_igemm256 == 2 || igemm256_wins(p)) return launch_igemm256(p, st);
   }
   if (d->dtype == DC_BF16) return out32 ? launch_igemm<bf16, true>(p, st) : launch_igemm<bf16, false>(p, st);
   return launch_igemm<float, false>(p, st);
@@ -668,6 +669,8 @@ extern "C" int dc_set_option(const char* name, int value) {
     g_igemm_mode = value;
     return 0;
   }
+  if (name != nullptr && strcmp(name, "igemm256") == 0) { g_igemm256 = value; return 0; }
+  if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }
   if (name != nullptr && strcmp(name, "wgrad_target_blocks") == 0) return dc_wgrad_set_target_blocks(value);
   if (name != nullptr && strcmp(name, "wgrad_mode") == 0) return dc_wgrad_set_mode(value);
   if (name != nullptr && dc_dw_set_option(name, value) == 0) return 0;
