@@ -485,15 +485,20 @@ static int launch_igemm(const IgemmParams& p, hipStream_t st) {
   return launch_igemm2<T, OUT32, 0>(p, st);
 }
 
-// Planner for the tile shape.  Measured (scripts/gemm256_bench.py): one round of 256 x 256 tiles, one per CU, takes as long as
-// one round of 128 x 128 tiles, three per CU -- for 4/3 of the work.  So the 256-tile kernel is chosen when it needs strictly
-// fewer rounds; on a tie, and whenever everything fits one round, the small tile (more workgroups, finer tail) stays.
-static int g_rel256 = 100;   // cost of a 256-tile round relative to a 128-tile round, in percent (tuning switch)
+// Planner for the tile shape.  The 128-tile kernel keeps 3 workgroups per CU (768 slots), the 256-tile kernel one (256 slots).
+// Measured per ROUND (scripts/gemm256_bench.py): a 256-tile round costs 0.83-0.93 of a 128-tile round when the K loop is long
+// (>= 64 steps of 32), about the same at 20-60 steps (the 728-channel layers) and 1.1-1.2 when it is short (its prologue and
+// 132 KiB epilogue are not hidden by a co-resident workgroup) -- for 4/3 of the work per round.  When both fit one round the
+// small tile (finer tail, three workgroups hiding each other's latencies) keeps the layer unless the K loop is long.
+static int g_rel256 = 0;   // 0: model below; otherwise cost of a 256-tile round in percent of a 128-tile round (tuning switch)
 static bool igemm256_wins(const IgemmParams& p) {
   const long t128 = (long)cdiv(p.g.Cout, BN) * p.mtiles * p.g.os * p.g.os;
   const long t256 = igemm256_tiles(p);
   const long r128 = cdiv(t128, 768), r256 = cdiv(t256, 256);
-  return r256 * g_rel256 < r128 * 100;
+  const int steps = cdiv(p.g.Cin, 32) * (p.g.ntaps / (p.g.os * p.g.os) > 0 ? p.g.ntaps / (p.g.os * p.g.os) : 1);   // average over phases
+  if (r128 == 1 && r256 == 1 && steps < 64) return false;
+  const int rel = g_rel256 > 0 ? g_rel256 : steps >= 64 ? 90 : steps >= 20 ? 97 : 115;
+  return r256 * rel < r128 * 100;
 }
 
 static int check_view(const void* ptr, int ld, int c, int dtype, const char* what) {

@@ -5,25 +5,21 @@
 // (~33 B/clk) while its MFMA pipes are busy half of that time: the loop is bound by the global->LDS fill, and the bytes to
 // fill per MFMA fall with the tile edge.  A 256 x 256 tile needs half the operand bytes per flop.
 //
-//   waves     8 = 2 pixel halves (the two "groups") x 4 channel quarters; a wave owns 128 pixels x 64 channels
+//   waves     8 = 2 pixel halves x 4 channel quarters; a wave owns 128 pixels x 64 channels
 //             (8 x 4 MFMA tiles of 16 x 16, 128 accumulator registers), so 12 ds_read_b128 feed 32 MFMAs
 //   K step    32 (64-byte rows, the XOR swizzle of igemm.hip); ring of 4 stages x (16 KiB weights + 16 KiB pixels) = 128 KiB
-//   schedule  per stage and wave four segments separated by workgroup barriers:
-//               L0  read 4 weight + 4 pixel fragments of stage s; start the LDS-DMA of the WEIGHT half of stage s+3
-//               M0  16 MFMAs (s_setprio 1)
-//               L1  read the other 4 pixel fragments; start the PIXEL half of stage s+3; s_waitcnt vmcnt(8): stage s+1 landed
-//               M1  16 MFMAs
-//             Group 1 runs one barrier behind group 0 (an extra barrier before its loop, one after group 0's), so on every SIMD
-//             one wave is in an M segment while its partner wave is in an L segment: the MFMA pipe and the LDS/DMA issue
-//             alternate instead of colliding.
-//   hazards   a stage is read one segment after the barrier that follows every wave's vmcnt for it (RAW); the weight half of
-//             ring slot (s+3)%4 is overwritten in L0(s), two barriers after its last reader retired its reads (all of
-//             them in L0(s-1)); the pixel half in L1(s), two barriers after the trailing group's L1(s-1) reads were retired
-//             by the lgkmcnt(0) of its M1(s-1) (WAR).  Past the last stage the DMA slots are filled from the zero page so that
-//             the vmcnt arithmetic is the same in every iteration.
+//   schedule  software-pipelined, ONE workgroup barrier per stage (see the loop): every ds_read and LDS-DMA issue sits in the
+//             shadow of the 32 MFMAs of the stage, so the two waves of a SIMD stream MFMAs back to back.  (A first version
+//             alternated load and MFMA segments between two staggered wave groups with four barriers per stage: stamps
+//             showed ~370-470-cycle load segments against 330-cycle MFMA segments, 54 % MFMA duty; this form reads the
+//             next operands while the current ones are multiplied.)
+//   hazards   RAW/WAR argument at the loop.  Past the last stage the DMA slots are filled from the zero page so that the vmcnt
+//             arithmetic is the same in every iteration.
 //   epilogue  as igemm.hip: accumulators -> LDS C tile (256 rows x 528 B) -> coalesced 16-byte stores, optional bias /
 //             accumulate, BatchNorm partial sums of the stored values, one slab row per 128-pixel half (same slab shape as the
 //             128-tile kernel, so the two are interchangeable per layer).
+#include <type_traits>
+
 #include "igemm.h"
 
 namespace dc {
@@ -46,6 +42,16 @@ static __device__ __attribute__((aligned(256))) unsigned char zero_page256[256];
 __device__ inline const void* zero_page256_ptr(const IgemmParams& p) { return p.zero_page; }
 typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// Diagnostic build only (-DDC_STAMPS): per-segment cycle sums of the K loop for one wave of each group (scripts/igemm_stamps.py).
+#ifdef DC_STAMPS
+__device__ unsigned long long* dc_stamp_buf256 = nullptr;
+#define SEG_T() __builtin_amdgcn_s_memtime()
+#define SEG_ADD(k, t0, t1) seg[k] += (t1) - (t0)
+#else
+#define SEG_T() 0ull
+#define SEG_ADD(k, t0, t1)
+#endif
 
 __device__ inline int swz64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 1) & 3)) << 4); }
 
@@ -171,56 +177,107 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
     issue_B(itap, ikc, q, live);
     advance();
   }
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage 0 has landed (stages 1, 2 = 8 instructions stay in flight)
   __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
 
-  for (int s = 0; s < steps; ++s) {
-    const char* wa = smem + (s & (NSTAGE - 1)) * STAGE;
+  // Software-pipelined loop, ONE barrier per stage.  All LDS reads and LDS-DMA issues sit in the shadow of MFMAs:
+  //   M0(s)  fb2 <- pixel blocks 4..7 of stage s;  DMA weight half of stage s+3;  16 MFMAs on (fa, fb)
+  //          lgkmcnt(0) (every read of stage s-1 and the fb2 reads retired), vmcnt(6) (stage s+1 landed), barrier
+  //   M1(s)  fb <- pixel blocks 0..3 of stage s+1;  DMA pixel half of stage s+3;  16 MFMAs on (fa, fb2), each weight
+  //          fragment fa[i] re-read from stage s+1 right after its last use
+  // RAW: stage s+1 is read only after the barrier that follows every wave's vmcnt for it.  WAR: slot (s+3)%4 held stage s-1,
+  // whose last reads (fb2 in M0(s-1)) every wave retired before the barrier of stage s-1; the first DMA into it is issued after
+  // that barrier.  vmcnt(6): at the wait the queue holds stages s+1 (4), s+2 (4) and the weight half of s+3 (2).
+  vec16 fa[4], fb[4], fb2[4];
+  {
+    const char* wa = smem;
     const char* xb = wa + OPER;
-    const int nslot = (s + NSTAGE - 1) & (NSTAGE - 1);
-    const bool live = s + NSTAGE - 1 < steps;
-    vec16 fa[4], fb[4], fb2[4];
-    // ---- L0
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const vec16*>(wa + swz64(wc * 64 + i * 16 + fr, fg));
 #pragma unroll
     for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const vec16*>(xb + swz64(grp * 128 + j * 16 + fr, fg));
-    issue_A(itap, ikc, nslot, live);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- M0
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- L1
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fb2[j] = *reinterpret_cast<const vec16*>(xb + swz64(grp * 128 + (4 + j) * 16 + fr, fg));
-    issue_B(itap, ikc, nslot, live);
-    advance();
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage s+1 has landed (stages s+2, s+3 = 8 instructions stay in flight)
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- M1
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb2[j]), acc[i][4 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups
+#ifdef DC_STAMPS
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long t_loop0 = SEG_T();
+#endif
+  // The two waves of a SIMD (w and w+4, i.e. the two pixel halves) run the halves of every segment in opposite order: while
+  // one issues its reads and LDS-DMAs (which hold a wave's issue for 60-185 cycles apiece) the other issues MFMAs.  The
+  // whole loop is instantiated twice (a branch inside the loop body made the register allocator spill).
+  auto k_loop = [&](auto loads_first_tag) {
+    constexpr bool LOADS_FIRST = decltype(loads_first_tag)::value;
+    for (int s = 0; s < steps; ++s) {
+      [[maybe_unused]] const unsigned long long t0 = SEG_T();
+      const char* xb = smem + (s & (NSTAGE - 1)) * STAGE + OPER;
+      const char* wa1 = smem + ((s + 1) & (NSTAGE - 1)) * STAGE;
+      const char* xb1 = wa1 + OPER;
+      const int nslot = (s + NSTAGE - 1) & (NSTAGE - 1);
+      const bool live = s + NSTAGE - 1 < steps;
+      // ---- M0
+      if constexpr (LOADS_FIRST) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb2[j] = *reinterpret_cast<const vec16*>(xb + swz64(grp * 128 + (4 + j) * 16 + fr, fg));
+        issue_A(itap, ikc, nslot, live);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (!LOADS_FIRST) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb2[j] = *reinterpret_cast<const vec16*>(xb + swz64(grp * 128 + (4 + j) * 16 + fr, fg));
+        issue_A(itap, ikc, nslot, live);
+      }
+      [[maybe_unused]] const unsigned long long t1 = SEG_T();
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      [[maybe_unused]] const unsigned long long t2 = SEG_T();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      [[maybe_unused]] const unsigned long long t3 = SEG_T();
+      // ---- M1
+      if constexpr (LOADS_FIRST) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const vec16*>(xb1 + swz64(grp * 128 + j * 16 + fr, fg));
+        issue_B(itap, ikc, nslot, live);
+        advance();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb2[j]), acc[i][4 + j], 0, 0, 0);
+        fa[i] = *reinterpret_cast<const vec16*>(wa1 + swz64(wc * 64 + i * 16 + fr, fg));
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (!LOADS_FIRST) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const vec16*>(xb1 + swz64(grp * 128 + j * 16 + fr, fg));
+        issue_B(itap, ikc, nslot, live);
+        advance();
+      }
+      [[maybe_unused]] const unsigned long long t4 = SEG_T();
+      SEG_ADD(0, t0, t1); SEG_ADD(1, t1, t2); SEG_ADD(2, t2, t3); SEG_ADD(3, t3, t4);
+    }
+  };
+  if (grp == 0) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
+#ifdef DC_STAMPS
+  if (dc_stamp_buf256 != nullptr && lane == 0 && wc == 0) {
+    unsigned long long* o = dc_stamp_buf256 + ((size_t)blockIdx.x * 2 + grp) * 8;
+    for (int k = 0; k < 6; ++k) o[k] = seg[k];
+    o[6] = SEG_T() - t_loop0;
+    o[7] = (unsigned long long)steps;
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the zero-page fills of the last three slots
   __builtin_amdgcn_s_barrier();
 
@@ -320,6 +377,13 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
 }
 
 }  // namespace
+
+#ifdef DC_STAMPS
+extern "C" int dc_debug_stamp_buf256(void* buf) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(dc_stamp_buf256), &buf, sizeof(buf));
+  return e == hipSuccess ? 0 : dc_set_error(e, __FILE__, __LINE__);
+}
+#endif
 
 int launch_igemm256(const IgemmParams& p_in, hipStream_t st) {
   const size_t lds = (size_t)MAIN_BYTES + 128;

@@ -114,6 +114,11 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # DEEPCAM_HIP_OPTIONS="igemm256=0,dw_tile=1": tuning switches of dc_set_option for A/B runs of whole programs
+    for item in filter(None, os.environ.get("DEEPCAM_HIP_OPTIONS", "").split(",")):
+        key, _, val = item.partition("=")
+        if lib.dc_set_option(key.strip().encode(), int(val)) != 0:
+            raise DeepcamHipError(f"DEEPCAM_HIP_OPTIONS: {lib.dc_last_error().decode()}")
     return lib
 
 

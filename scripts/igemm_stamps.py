@@ -36,3 +36,22 @@ for i, nme in enumerate(names):
     print(f"  {nme:32s} mean {d.mean():9.0f} cyc  ({100 * d.mean() / (s[:, 6] - s[:, 1]).mean():5.1f} %)   p90 {np.percentile(d, 90):9.0f}")
 hist, edges = np.histogram(start_us, bins=12)
 print("start-time histogram (us):", " ".join(f"{edges[i]:.0f}:{hist[i]}" for i in range(len(hist))))
+
+# ---- the 256 x 256 eight-wave kernel: per-segment cycle sums of the K loop (wave 0 of each group)
+if hasattr(lib, "dc_debug_stamp_buf256"):
+    L.call("dc_set_option", b"igemm256", 2)
+    nblk2 = ((cout + 255) // 256) * ((N * H * W + 255) // 256)
+    buf2 = torch.zeros(nblk2 * 16, dtype=torch.int64, device=dev)
+    for _ in range(5): run()
+    torch.cuda.synchronize()
+    assert lib.dc_debug_stamp_buf256(C.c_void_p(buf2.data_ptr())) == 0
+    e0.record(); run(); e1.record(); torch.cuda.synchronize()
+    s2 = buf2.cpu().numpy().reshape(nblk2, 2, 8).astype(np.float64)
+    print(f"256-tile kernel: {nblk2} workgroups, kernel {e0.elapsed_time(e1) * 1e3:.1f} us (stamped launch)")
+    segn = ["M0: 4 ds_read + 2 LDS-DMA + 16 MFMA issue", "wait vmcnt(6) lgkmcnt(0)", "barrier", "M1: 8 ds_read + 2 LDS-DMA + 16 MFMA issue", "-", "-"]
+    for gidx in (0, 1):
+        st_ = s2[:, gidx, 7].mean()
+        print(f"  group {gidx}: {st_:.0f} stages, loop {s2[:, gidx, 6].mean() / st_:.0f} cycles per stage")
+        for k in range(6):
+            print(f"      {segn[k]:52s} {s2[:, gidx, k].mean() / st_:7.0f} cyc")
+    L.call("dc_set_option", b"igemm256", 1)
