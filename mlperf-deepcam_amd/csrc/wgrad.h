@@ -1,0 +1,23 @@
+// Shared by the weight-gradient kernels (wgrad.hip: 128 x 128 tile, 4 waves; wgrad256.hip: 256 x 256 tile, 8 waves).
+#pragma once
+#include "conv_geom.h"
+
+namespace dc {
+
+struct WgradParams {
+  const void* x;   // gathered operand (forward input), channels -> ci
+  const void* dy;  // output-side operand, channels -> co
+  float* slab;     // [splits][taps][Co][Ci]
+  GatherGeom g;    // forward geometry: Cin = ci extent, Cout = co extent
+  int N, ldx, lddy;
+  int M;           // pixels per phase
+  int splits;
+  int chunk;       // pixels per split (multiple of BP)
+};
+
+// 256 x 256 tile kernel (bf16 only): split plan and launch.  The slab layout [split][tap][Co][Ci] is the same as the small
+// kernel's, so wgrad_reduce_kernel serves both.
+void wgrad256_plan(const GatherGeom& g, long M, int* splits, int* chunk);
+int launch_wgrad256(const WgradParams& p, hipStream_t st);
+
+}  // namespace dc

@@ -8,19 +8,9 @@
 // go to a slab with plain stores and a second kernel reduces them in a fixed order straight into the PyTorch
 // master layout of the gradient -- deterministic, no float atomics.
 #include "conv_geom.h"
+#include "wgrad.h"
 
 namespace dc {
-
-struct WgradParams {
-  const void* x;   // gathered operand (forward input), channels -> ci
-  const void* dy;  // output-side operand, channels -> co
-  float* slab;     // [splits][taps][Co][Ci]
-  GatherGeom g;    // forward geometry: Cin = ci extent, Cout = co extent
-  int N, ldx, lddy;
-  int M;           // pixels per phase
-  int splits;
-  int chunk;       // pixels per split (multiple of BP)
-};
 
 template <typename T>
 struct WgTraits;
@@ -415,6 +405,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 static int g_wgrad_mode = 1;               // 1 = LDS-DMA 3-stage kernel, 0 = register-staged kernel
+static int g_wgrad256 = 1;                 // 0: 128-tile kernel only, 1: planner, 2: 256-tile kernel wherever eligible (bf16)
 static int g_wgrad_target_blocks = 768;    // resident capacity: 256 CUs x 3 workgroups (48 KiB LDS, 146 registers)
 
 static void plan_splits(const GatherGeom& g, long M, int BP, int* splits, int* chunk) {
@@ -439,6 +430,20 @@ extern "C" int dc_wgrad_set_mode(int m) {
   return 0;
 }
 
+extern "C" int dc_wgrad_set_256(int m) {
+  g_wgrad256 = m;
+  return 0;
+}
+
+// Tile-shape planner (bf16): the 256-tile kernel when both channel extents fill at least most of a 256 tile.
+static bool wgrad256_wins(const GatherGeom& g) {
+  if (g_wgrad256 == 2) return true;
+  if (g_wgrad256 == 0) return false;
+  const long pad256 = (long)cdiv(g.Cin, 256) * 256 * cdiv(g.Cout, 256) * 256;
+  const long pad128 = (long)cdiv(g.Cin, 128) * 128 * cdiv(g.Cout, 128) * 128;
+  return pad256 * 100 <= pad128 * 115;   // at most 15 % more padded work than the small tile
+}
+
 extern "C" int dc_wgrad_set_target_blocks(int n) {
   if (n > 0) g_wgrad_target_blocks = n;
   return 0;
@@ -449,6 +454,11 @@ extern "C" size_t dc_conv_wgrad_workspace(const dc_conv_desc* d, int N, int Hi, 
   if (d == nullptr || !build_geom(*d, Hi, Wi, kFwd, &g)) return 0;
   int splits, chunk;
   plan_splits(g, (long)N * g.Qh * g.Qw, d->dtype == DC_BF16 ? 64 : 32, &splits, &chunk);
+  if (d->dtype == DC_BF16) {   // either tile shape may serve the layer: size for the larger plan
+    int s2, c2;
+    wgrad256_plan(g, (long)N * g.Qh * g.Qw, &s2, &c2);
+    if (s2 > splits) splits = s2;
+  }
   return (size_t)splits * g.ntaps * g.Cout * g.Cin * sizeof(float);
 }
 
@@ -462,14 +472,18 @@ extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const
   const long M = (long)N * p.g.Qh * p.g.Qw;
   DC_REQUIRE(M < (1L << 31) - 256, "dc_conv_wgrad: too many pixels for 32-bit indexing");
   const int BP = d->dtype == DC_BF16 ? 64 : 32;    // chunk granularity (a multiple of both kernels' pixels per stage)
-  plan_splits(p.g, M, BP, &p.splits, &p.chunk);
+  const bool big = d->dtype == DC_BF16 && wgrad256_wins(p.g);
+  if (big) wgrad256_plan(p.g, M, &p.splits, &p.chunk);
+  else plan_splits(p.g, M, BP, &p.splits, &p.chunk);
   const size_t need = (size_t)p.splits * p.g.ntaps * p.g.Cout * p.g.Cin * sizeof(float);
   DC_REQUIRE(workspace_bytes >= need, "dc_conv_wgrad: workspace too small");
   p.x = x; p.dy = dy; p.slab = (float*)workspace;
   p.N = N; p.ldx = ldx; p.lddy = lddy; p.M = (int)M;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(p.g.Cin, 128) * cdiv(p.g.Cout, 128) * p.g.ntaps * p.splits);
-  if (g_wgrad_mode == 1) {
+  if (big) {
+    if (int e = launch_wgrad256(p, st)) return e;
+  } else if (g_wgrad_mode == 1) {
     const size_t lds = 3 * 2 * 8192;
     static bool once_b = false, once_f = false;
     if (d->dtype == DC_BF16) {

@@ -101,6 +101,16 @@ def test_conv_256_tile_kernel(case):
         L.call("dc_set_option", b"igemm256", 1)
 
 
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_256_tile_wgrad_kernel(case):
+    """The eight-wave 256 x 256 weight-gradient kernel, forced on every layer, passes the same checks."""
+    L.call("dc_set_option", b"wgrad256", 2)
+    try:
+        test_conv_fwd_dgrad_wgrad(case, torch.bfloat16)
+    finally:
+        L.call("dc_set_option", b"wgrad256", 1)
+
+
 def conv_ref(x, w, bias, k, stride, pad, dil, transposed):
     if transposed:
         return F.conv_transpose2d(x, w, bias, 2, 1, 1)
