@@ -71,8 +71,9 @@ def cpu_baseline(local_batch, H, W, budget_s=30.0):
 
 class KernelTimer:
     """HIP-event timing of every launch of the two MFMA kernel families on the stream they run on:
-       igemm  dc::igemm_kernel<T>  (dc_conv_fwd + dc_conv_dgrad: dense conv forward and data gradient)
-       wgrad  dc::wgrad_kernel<T>  (+ its slab reduction; dc_conv_wgrad: dense conv weight gradient)"""
+       igemm  dc::igemm256_kernel / dc::igemm_kernel<T> / dc::tiny_gemm_kernel<T>  (dc_conv_fwd + dc_conv_dgrad: dense conv forward
+              and data gradient; the library's planner picks the tile shape per layer)
+       wgrad  dc::wgrad256_kernel / dc::wgrad_dma_kernel<T>  (+ the slab reduction; dc_conv_wgrad: dense conv weight gradient)"""
 
     FAMILY = {"dc_conv_fwd": "igemm", "dc_conv_dgrad": "igemm", "dc_conv_wgrad": "wgrad"}
 
@@ -80,6 +81,7 @@ class KernelTimer:
         self.L = lib_module
         self.events = {"igemm": [], "wgrad": []}
         self.flops = {"igemm": 0.0, "wgrad": 0.0}
+        self.bytes = {"igemm": 0.0, "wgrad": 0.0}        # algorithmic: input + output + weights, each touched once
         self._orig = lib_module.call
 
     def __enter__(self):
@@ -94,10 +96,14 @@ class KernelTimer:
             k = 3 if d.transposed else d.k
             if d.transposed:
                 macs = N * Hi * Wi * d.cin * d.cout * 9
+                Ho, Wo = 2 * Hi, 2 * Wi
             else:
                 Ho = (Hi + 2 * d.pad - d.dil * (k - 1) - 1) // d.stride + 1
                 Wo = (Wi + 2 * d.pad - d.dil * (k - 1) - 1) // d.stride + 1
                 macs = N * Ho * Wo * d.cin * d.cout * k * k
+            esz = 2 if d.dtype == timer.L.DC_BF16 else 4
+            wbytes = k * k * d.cin * d.cout * (4 if fam == "wgrad" else esz)        # the weight gradient leaves as fp32
+            timer.bytes[fam] += (N * Hi * Wi * d.cin + N * Ho * Wo * d.cout) * esz + wbytes
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             timer._orig(name, *args)
@@ -115,7 +121,7 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for fam, evs in self.events.items():
-            out[fam] = (self.flops[fam], sum(a.elapsed_time(b) for a, b in evs) * 1e-3, len(evs))
+            out[fam] = (self.flops[fam], sum(a.elapsed_time(b) for a, b in evs) * 1e-3, len(evs), self.bytes[fam])
         return out
 
 
@@ -219,14 +225,16 @@ def main():
     barrier()
     if rank == 0:
         peak = PEAK[a.dtype]
-        names = {"igemm": f"dc::igemm_kernel<{a.dtype}> (dense conv forward + data gradient, gather-form implicit GEMM)",
-                 "wgrad": f"dc::wgrad_kernel<{a.dtype}> + dc::wgrad_reduce_kernel (dense conv weight gradient)"}
+        names = {"igemm": f"dc::igemm256_kernel + dc::igemm_kernel<{a.dtype}> (dense conv forward + data gradient: gather-form implicit "
+                          "GEMM, 256x256 eight-wave or 128x128 four-wave tile per layer)",
+                 "wgrad": f"dc::wgrad256_kernel + dc::wgrad_dma_kernel<{a.dtype}> + dc::wgrad_reduce_kernel (dense conv weight gradient)"}
         dom = max(fams, key=lambda f: fams[f][1])
         def entry(f, src=None):
-            fl, secs, n = (src or fams)[f]
+            fl, secs, n, nbytes = (src or fams)[f]
             ach = fl / secs if secs > 0 else 0.0
             return {"kernel": names[f], "achieved": round(ach / 1e12, 2), "frac": round(ach / peak, 4), "launches_timed": n,
-                    "avg_launch_us": round(secs / max(n, 1) * 1e6, 2), "ms_per_step": round(secs / min(a.steps, 3) * 1e3, 3)}
+                    "avg_launch_us": round(secs / max(n, 1) * 1e6, 2), "ms_per_step": round(secs / min(a.steps, 3) * 1e3, 3),
+                    "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 2), "algorithmic_bytes_per_launch": round(nbytes / max(n, 1))}
         e = entry(dom)
         # HBM bytes per launch come from PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs of this very command) that
         # cannot be taken from inside the process; the committed measurement is attached when it matches this configuration.
@@ -239,7 +247,8 @@ def main():
             traffic = None
         roof = {"bound": "mfma", "achieved": e["achieved"], "peak": peak / 1e12, "unit": "TFLOP/s", "frac": e["frac"], "traffic": traffic,
                 "kernel": e["kernel"], "launches_timed": e["launches_timed"], "avg_launch_us": e["avg_launch_us"],
-                "ms_per_step": e["ms_per_step"], "other_mfma_kernel": entry([f for f in fams if f != dom][0]),
+                "ms_per_step": e["ms_per_step"], "algorithmic_gflop_per_launch": e["algorithmic_gflop_per_launch"],
+                "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"], "other_mfma_kernel": entry([f for f in fams if f != dom][0]),
                 "note": "achieved/frac are measured as in the timed region, i.e. while weight-gradient kernels run concurrently on the "
                         "side stream; 'standalone' repeats the measurement with one kernel on the GPU at a time",
                 "standalone": {f: {k: v for k, v in entry(f, fams_alone).items() if k != "kernel"} for f in fams_alone},

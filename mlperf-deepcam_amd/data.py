@@ -142,7 +142,8 @@ class InputPipeline:
     `depth` slots (>= 2) bound the memory; a slot is recycled only after the compute stream has passed the point where its
     tensors were last used (the consumer calls release(), or simply asks for the next batch)."""
 
-    def __init__(self, dataset, batch_size: int, dtype=torch.bfloat16, device=None, depth: int = 3, drop_last: bool = True):
+    def __init__(self, dataset, batch_size: int, dtype=torch.bfloat16, device=None, depth: int = 3, drop_last: bool = True,
+                 workers: int = 4):
         if not torch.cuda.is_available():
             raise L.DeepcamHipError("InputPipeline needs a HIP device")
         self.ds, self.B, self.dtype = dataset, batch_size, dtype
@@ -159,11 +160,16 @@ class InputPipeline:
         self.channels = None if ident else torch.tensor(list(dataset.channels), dtype=torch.int32, device=self.device)
         self.nbatches = len(dataset) // batch_size if drop_last else -(-len(dataset) // batch_size)
         self._prev: Optional[_Slot] = None
+        # one 56.6 MB sample is ~10 ms of host copy/decoding: a single reader caps the pipeline near 100 samples/s, below the
+        # train step's rate, so the samples of a batch are read by `workers` threads (numpy / h5py release the GIL while copying)
+        self.workers = max(1, int(workers))
 
     def __len__(self):
         return self.nbatches
 
     def _reader(self, free_q: "queue.Queue", full_q: "queue.Queue"):
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(self.workers) if self.workers > 1 else None
         try:
             for b in range(self.nbatches):
                 slot = free_q.get()
@@ -171,11 +177,17 @@ class InputPipeline:
                     return
                 slot.consumed.synchronize()                       # host wait: the GPU is done with this slot's tensors
                 dn, ln = slot.data_host.numpy(), slot.label_host.numpy()
-                slot.names = [self.ds.read_into(b * self.B + j, dn[j], ln[j]) for j in range(self.B)]
+                if pool is None:
+                    slot.names = [self.ds.read_into(b * self.B + j, dn[j], ln[j]) for j in range(self.B)]
+                else:
+                    slot.names = list(pool.map(lambda j: self.ds.read_into(b * self.B + j, dn[j], ln[j]), range(self.B)))
                 full_q.put(slot)
             full_q.put(None)
         except BaseException as e:  # surface reader failures in the consumer
             full_q.put(e)
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=False)
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, List[str]]]:
         free_q: "queue.Queue" = queue.Queue()
