@@ -10,8 +10,9 @@ HWC sample is copied as it lies in the file into a pinned staging buffer, DMA'd 
 (dc_input_normalize_hwc) selects the channels, applies scale*(x-shift) and writes the NHWC activation tensor the stem
 consumes: the training step then contains no layout pass at all.  Reading is double-buffered behind the compute stream.
 
-h5py is not available in every image: the HDF5 decoding is gated at run time (CamDataset raises a clear error without
-it); file listing / sharding / the GPU half are independent of it and are what the tests exercise (SyntheticHWC source).
+h5py is not available in every image: CamDataset decodes with h5py when it is installed and otherwise through `h5lite`, a ctypes
+binding of the HDF5 C library (contiguous fp32 payloads are pread() straight into the pinned staging buffer, several files in
+parallel).  The tests write small CAM5-shaped files with h5lite and read them back through the whole pipeline.
 """
 from __future__ import annotations
 
@@ -50,27 +51,46 @@ def shard_files(all_files: Sequence[str], comm_size: int, comm_rank: int, allow_
     return list(mine), global_size
 
 
+def _h5_backend():
+    """h5py when it is installed, else the ctypes binding of libhdf5 (h5lite); RuntimeError when neither is usable."""
+    try:
+        import h5py
+        return "h5py", h5py
+    except ImportError:
+        from . import h5lite
+        if h5lite.available():
+            return "h5lite", h5lite
+    raise RuntimeError("CamDataset needs h5py or an HDF5 C library (libhdf5.so; set DEEPCAM_HDF5_LIB) to decode the CAM5 files; "
+                       "neither was found (data.SyntheticHWC runs without)")
+
+
 class CamDataset:
-    """HDF5-backed source.  read(i) -> (data float32 [H, W, Cfile] as stored, label [H, W], filename)."""
+    """HDF5-backed source (cam_hdf5_dataset.py:36-131).  read_into(i, data, label) fills data float32 [H, W, Cfile] exactly as
+    stored and label int64 [H, W]; channel selection and normalisation happen on the device."""
 
     def __init__(self, source: str, statsfile: str, channels: Sequence[int], allow_uneven_distribution: bool = False,
                  shuffle: bool = False, preprocess: bool = True, comm_size: int = 1, comm_rank: int = 0, seed: int = 12345):
-        try:
-            import h5py
-        except ImportError:
-            raise RuntimeError("CamDataset needs h5py to decode the CAM5 files; this image has none "
-                               "(use data.SyntheticHWC, or install h5py where the data lives)") from None
-        self._h5 = h5py
+        self.backend, self._h5 = _h5_backend()
         self.channels = list(channels)
         all_files = [os.path.join(source, x) for x in os.listdir(source) if x.endswith(".h5")]
         self.files, self.global_size = shard_files(all_files, comm_size, comm_rank, allow_uneven_distribution, shuffle, seed)
         self.local_size = len(self.files)
-        with h5py.File(self.files[0], "r") as f:
-            self.data_shape = f["climate"]["data"].shape
-            self.label_shape = f["climate"]["labels_0"].shape
-        with h5py.File(statsfile, "r") as f:
-            shift = f["climate"]["minval"][self.channels]
-            scale = 1.0 / (f["climate"]["maxval"][self.channels] - shift)
+        if self.backend == "h5py":
+            with self._h5.File(self.files[0], "r") as f:
+                self.data_shape = tuple(f["climate"]["data"].shape)
+                self.label_shape = tuple(f["climate"]["labels_0"].shape)
+            with self._h5.File(statsfile, "r") as f:
+                minval, maxval = f["climate"]["minval"][...], f["climate"]["maxval"][...]
+        else:
+            with self._h5.File(self.files[0]) as f:
+                self.data_shape, self.label_shape = f.shape("climate/data"), f.shape("climate/labels_0")
+                self._label_dtype = f.dtype("climate/labels_0").newbyteorder("=")
+            with self._h5.File(statsfile) as f:
+                minval, maxval = f.read("climate/minval"), f.read("climate/maxval")
+        shift = np.asarray(minval)[self.channels]                                   # :96-98
+        scale = 1.0 / (np.asarray(maxval)[self.channels] - shift)
+        if not preprocess:                                                          # :100-102
+            shift, scale = np.zeros_like(shift), np.ones_like(scale)
         self.data_shift = np.asarray(shift, np.float32)
         self.data_scale = np.asarray(scale, np.float32)
         if comm_rank == 0:
@@ -80,9 +100,17 @@ class CamDataset:
         return self.local_size
 
     def read_into(self, i: int, data_out: np.ndarray, label_out: np.ndarray) -> str:
-        with self._h5.File(self.files[i], "r") as f:
-            f["climate/data"].read_direct(data_out)
-            label_out[...] = f["climate/labels_0"][...]
+        if self.backend == "h5py":
+            with self._h5.File(self.files[i], "r") as f:
+                f["climate/data"].read_direct(data_out)
+                label_out[...] = f["climate/labels_0"][...]
+        else:
+            with self._h5.File(self.files[i]) as f:
+                f.read_direct("climate/data", data_out)               # contiguous fp32: pread straight into the pinned buffer
+                if self._label_dtype == label_out.dtype:
+                    f.read_direct("climate/labels_0", label_out)
+                else:
+                    label_out[...] = f.read("climate/labels_0")
         return self.files[i]
 
 

@@ -4,8 +4,8 @@ Same command line as the reference (src/deepCam/train_hdf5_ddp.py:548-578, flag 
 same logging-frequency reductions (:398-414), validation averaging (:423-512: mean of per-sample IoUs at batch 1),
 checkpoint dictionary (:515-527: step, epoch, model with 'module.'-prefixed keys, optimizer) and ``:::MLLOG`` event keys
 (utils/mlperf_log_utils.py).  Out of scope by SURVEY section 8: W&B and Basemap plots (flags accepted, ignored).
-Input: data.InputPipeline over the HDF5 files when h5py is importable, or over
-synthetic HWC fields with ``--synthetic_samples N`` (this image has no h5py).
+Input: data.InputPipeline over the HDF5 files (decoded with h5py, or through the HDF5 C library when h5py is not installed:
+h5lite), or over synthetic HWC fields with ``--synthetic_samples N``.
 
 Extra flags (not in the reference): --wireup_method env|single, --dtype, --synthetic_samples, --height/--width, --max_steps.
 """

@@ -66,3 +66,30 @@ def test_training_through_the_pipeline_equals_the_nchw_path():
     # (the loss is a sum of per-block fp64 atomics: the last bit depends on arrival order; the weights must be bit-identical)
     assert losses[0][0] == pytest.approx(losses[1][0], rel=1e-12)
     assert torch.equal(losses[0][1], losses[1][1])
+
+
+def test_pipeline_over_real_hdf5_files_matches_host_normalisation(tmp_path):
+    """CAM5-shaped HDF5 files written and read through the HDF5 C library (no h5py), statistics from the dataset-preparation
+    tool, then the whole device path: staged batches equal what the reference's __getitem__ computes on the host."""
+    from mlperf_deepcam_amd import h5lite, prep
+    if not h5lite.available():
+        pytest.skip("no HDF5 C library in this image")
+    Hh, Ww, root = 16, 24, str(tmp_path / "train")
+    import os
+    os.makedirs(root)
+    rs = np.random.RandomState(5)
+    for i in range(5):
+        with h5lite.File(os.path.join(root, f"data-{i:02d}.h5"), "w") as f:
+            f.write("climate/data", (rs.rand(Hh, Ww, 16) * np.linspace(1, 300, 16) - 40.0).astype(np.float32))
+            f.write("climate/labels_0", rs.randint(0, 3, (Hh, Ww)).astype(np.int64))
+    stats = prep.summarize(str(tmp_path), workers=2)
+    channels = [0, 1, 2, 10]
+    ds = ddata.CamDataset(root, stats, channels, shuffle=True)
+    pipe = ddata.InputPipeline(ds, 2, dtype=torch.float32, depth=2, workers=2)
+    nb = 0
+    for b, (x, y, names) in enumerate(pipe):
+        xr, yr = _reference_batch(ds, 2 * b, 2)
+        assert torch.equal(x.cpu().permute(0, 3, 1, 2), xr) and torch.equal(y.cpu(), yr)
+        assert names == ds.files[2 * b:2 * b + 2]
+        nb += 1
+    assert nb == 2
