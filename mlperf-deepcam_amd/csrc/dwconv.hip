@@ -489,6 +489,8 @@ extern "C" int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int H
   hipStream_t st = (hipStream_t)stream;
   DC_REQUIRE((pscale == nullptr) == (pshift == nullptr), "dc_dwconv_fwd: pscale and pshift go together");
   if (stride == 1 && (dil == 1 || dil == 2)) return launch_dw_s1(dtype, dil, false, x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, C, st, pscale, pshift, prelu);
+  if (stride == 2 && dil == 1 && g_dw_tile && pscale == nullptr)
+    return launch_dw_tile_s2(dtype, 0, N, Hi, Wi, C, x, ldx, w, nullptr, 0, y, ldy, nullptr, nullptr, st);
   return dtype == DC_BF16 ? launch_dw<bf16, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st, pscale, pshift, prelu)
                           : launch_dw<float, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st, pscale, pshift, prelu);
 }
@@ -504,6 +506,8 @@ extern "C" int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int
   const int Ho = dw_out(Hi, stride, dil), Wo = dw_out(Wi, stride, dil);
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1 && (dil == 1 || dil == 2)) return launch_dw_s1(dtype, dil, true, dy, lddy, w, addend, ldadd, dx, lddx, N, Hi, Wi, C, st);
+  if (stride == 2 && dil == 1 && g_dw_tile)
+    return launch_dw_tile_s2(dtype, 1, N, Hi, Wi, C, dy, lddy, w, addend, ldadd, dx, lddx, nullptr, nullptr, st);
   // gather from dy [Ho,Wo] into dx [Hi,Wi]
   return dtype == DC_BF16 ? launch_dw<bf16, 1>(dy, lddy, w, addend, ldadd, dx, lddx, N, Ho, Wo, Hi, Wi, C, stride, dil, st)
                           : launch_dw<float, 1>(dy, lddy, w, addend, ldadd, dx, lddx, N, Ho, Wo, Hi, Wi, C, stride, dil, st);
@@ -518,6 +522,11 @@ extern "C" size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int st
   size_t bytes = (size_t)rows * 9 * C * sizeof(float);
   if (stride == 1) {
     const size_t tb = dw_tile_wgrad_workspace(C, N, Hi, Wi);
+    if (tb > bytes) bytes = tb;
+  } else {
+    long tiles = (long)N * cdiv(Ho, 4) * cdiv(Wo, 8);           // stride-2 tiled path: 4 x (8..32) output tiles, one slab row each at most
+    if (tiles > DWT_MAX_ROWS) tiles = DWT_MAX_ROWS;
+    const size_t tb = (size_t)tiles * 9 * C * sizeof(float);
     if (tb > bytes) bytes = tb;
   }
   return bytes;
@@ -539,6 +548,11 @@ extern "C" int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int
   const int cgw = dw_pick_cgw(C / kpv);
   if (stride == 1 && (dil == 1 || dil == 2) && g_dw_tile && pscale == nullptr)
     return launch_dw_tile_wgrad(dtype, dil, x, ldx, dy, lddy, (float*)workspace, grad_w, N, Hi, Wi, C, st);
+  if (stride == 2 && dil == 1 && g_dw_tile && pscale == nullptr) {
+    int trows = 0;
+    if (int e = launch_dw_tile_s2(dtype, 2, N, Hi, Wi, C, x, ldx, nullptr, dy, lddy, nullptr, 0, (float*)workspace, &trows, st)) return e;
+    return dw_tile_reduce((const float*)workspace, grad_w, trows, C, st);
+  }
   if (stride == 1 && (dil == 1 || dil == 2)) {
     const int nstrips = N * Hi * ((Wi + DW_PX - 1) / DW_PX);
     const int nsl = 256 / cgw;

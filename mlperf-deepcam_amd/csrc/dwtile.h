@@ -13,5 +13,10 @@ int launch_dw_tile_wgrad(int dtype, int dil, const void* x, int ldx, const void*
                          int H, int W, int C, hipStream_t st);
 size_t dw_tile_wgrad_workspace(int C, int N, int H, int W);
 void dw_tile_set_tpb(int v);
+int dw_tile_reduce(const float* slab, float* grad_w, int rows, int C, hipStream_t st);   // grad[c][t] = sum of slab rows (fp64, fixed order)
+
+// stride-2 kernels (dwtile_s2.hip).  mode 0 forward, 1 data gradient (p1 = addend or null), 2 weight-gradient rows into the slab
+int launch_dw_tile_s2(int dtype, int mode, int N, int Hi, int Wi, int C, const void* p0, int ld0, const float* wp, const void* p1, int ld1,
+                      void* out, int ldout, float* slab, int* rows_out, hipStream_t st);
 
 }  // namespace dc

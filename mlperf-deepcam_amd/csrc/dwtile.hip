@@ -14,10 +14,10 @@
 // TW = 8 / 16 / 32 pixels.
 #include "common.h"
 #include "dwtile.h"
+#include "dwtile_common.h"
 
 namespace dc {
 
-constexpr int DT_PX = 4;   // pixels per strip
 #ifndef DT_TH_VALUE
 #define DT_TH_VALUE 8
 #endif
@@ -39,12 +39,6 @@ static __device__ __attribute__((aligned(256))) unsigned char dwt_zero_page[256]
 typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
-// XCD-aware bijective remap of the 1-D grid (see igemm.hip), then tile id -> (channel block fastest, tx, ty, n)
-__device__ inline int xcd_remap(int bid, int nwg) {
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, slot = bid >> 3;
-  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-}
-
 template <typename T, int DIL, int CG>
 __device__ inline void stage_halo(char* smem, const T* __restrict__ in, int ldin, int n, int y0, int x0, int cg0, int ngroups, int H,
                                   int W) {
@@ -63,47 +57,6 @@ __device__ inline void stage_halo(char* smem, const T* __restrict__ in, int ldin
     const bool ok = gok && hp < K::HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     const void* src = ok ? (const void*)(base + ((size_t)iy * W + ix) * ldin) : (const void*)dwt_zero_page;
     __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(smem + (it * 256 + wv * 64) * 16), 16, 0, 0);
-  }
-}
-
-// A thread computes on HALF a channel group (8 bytes: 4 bf16 / 2 f32 channels): its nine taps then take 36 (18) registers
-// instead of 72, which is what decides the occupancy of these kernels; LDS is read with ds_read_b64 (same bytes per clock as
-// b128), global memory is still filled / written in full 512-byte runs per pixel.
-struct alignas(8) vec8 {
-  uint32_t w[2];
-};
-__device__ inline void unpack8(const vec8& v, float (&f)[2], float) {
-  f[0] = __uint_as_float(v.w[0]);
-  f[1] = __uint_as_float(v.w[1]);
-}
-__device__ inline void unpack8(const vec8& v, float (&f)[4], bf16) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    f[2 * i] = __uint_as_float(v.w[i] << 16);
-    f[2 * i + 1] = __uint_as_float(v.w[i] & 0xffff0000u);
-  }
-}
-__device__ inline void pack8(vec8& v, const float (&f)[2], float) {
-  v.w[0] = __float_as_uint(f[0]);
-  v.w[1] = __float_as_uint(f[1]);
-}
-__device__ inline void pack8(vec8& v, const float (&f)[4], bf16) {
-  v.w[0] = pack2_bf16(f[0], f[1]);
-  v.w[1] = pack2_bf16(f[2], f[3]);
-}
-
-template <int KH>
-__device__ inline void load_taps(const float* __restrict__ wp, int ch0, int C, bool flip, float (&wk)[9][KH]) {
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const float* src = wp + (size_t)(flip ? 8 - t : t) * C + ch0;
-    if constexpr (KH == 4) {
-      const float4 v = *reinterpret_cast<const float4*>(src);
-      wk[t][0] = v.x; wk[t][1] = v.y; wk[t][2] = v.z; wk[t][3] = v.w;
-    } else {
-      const float2 v = *reinterpret_cast<const float2*>(src);
-      wk[t][0] = v.x; wk[t][1] = v.y;
-    }
   }
 }
 
@@ -320,6 +273,12 @@ __global__ __launch_bounds__(256) void dwt_reduce_kernel(const float* __restrict
     const int tp = j / C, c = j % C;
     grad[(size_t)c * 9 + tp] = (float)s;
   }
+}
+
+int dw_tile_reduce(const float* slab, float* grad_w, int rows, int C, hipStream_t st) {
+  hipLaunchKernelGGL(dwt_reduce_kernel, dim3(cdiv(9 * C, 16)), dim3(256), 0, st, slab, grad_w, rows, C);
+  DC_CHECK_LAUNCH();
+  return 0;
 }
 
 static int g_dw_tpb = 0;   // tiles per workgroup of the weight gradient; 0 = planner

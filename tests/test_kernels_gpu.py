@@ -250,7 +250,9 @@ def test_pack_all_matches_per_layer_pack(dtype):
 
 DW_CASES = [("s1", 728, 1, 1, 2, 12, 10), ("s2", 128, 2, 1, 2, 16, 12), ("d2", 1024, 1, 2, 1, 10, 14), ("odd", 64, 2, 1, 1, 9, 11),
             # stride-1 tiled path with thin layers (16 / 8 channel groups -> 16 / 32 pixel wide tiles), several tiles, ragged edges
-            ("thin128", 128, 1, 1, 1, 17, 37), ("thin64", 64, 1, 1, 2, 9, 40), ("thin32d2", 32, 1, 2, 1, 11, 35)]
+            ("thin128", 128, 1, 1, 1, 17, 37), ("thin64", 64, 1, 1, 2, 9, 40), ("thin32d2", 32, 1, 2, 1, 11, 35),
+            # stride-2 tiled path: several tiles, ragged edges, odd extents, all three channel-group widths
+            ("s2_728", 728, 2, 1, 1, 22, 34), ("s2_256", 256, 2, 1, 2, 13, 41), ("s2_64", 64, 2, 1, 1, 18, 70)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])

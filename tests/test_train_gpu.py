@@ -68,5 +68,7 @@ def test_driver_trains_validates_saves_and_resumes(tmp_path):
 def test_driver_rejects_unknown_optimizer_and_missing_data(tmp_path):
     r = _run(["--wireup_method", "single", "--run_tag", "t", "--output_dir", str(tmp_path), "--optimizer", "SGD"])
     assert r.returncode != 0 and "invalid choice" in r.stderr
-    r = _run(["--wireup_method", "single", "--run_tag", "t", "--output_dir", str(tmp_path), "--local_batch_size", "2"])
-    assert r.returncode != 0 and "h5py" in r.stderr          # no data directory / no h5py in this image: a clear error, no fallback
+    r = _run(["--wireup_method", "single", "--run_tag", "t", "--output_dir", str(tmp_path), "--local_batch_size", "2",
+              "--data_dir_prefix", str(tmp_path / "no_such_data")])
+    # no data directory: a clear error (missing directory, or missing HDF5 support), never a silent fallback to synthetic data
+    assert r.returncode != 0 and ("No such file or directory" in r.stderr or "h5py" in r.stderr)
