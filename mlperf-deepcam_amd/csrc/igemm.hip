@@ -667,6 +667,7 @@ extern "C" int dc_pack_all(int dtype, const void* table_dev, int nentries, void*
 extern "C" int dc_wgrad_set_target_blocks(int n);
 extern "C" int dc_wgrad_set_mode(int m);
 extern "C" int dc_wgrad_set_256(int m);
+extern "C" int dc_wgrad_set_thin(int m);
 extern "C" int dc_dw_set_option(const char* name, int value);
 extern "C" int dc_bn_set_option(const char* name, int value);
 extern "C" int dc_set_option(const char* name, int value) {
@@ -680,6 +681,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "wgrad_target_blocks") == 0) return dc_wgrad_set_target_blocks(value);
   if (name != nullptr && strcmp(name, "wgrad_mode") == 0) return dc_wgrad_set_mode(value);
   if (name != nullptr && strcmp(name, "wgrad256") == 0) return dc_wgrad_set_256(value);
+  if (name != nullptr && strcmp(name, "thin_wgrad") == 0) return dc_wgrad_set_thin(value);
   if (name != nullptr && dc_dw_set_option(name, value) == 0) return 0;
   if (name != nullptr && dc_bn_set_option(name, value) == 0) return 0;
   return dc_fail("dc_set_option: unknown option", __FILE__, __LINE__);

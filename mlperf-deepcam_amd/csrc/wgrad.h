@@ -20,4 +20,9 @@ struct WgradParams {
 void wgrad256_plan(const GatherGeom& g, long M, int* splits, int* chunk);
 int launch_wgrad256(const WgradParams& p, hipStream_t st);
 
+// thinconv.hip: all nine taps of the 16->32 (stride 2) and 32->64 stem convolutions in one pass over x and dy
+bool thin_wgrad_eligible(const dc_conv_desc& d, int Hi, int Wi);
+int thin_wgrad_splits(const dc_conv_desc& d, int N, int Hi, int Wi);
+int launch_thin_wgrad(const dc_conv_desc& d, int N, int Hi, int Wi, const void* x, int ldx, const void* dy, int lddy, float* slab, hipStream_t st);
+
 }  // namespace dc

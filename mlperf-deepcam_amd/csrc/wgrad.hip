@@ -405,6 +405,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 static int g_wgrad_mode = 1;               // 1 = LDS-DMA 3-stage kernel, 0 = register-staged kernel
+static int g_thin_wgrad = 1;               // one-pass kernel for the two thin stem convolutions (thinconv.hip)
 static int g_wgrad256 = 1;                 // 0: 128-tile kernel only, 1: planner, 2: 256-tile kernel wherever eligible (bf16)
 static int g_wgrad_target_blocks = 768;    // resident capacity: 256 CUs x 3 workgroups (48 KiB LDS, 146 registers)
 
@@ -435,6 +436,11 @@ extern "C" int dc_wgrad_set_256(int m) {
   return 0;
 }
 
+extern "C" int dc_wgrad_set_thin(int m) {
+  g_thin_wgrad = m ? 1 : 0;
+  return 0;
+}
+
 // Tile-shape planner (bf16): the 256-tile kernel when both channel extents fill at least most of a 256 tile.
 static bool wgrad256_wins(const GatherGeom& g) {
   if (g_wgrad256 == 2) return true;
@@ -458,6 +464,10 @@ extern "C" size_t dc_conv_wgrad_workspace(const dc_conv_desc* d, int N, int Hi, 
     int s2, c2;
     wgrad256_plan(g, (long)N * g.Qh * g.Qw, &s2, &c2);
     if (s2 > splits) splits = s2;
+    if (thin_wgrad_eligible(*d, Hi, Wi)) {
+      const int s3 = thin_wgrad_splits(*d, N, Hi, Wi);
+      if (s3 > splits) splits = s3;
+    }
   }
   return (size_t)splits * g.ntaps * g.Cout * g.Cin * sizeof(float);
 }
@@ -472,8 +482,10 @@ extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const
   const long M = (long)N * p.g.Qh * p.g.Qw;
   DC_REQUIRE(M < (1L << 31) - 256, "dc_conv_wgrad: too many pixels for 32-bit indexing");
   const int BP = d->dtype == DC_BF16 ? 64 : 32;    // chunk granularity (a multiple of both kernels' pixels per stage)
-  const bool big = d->dtype == DC_BF16 && wgrad256_wins(p.g);
-  if (big) wgrad256_plan(p.g, M, &p.splits, &p.chunk);
+  const bool thin = g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi);
+  const bool big = !thin && d->dtype == DC_BF16 && wgrad256_wins(p.g);
+  if (thin) { p.splits = thin_wgrad_splits(*d, N, Hi, Wi); p.chunk = 0; }
+  else if (big) wgrad256_plan(p.g, M, &p.splits, &p.chunk);
   else plan_splits(p.g, M, BP, &p.splits, &p.chunk);
   const size_t need = (size_t)p.splits * p.g.ntaps * p.g.Cout * p.g.Cin * sizeof(float);
   DC_REQUIRE(workspace_bytes >= need, "dc_conv_wgrad: workspace too small");
@@ -481,7 +493,9 @@ extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const
   p.N = N; p.ldx = ldx; p.lddy = lddy; p.M = (int)M;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(cdiv(p.g.Cin, 128) * cdiv(p.g.Cout, 128) * p.g.ntaps * p.splits);
-  if (big) {
+  if (thin) {
+    if (int e = launch_thin_wgrad(*d, N, Hi, Wi, x, ldx, dy, lddy, p.slab, st)) return e;
+  } else if (big) {
     if (int e = launch_wgrad256(p, st)) return e;
   } else if (g_wgrad_mode == 1) {
     const size_t lds = 3 * 2 * 8192;

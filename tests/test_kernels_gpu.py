@@ -88,6 +88,10 @@ CONV_CASES = [
     ("gemm_rows2", 1, 1, 0, 1, 0, 2048, 256, 2, 1, 1),      # <= 16 pixels: the GEMV path of the image-pool branch
     ("gemm_rows16", 1, 1, 0, 1, 0, 264, 72, 16, 1, 1),
     ("gemm_rows17", 1, 1, 0, 1, 0, 264, 72, 17, 1, 1),      # one more pixel: back on the tiled kernel
+    # the two thin stem convolutions at widths that are multiples of 32 output pixels: one-pass weight gradient (thinconv.hip)
+    ("stem_thin", 3, 2, 1, 1, 0, 16, 32, 2, 10, 128),
+    ("conv2_thin", 3, 1, 1, 1, 0, 32, 64, 2, 7, 96),
+    ("stem_thin_19_rows", 3, 2, 1, 1, 0, 16, 32, 1, 38, 64),
 ]
 
 
