@@ -219,6 +219,99 @@ __global__ __launch_bounds__(256) void head_combine_kernel(const float* __restri
   }
 }
 
+// Fused forward (bf16): products and sub-pixel combination in one kernel, so the 27-product image (226 MB written and read
+// back at B=8, on top of a GEMM that fills a quarter of its 128-wide tile) never exists.  A workgroup walks HF_TILES tiles of
+// 4 x 32 input pixels; per tile the products of the 5 x 33 pixels it touches (the +1 halo supplies the (qy+1, qx+1) neighbours)
+// are computed with MFMA straight from global memory -- a lane loads the 16 bytes of ITS pixel's K group, which is exactly the
+// A-fragment layout, out-of-image pixels load zeros -- against the 32 x Cin weight image held in LDS, land in an LDS tile
+// P[pixel][32] (fp32) and are combined into 8 x 64 x 3 logits with the same addition order as head_combine_kernel,
+// written as coalesced NCHW rows.
+constexpr int HF_TY = 4, HF_TX = 32;
+constexpr int HF_PX = (HF_TY + 1) * (HF_TX + 1);        // 165 product pixels per tile
+constexpr int HF_MB = (HF_PX + 15) / 16;                // 11 MFMA row blocks
+constexpr int HF_TILES = 6;                             // tiles per workgroup (along x), amortises the weight image
+
+__global__ __launch_bounds__(256) void head_fused_fwd_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ wf,
+                                                             float* __restrict__ out, int N, int Hi, int Wi, int Cin, int ntx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* P = reinterpret_cast<float*>(smem);                       // [HF_MB*16][HEAD_NP]
+  char* wl = smem + HF_MB * 16 * HEAD_NP * 4;                      // weight image [32][Cin] bf16, 64-byte K rows swizzled per 16-B slot
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  // stage the weights: row j (product), K step k, slot s  ->  wl[(k*32 + j)*64 + ((s ^ ((j >> 1) & 3)) << 4)]
+  for (int i = tid; i < HEAD_NP * Cin / 8; i += 256) {
+    const int j = i / (Cin / 8), v = i % (Cin / 8);
+    const int k = v >> 2, sl = v & 3;
+    *reinterpret_cast<vec16*>(wl + (k * 32 + j) * 64 + ((sl ^ ((j >> 1) & 3)) << 4)) = ldg16(wf + (size_t)j * Cin + v * 8);
+  }
+  const int strips = (ntx + HF_TILES - 1) / HF_TILES;
+  int b = blockIdx.x;
+  const int strip = b % strips;
+  b /= strips;
+  const int nty = (Hi + HF_TY - 1) / HF_TY;
+  const int ty = b % nty, n = b / nty;
+  const int y0 = ty * HF_TY;
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  for (int tt = 0; tt < HF_TILES; ++tt) {
+    const int tx = strip * HF_TILES + tt;
+    if (tx >= ntx) break;
+    const int x0 = tx * HF_TX;
+    __syncthreads();   // weights staged (first pass) / the previous tile's combine is done with P
+    // A fragments of row block mb: this lane's pixel, its 16-byte K group of each of the 8 K steps (Cin = 256); the next block's
+    // loads are in flight while the current one is multiplied
+    auto load_block = [&](int mb, vec16 (&fa)[8]) {
+      const int idx = mb * 16 + fr;
+      const int ry = idx / (HF_TX + 1), rx = idx - ry * (HF_TX + 1);
+      const int qy = y0 + ry, qx = x0 + rx;
+      const bool ok = idx < HF_PX && qy < Hi && qx < Wi;
+      const bf16* src = x + (((size_t)n * Hi + (ok ? qy : 0)) * Wi + (ok ? qx : 0)) * ldx + fg * 8;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) fa[u] = ok ? ldg16(src + u * 32) : zero16();
+    };
+    vec16 cur[8], nxt[8];
+    if (wave < HF_MB) load_block(wave, cur);
+    for (int mb = wave; mb < HF_MB; mb += 4) {
+      if (mb + 4 < HF_MB) load_block(mb + 4, nxt);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const char* wk = wl + u * 32 * 64;
+        const vec16 b0 = *reinterpret_cast<const vec16*>(wk + fr * 64 + ((fg ^ ((fr >> 1) & 3)) << 4));
+        const vec16 b1 = *reinterpret_cast<const vec16*>(wk + (16 + fr) * 64 + ((fg ^ (((16 + fr) >> 1) & 3)) << 4));
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[u]), __builtin_bit_cast(bf16x8, b0), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[u]), __builtin_bit_cast(bf16x8, b1), acc1, 0, 0, 0);
+      }
+      // D[row = pixel fg*4 + r][col = product fr]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        P[(mb * 16 + fg * 4 + r) * HEAD_NP + fr] = acc0[r];
+        P[(mb * 16 + fg * 4 + r) * HEAD_NP + 16 + fr] = acc1[r];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+    }
+    __syncthreads();
+    // combine: 2*HF_TY x 2*HF_TX outputs per class, consecutive lanes along x
+    for (int i = tid; i < HEAD_NC * 2 * HF_TY * 2 * HF_TX; i += 256) {
+      const int ox_l = i % (2 * HF_TX);
+      const int t2 = i / (2 * HF_TX);
+      const int oy_l = t2 % (2 * HF_TY), co = t2 / (2 * HF_TY);
+      const int qy_l = oy_l >> 1, py = oy_l & 1, qx_l = ox_l >> 1, px = ox_l & 1;
+      const int qy = y0 + qy_l, qx = x0 + qx_l;
+      if (qy < Hi && qx < Wi) {
+        const float* p00 = P + (qy_l * (HF_TX + 1) + qx_l) * HEAD_NP + co * 9;
+        const float* p01 = p00 + HEAD_NP;
+        const float* p10 = p00 + (HF_TX + 1) * HEAD_NP;
+        const float* p11 = p10 + HEAD_NP;
+        float o;
+        if (py == 0) o = px == 0 ? p00[4] : p00[5] + p01[3];
+        else o = px == 0 ? p00[7] + p10[1] : ((p00[8] + p01[6]) + p10[2]) + p11[0];
+        out[(((size_t)n * HEAD_NC + co) * Ho + 2 * qy + py) * Wo + 2 * qx + px] = o;
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void head_gather_kernel(const float* __restrict__ dl, T* __restrict__ dP, int N, int Hi, int Wi) {
   const long total = (long)N * Hi * Wi;
@@ -363,6 +456,9 @@ __global__ __launch_bounds__(256) void input_normalize_kernel(long npix, int Cfi
   }
 }
 
+static int g_head_fused = 1;   // bf16 forward: products + combination in one kernel (0: GEMM + combine kernels)
+extern "C" int dc_head_set_fused(int v) { g_head_fused = v ? 1 : 0; return 0; }
+
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct HeadWs {
@@ -400,6 +496,16 @@ extern "C" int dc_head_fwd(int dtype, int N, int Cin, int Hi, int Wi, const void
   if (dtype == DC_BF16) hipLaunchKernelGGL(head_pack_kernel<bf16>, dim3(cdiv(np, 256)), dim3(256), 0, st, w, (bf16*)ws.wf, (bf16*)ws.wb, Cin);
   else hipLaunchKernelGGL(head_pack_kernel<float>, dim3(cdiv(np, 256)), dim3(256), 0, st, w, (float*)ws.wf, (float*)ws.wb, Cin);
   DC_CHECK_LAUNCH();
+  if (dtype == DC_BF16 && g_head_fused && Cin == 256) {
+    const int ntx = cdiv(Wi, HF_TX), nty = cdiv(Hi, HF_TY), strips = cdiv(ntx, HF_TILES);
+    const size_t lds = (size_t)HF_MB * 16 * HEAD_NP * 4 + (size_t)HEAD_NP * Cin * 2;
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    hipLaunchKernelGGL(head_fused_fwd_kernel, dim3(strips * nty * N), dim3(256), lds, st, (const bf16*)x, ldx, (const bf16*)ws.wf, logits_nchw,
+                       N, Hi, Wi, Cin, ntx);
+    DC_CHECK_LAUNCH();
+    return 0;
+  }
   dc_conv_desc d{dtype, 1, 1, 0, 1, 0, Cin, HEAD_NP};
   if (int e = dc_conv_fwd_f32out(&d, N, Hi, Wi, x, ldx, ws.wf, ws.P, HEAD_NP, stream)) return e;
   const long P = (long)N * Hi * Wi;

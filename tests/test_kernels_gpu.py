@@ -540,6 +540,31 @@ def test_head(dtype):
     assert_close(gw.cpu(), gw_ref, dtype, f32=2e-4, bf16=1e-2)
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 70), (1, 9, 229), (1, 8, 32)], ids=["3x3tiles", "8tiles_wide", "one_exact_tile"])
+def test_head_fused_forward_matches_gemm_plus_combine(shape):
+    """bf16 classifier head: the fused products+combination kernel equals the GEMM + combine kernels bit for bit (same fp32
+    products, same addition order) over several tiles, ragged edges and more tiles than one workgroup walks."""
+    N, H, W = shape
+    Cin = 256
+    x = q(rnd(N, Cin, H, W, seed=5), torch.bfloat16)
+    wd = rnd(Cin, 3, 3, 3, seed=6, scale=0.05).to(dev())
+    _, xv = to_nhwc(x, torch.bfloat16)
+    wsb = L.load().dc_head_workspace(L.DC_BF16, N, Cin, H, W)
+    ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev())
+    wsp = C.c_void_p((ws.data_ptr() + 255) // 256 * 256)
+    outs = []
+    for mode in (1, 0):
+        L.call("dc_set_option", b"head_fused", mode)
+        out = torch.full((N, 3, 2 * H, 2 * W), float("nan"), device=dev())
+        L.call("dc_head_fwd", L.DC_BF16, N, Cin, H, W, vptr(xv), Cin, vptr(wd), vptr(out), wsp, S())
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    L.call("dc_set_option", b"head_fused", 1)
+    assert torch.equal(outs[0], outs[1])
+    ref = F.conv_transpose2d(x, q(wd.cpu(), torch.bfloat16), None, 2, 1, 1)
+    assert_close(outs[0].cpu(), ref, torch.float32, f32=2e-4)
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_nchw_to_nhwc(dtype):
     x = rnd(2, 16, 9, 13, seed=1)
