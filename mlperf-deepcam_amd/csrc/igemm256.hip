@@ -61,6 +61,7 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
   const GatherGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  [[maybe_unused]] const unsigned long long t_start = SEG_T();
   const int grp = wave >> 2;   // pixel half; also the stagger group
   const int wc = wave & 3;     // channel quarter
 
@@ -273,7 +274,8 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
 #ifdef DC_STAMPS
   if (dc_stamp_buf256 != nullptr && lane == 0 && wc == 0) {
     unsigned long long* o = dc_stamp_buf256 + ((size_t)blockIdx.x * 2 + grp) * 8;
-    for (int k = 0; k < 6; ++k) o[k] = seg[k];
+    for (int k = 0; k < 4; ++k) o[k] = seg[k];
+    o[4] = t_loop0 - t_start;      // prologue: tap table, row bookkeeping, three stages issued, stage 0 landed
     o[6] = SEG_T() - t_loop0;
     o[7] = (unsigned long long)steps;
   }
@@ -374,6 +376,12 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
       }
     }
   }
+#ifdef DC_STAMPS
+  if (dc_stamp_buf256 != nullptr && lane == 0 && wc == 0) {
+    unsigned long long* o = dc_stamp_buf256 + ((size_t)blockIdx.x * 2 + grp) * 8;
+    o[5] = SEG_T() - t_start;      // whole kernel
+  }
+#endif
 }
 
 }  // namespace

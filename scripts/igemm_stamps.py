@@ -52,6 +52,8 @@ if hasattr(lib, "dc_debug_stamp_buf256"):
     for gidx in (0, 1):
         st_ = s2[:, gidx, 7].mean()
         print(f"  group {gidx}: {st_:.0f} stages, loop {s2[:, gidx, 6].mean() / st_:.0f} cycles per stage")
-        for k in range(6):
+        for k in range(4):
             print(f"      {segn[k]:52s} {s2[:, gidx, k].mean() / st_:7.0f} cyc")
+        tot, pro, loop = s2[:, gidx, 5].mean(), s2[:, gidx, 4].mean(), s2[:, gidx, 6].mean()
+        print(f"      whole workgroup {tot:.0f} cyc = prologue {pro:.0f} + K loop {loop:.0f} + epilogue {tot - pro - loop:.0f}")
     L.call("dc_set_option", b"igemm256", 1)
