@@ -27,4 +27,9 @@ inline long igemm256_tiles(const IgemmParams& p) {
   return (long)((p.g.Cout + 255) / 256) * ((p.M + 255) / 256) * p.g.os * p.g.os;
 }
 
+// thinconv.hip: the thin 3x3 stem convolutions (forward and data gradient) without LDS staging of the pixel operand
+bool thin_fwd_eligible(const GatherGeom& g, int dtype, int bias, int accumulate, int out32);
+int launch_thin_fwd(const GatherGeom& g, int N, const void* in, int ldin, const void* w, int ldw, void* out, int ldout, float* slab,
+                    int slab_rows, hipStream_t st);
+
 }  // namespace dc

@@ -459,6 +459,7 @@ __global__ __launch_bounds__(256) void tiny_gemm_kernel(const IgemmParams p) {
 }
 
 static int g_igemm_mode = 2;
+static int g_thin_fwd = 1;    // dedicated kernel for the thin 3x3 stem convolutions (thinconv.hip)
 static int g_igemm256 = 1;   // 0: never, 1: where the planner expects it to win, 2: whenever eligible (bf16, bf16 output)
 
 template <typename T, bool OUT32, int MODE>
@@ -534,6 +535,8 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
     DC_CHECK_LAUNCH();
     return 0;
   }
+  if (g_thin_fwd && thin_fwd_eligible(p.g, d->dtype, bias != nullptr, accumulate, out32))
+    return launch_thin_fwd(p.g, N, in, ldin, w, p.ldw, out, ldout, slab, p.mtiles * p.g.os * p.g.os, st);
   if (d->dtype == DC_BF16 && !out32 && g_igemm256 != 0) {
     if (g_igemm256 == 2 || igemm256_wins(p)) return launch_igemm256(p, st);
   }
@@ -678,6 +681,7 @@ extern "C" int dc_set_option(const char* name, int value) {
     return 0;
   }
   if (name != nullptr && strcmp(name, "igemm256") == 0) { g_igemm256 = value; return 0; }
+  if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }
   if (name != nullptr && strcmp(name, "wgrad_target_blocks") == 0) return dc_wgrad_set_target_blocks(value);
   if (name != nullptr && strcmp(name, "wgrad_mode") == 0) return dc_wgrad_set_mode(value);

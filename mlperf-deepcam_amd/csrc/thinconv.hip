@@ -13,6 +13,7 @@
 //   * 4 waves = 2 halves of co x 2 halves of the (tap, ci) columns; a wave keeps <= 18 accumulator tiles;
 //   * one partial [9][Co][Ci] per workgroup goes to the fp32 slab of wgrad.hip ([split][tap][Co][Ci]) and its fixed-order
 //     reduction kernel finishes the job (deterministic).
+#include "igemm.h"
 #include "wgrad.h"
 
 namespace dc {
@@ -165,6 +166,164 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward / data gradient of the thin 3x3 convolutions (16 -> 32 stride 2, 32 -> 64, and the data gradient 64 -> 32 of the
+// latter) in gather form:  out[m][co] = sum over taps t, channels ci of in[gather(m, t)][ci] * w[t][co][ci].
+// The tiled GEMM kernel spends these layers on per-tile overhead (13824 tiles of 9 K steps, a quarter or half of the 128
+// columns used): 230-330 us against ~70 us of traffic.  Here the pixel operand needs no LDS at all: with K = (tap, channel)
+// a lane's 16-byte load of ITS pixel's channel group is exactly the MFMA fragment layout, consecutive lanes read consecutive
+// pixels (NHWC rows), and the 3x3 reuse is served by L1/L2.  The whole weight set (<= 36 KiB) sits in LDS for the life of a
+// persistent workgroup.  Weight rows are staged in a permuted order so that a lane ends up with 8 consecutive output
+// channels per 16-byte store and the lanes of a pixel complete its row.
+struct ThinFwdArgs {
+  const void* in;
+  const void* w;       // [tap][Cout][ldw]
+  void* out;
+  float* slab;         // [2][rows][Cout] or null; this kernel writes rows 0 .. gridDim.x-1 (the rest is zeroed by the launcher)
+  int N, Hin, Win, Hout, Wout, ldin, ldout, ldw, is, M, slab_rows;
+  int tdy[9], tdx[9], twidx[9];
+  FastDiv div_hw, div_w;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void thin_fwd_kernel(const ThinFwdArgs a) {
+  constexpr int KS = (9 * CIN + 31) / 32;        // K steps of 32: 5 (two taps each, the last half empty) / 9 / 18
+  constexpr int MB = COUT / 16;                  // channel blocks
+  constexpr int PB = 4;                          // pixel blocks of 16 per wave iteration
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const bf16* __restrict__ xin = reinterpret_cast<const bf16*>(a.in);
+  const bf16* __restrict__ wg = reinterpret_cast<const bf16*>(a.w);
+
+  // ---- weight image: wl[(ks*COUT + row)*64 + swizzled slot], row rho of a channel block set holds channel perm(rho)
+  for (int i = tid; i < KS * COUT * 4; i += 256) {
+    const int sl = i & 3, row = (i >> 2) % COUT, ks = i / (4 * COUT);
+    // COUT = 64: perm(16 i + 4 g + r) = 32 (i >> 1) + 8 g + 4 (i & 1) + r;  COUT = 32: perm(16 i + 4 g + r) = 8 g + 4 i + r
+    const int bi = row >> 4, g = (row >> 2) & 3, r = row & 3;
+    const int co = COUT == 64 ? (bi >> 1) * 32 + g * 8 + (bi & 1) * 4 + r : g * 8 + bi * 4 + r;
+    int tap, coff;                                 // this 16-byte slot = 8 channels of one tap
+    if (CIN == 16) { tap = 2 * ks + (sl >> 1); coff = (sl & 1) * 8; }
+    else if (CIN == 32) { tap = ks; coff = sl * 8; }
+    else { tap = ks >> 1; coff = (ks & 1) * 32 + sl * 8; }
+    vec16 v = zero16();
+    if (tap < 9) v = ldg16(wg + ((size_t)a.twidx[tap] * COUT + co) * a.ldw + coff);
+    *reinterpret_cast<vec16*>(smem + (ks * COUT + row) * 64 + ((sl ^ ((row >> 1) & 3)) << 4)) = v;
+  }
+  __syncthreads();
+
+  // this lane's K slice: which tap(s) and channel offset for each K step
+  float ssum[MB * 4], ssq[MB * 4];
+#pragma unroll
+  for (int c = 0; c < MB * 4; ++c) ssum[c] = ssq[c] = 0.f;
+  bf16* __restrict__ yout = reinterpret_cast<bf16*>(a.out);
+  const int chunks = (a.M + 255) / 256;
+  for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+    const int mbase = chunk * 256 + wave * 64;
+    // pixel coordinates of this lane's pixel in each of the 4 pixel blocks
+    int iy0[PB], ix0[PB];
+    const bf16* base[PB];
+    bool pok[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int m = mbase + j * 16 + fr;
+      pok[j] = m < a.M;
+      const int mm = pok[j] ? m : 0;
+      const int n = fast_div(mm, a.div_hw);
+      const int rem = mm - n * (a.Hout * a.Wout);
+      const int oy = fast_div(rem, a.div_w), ox = rem - oy * a.Wout;
+      iy0[j] = oy * a.is;
+      ix0[j] = ox * a.is;
+      base[j] = xin + (size_t)n * a.Hin * a.Win * a.ldin;
+    }
+    f32x4 acc[MB][PB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load_step = [&](int ks, vec16 (&fb)[PB]) {
+      int tap, coff;
+      if (CIN == 16) { tap = 2 * ks + (fg >> 1); coff = (fg & 1) * 8; }
+      else if (CIN == 32) { tap = ks; coff = fg * 8; }
+      else { tap = ks >> 1; coff = (ks & 1) * 32 + fg * 8; }
+      const bool tok = tap < 9;
+      const int dy = a.tdy[tok ? tap : 0], dx = a.tdx[tok ? tap : 0];
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const int iy = iy0[j] + dy, ix = ix0[j] + dx;
+        const bool ok = tok && pok[j] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        fb[j] = ok ? ldg16(base[j] + ((size_t)iy * a.Win + ix) * a.ldin + coff) : zero16();
+      }
+    };
+    vec16 cur[PB], nxt[PB];
+    load_step(0, cur);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) load_step(ks + 1, nxt);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const int row = i * 16 + fr;
+        const vec16 fa = *reinterpret_cast<const vec16*>(smem + (ks * COUT + row) * 64 + ((fg ^ ((row >> 1) & 3)) << 4));
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, cur[j]), acc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j) cur[j] = nxt[j];
+    }
+    // ---- store: D rows (channels) fg*4 + r of block i, column (pixel) fr.  Vector hh of this lane = channels 32 hh + 8 fg .. +7
+    // (COUT = 64) or 8 fg .. +7 (COUT = 32)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int m = mbase + j * 16 + fr;
+      if (m < a.M) {
+        bf16* dst = yout + (size_t)m * a.ldout + fg * 8;
+#pragma unroll
+        for (int hh = 0; hh < MB / 2; ++hh) {
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = acc[2 * hh + (e >> 2)][j][e & 3];
+          vec16 v;
+          pack(v, f, bf16());
+          stg16(dst + 32 * hh, v);
+          unpack(v, f, bf16());
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            ssum[8 * hh + e] += f[e];
+            ssq[8 * hh + e] = fmaf(f[e], f[e], ssq[8 * hh + e]);
+          }
+        }
+      }
+    }
+  }
+  if (a.slab != nullptr) {
+    // fold the 16 pixel lanes, then the 4 waves through LDS; one slab row per workgroup
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+      for (int c = 0; c < MB * 4; ++c) {
+        ssum[c] += __shfl_xor(ssum[c], off, 64);
+        ssq[c] += __shfl_xor(ssq[c], off, 64);
+      }
+    __syncthreads();   // the weight image is dead
+    float* red = reinterpret_cast<float*>(smem);   // [wave][2][COUT]
+    if (fr == 0) {
+#pragma unroll
+      for (int c = 0; c < MB * 4; ++c) {
+        const int ch = 32 * (c >> 3) + fg * 8 + (c & 7);
+        red[(wave * 2 + 0) * COUT + ch] = ssum[c];
+        red[(wave * 2 + 1) * COUT + ch] = ssq[c];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+      const int which = tid / COUT, ch = tid % COUT;
+      const float s = (red[(0 * 2 + which) * COUT + ch] + red[(1 * 2 + which) * COUT + ch]) + (red[(2 * 2 + which) * COUT + ch] + red[(3 * 2 + which) * COUT + ch]);
+      a.slab[((size_t)which * a.slab_rows + blockIdx.x) * COUT + ch] = s;
+    }
+  }
+}
+
 struct ThinPlan {
   int nseg, nchunk, rows_per, blocks;
 };
@@ -215,6 +374,47 @@ int launch_thin_wgrad(const dc_conv_desc& d, int N, int Hi, int Wi, const void* 
     if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_kernel<32, 64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS); once = true; }
     hipLaunchKernelGGL((thin_wgrad_kernel<32, 64, 1>), dim3(p.blocks), dim3(256), K::LDS, st, a);
   }
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+// Gather-form forward / data gradient of a thin 3x3 convolution (see thin_fwd_kernel).  `slab_rows` is the row count the caller's
+// statistics slab was sized for (dc_conv_stat_rows); rows this kernel does not write are zeroed.
+bool thin_fwd_eligible(const GatherGeom& g, int dtype, int bias, int accumulate, int out32) {
+  if (dtype != DC_BF16 || bias || accumulate || out32 || g.os != 1 || g.ntaps != 9) return false;
+  return (g.Cin == 16 && g.Cout == 32) || (g.Cin == 32 && g.Cout == 64) || (g.Cin == 64 && g.Cout == 32);
+}
+
+int launch_thin_fwd(const GatherGeom& g, int N, const void* in, int ldin, const void* w, int ldw, void* out, int ldout, float* slab,
+                    int slab_rows, hipStream_t st) {
+  ThinFwdArgs a;
+  a.in = in; a.w = w; a.out = out; a.slab = slab;
+  a.N = N; a.Hin = g.Hin; a.Win = g.Win; a.Hout = g.Hout; a.Wout = g.Wout; a.ldin = ldin; a.ldout = ldout; a.ldw = ldw; a.is = g.is;
+  a.M = N * g.Hout * g.Wout;
+  a.slab_rows = slab_rows;
+  for (int t = 0; t < 9; ++t) { a.tdy[t] = g.taps[t].dy; a.tdx[t] = g.taps[t].dx; a.twidx[t] = g.taps[t].widx; }
+  a.div_hw = make_fastdiv(g.Hout * g.Wout);
+  a.div_w = make_fastdiv(g.Wout);
+  const int chunks = cdiv(a.M, 256);
+  int grid = chunks < 1024 ? chunks : 1024;
+  if (slab != nullptr && grid > slab_rows) grid = slab_rows;
+  if (slab != nullptr && slab_rows > grid) {
+    for (int which = 0; which < 2; ++which) {
+      hipError_t e = hipMemsetAsync(slab + ((size_t)which * slab_rows + grid) * g.Cout, 0, (size_t)(slab_rows - grid) * g.Cout * sizeof(float), st);
+      if (e != hipSuccess) return dc_set_error(e, __FILE__, __LINE__);
+    }
+  }
+#define THIN_FWD(CI, CO)                                                                                                        \
+  do {                                                                                                                          \
+    constexpr int LDS = ((9 * CI + 31) / 32) * CO * 64;                                                                         \
+    static bool once = false;                                                                                                   \
+    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel<CI, CO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; } \
+    hipLaunchKernelGGL((thin_fwd_kernel<CI, CO>), dim3(grid), dim3(256), LDS, st, a);                                           \
+  } while (0)
+  if (g.Cin == 16) THIN_FWD(16, 32);
+  else if (g.Cin == 32) THIN_FWD(32, 64);
+  else THIN_FWD(64, 32);
+#undef THIN_FWD
   DC_CHECK_LAUNCH();
   return 0;
 }
