@@ -467,6 +467,7 @@ static int dw_check(int dtype, int C, int stride, int dil, int N, int Hi, int Wi
 extern "C" int dc_dw_set_option(const char* name, int value) {
   if (strcmp(name, "dw_tile") == 0) { g_dw_tile = value != 0; return 0; }
   if (strcmp(name, "dw_wgrad_tpb") == 0) { dw_tile_set_tpb(value); return 0; }
+  if (strcmp(name, "dw_cg") == 0) { dw_tile_set_cg(value); return 0; }
   return -1;
 }
 

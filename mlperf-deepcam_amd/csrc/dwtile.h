@@ -13,6 +13,7 @@ int launch_dw_tile_wgrad(int dtype, int dil, const void* x, int ldx, const void*
                          int H, int W, int C, hipStream_t st);
 size_t dw_tile_wgrad_workspace(int C, int N, int H, int W);
 void dw_tile_set_tpb(int v);
+void dw_tile_set_cg(int v);
 int dw_tile_reduce(const float* slab, float* grad_w, int rows, int C, hipStream_t st);   // grad[c][t] = sum of slab rows (fp64, fixed order)
 
 // stride-2 kernels (dwtile_s2.hip).  mode 0 forward, 1 data gradient (p1 = addend or null), 2 weight-gradient rows into the slab

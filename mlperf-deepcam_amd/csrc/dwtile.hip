@@ -284,7 +284,9 @@ int dw_tile_reduce(const float* slab, float* grad_w, int rows, int C, hipStream_
 static int g_dw_tpb = 0;   // tiles per workgroup of the weight gradient; 0 = planner
 void dw_tile_set_tpb(int v) { g_dw_tpb = v < 0 ? 0 : v; }
 
-static int pick_cg(int ngroups) { return ngroups <= 8 ? 8 : ngroups <= 16 ? 16 : 32; }
+static int g_dw_cg = 0;   // 0: by channel count; 8 / 16 / 32: force the channel-group width of a workgroup (tuning switch)
+void dw_tile_set_cg(int v) { g_dw_cg = (v == 8 || v == 16 || v == 32) ? v : 0; }
+static int pick_cg(int ngroups) { return g_dw_cg ? g_dw_cg : ngroups <= 8 ? 8 : ngroups <= 16 ? 16 : 32; }
 
 struct TileGrid {
   int cg, ncgb, ntx, nty, ntiles;
