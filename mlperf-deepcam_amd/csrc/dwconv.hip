@@ -439,7 +439,7 @@ static int launch_dw(const void* in, int ldin, const float* w, const void* adden
 static int launch_dw_s1(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
                         void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale = nullptr,
                         const float* pshift = nullptr, int prelu = 0) {
-  if (g_dw_tile && pscale == nullptr) return launch_dw_tile(dtype, dil, flip, in, ldin, wp, addend, ldadd, out, ldout, N, H, W, C, st);
+  if (g_dw_tile) return launch_dw_tile(dtype, dil, flip, in, ldin, wp, addend, ldadd, out, ldout, N, H, W, C, st, pscale, pshift, prelu);
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const long total = (long)N * H * ((W + DW_PX - 1) / DW_PX) * (C / kpv);
   DC_REQUIRE(total < (1L << 31), "dc_dwconv: tensor too large for the stride-1 fast path");
@@ -490,8 +490,8 @@ extern "C" int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int H
   hipStream_t st = (hipStream_t)stream;
   DC_REQUIRE((pscale == nullptr) == (pshift == nullptr), "dc_dwconv_fwd: pscale and pshift go together");
   if (stride == 1 && (dil == 1 || dil == 2)) return launch_dw_s1(dtype, dil, false, x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, C, st, pscale, pshift, prelu);
-  if (stride == 2 && dil == 1 && g_dw_tile && pscale == nullptr)
-    return launch_dw_tile_s2(dtype, 0, N, Hi, Wi, C, x, ldx, w, nullptr, 0, y, ldy, nullptr, nullptr, st);
+  if (stride == 2 && dil == 1 && g_dw_tile)
+    return launch_dw_tile_s2(dtype, 0, N, Hi, Wi, C, x, ldx, w, nullptr, 0, y, ldy, nullptr, nullptr, st, pscale, pshift, prelu);
   return dtype == DC_BF16 ? launch_dw<bf16, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st, pscale, pshift, prelu)
                           : launch_dw<float, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st, pscale, pshift, prelu);
 }
@@ -547,11 +547,11 @@ extern "C" int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int
   hipStream_t st = (hipStream_t)stream;
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const int cgw = dw_pick_cgw(C / kpv);
-  if (stride == 1 && (dil == 1 || dil == 2) && g_dw_tile && pscale == nullptr)
-    return launch_dw_tile_wgrad(dtype, dil, x, ldx, dy, lddy, (float*)workspace, grad_w, N, Hi, Wi, C, st);
-  if (stride == 2 && dil == 1 && g_dw_tile && pscale == nullptr) {
+  if (stride == 1 && (dil == 1 || dil == 2) && g_dw_tile)
+    return launch_dw_tile_wgrad(dtype, dil, x, ldx, dy, lddy, (float*)workspace, grad_w, N, Hi, Wi, C, st, pscale, pshift, prelu);
+  if (stride == 2 && dil == 1 && g_dw_tile) {
     int trows = 0;
-    if (int e = launch_dw_tile_s2(dtype, 2, N, Hi, Wi, C, x, ldx, nullptr, dy, lddy, nullptr, 0, (float*)workspace, &trows, st)) return e;
+    if (int e = launch_dw_tile_s2(dtype, 2, N, Hi, Wi, C, x, ldx, nullptr, dy, lddy, nullptr, 0, (float*)workspace, &trows, st, pscale, pshift, prelu)) return e;
     return dw_tile_reduce((const float*)workspace, grad_w, trows, C, st);
   }
   if (stride == 1 && (dil == 1 || dil == 2)) {

@@ -64,7 +64,8 @@ __device__ inline void stage_halo(char* smem, const T* __restrict__ in, int ldin
 template <typename T, int DIL, bool FLIP, int CG>
 __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int ldin, const float* __restrict__ wp,
                                                   const T* __restrict__ addend, int ldadd, T* __restrict__ out, int ldout, int H, int W,
-                                                  int C, int ncgb, int ntx, int nty) {
+                                                  int C, int ncgb, int ntx, int nty, const float* __restrict__ pscale,
+                                                  const float* __restrict__ pshift, int prelu) {
   typedef TileCfg<DIL, CG> K;
   constexpr int KPV = Elem<T>::kPerVec, KH = KPV / 2;
   constexpr int WC = DT_PX + 2 * DIL;
@@ -85,6 +86,10 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
   float wk[9][KH];
   load_taps<KH>(wp, ch0, C, FLIP, wk);
   __syncthreads();   // vmcnt(0) + barrier: the whole halo tile has landed
+  if (!FLIP && pscale != nullptr) {   // fused BatchNorm(+ReLU) of the producer, applied once per staged element
+    bn_transform_tile<T, K::HH, K::HW, CG>(smem, y0 - DIL, x0 - DIL, H, W, pscale, pshift, prelu, cg0, ngroups);
+    __syncthreads();
+  }
   if (!cok) return;
 
   const char* tile = smem + h * 8;
@@ -153,7 +158,8 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
 template <typename T, int DIL, int CG>
 __global__ __launch_bounds__(256) void dwt_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
                                                         float* __restrict__ slab, int H, int W, int C, int ncgb, int ntx, int nty,
-                                                        int ntiles, int tpb) {
+                                                        int ntiles, int tpb, const float* __restrict__ pscale,
+                                                        const float* __restrict__ pshift, int prelu) {
   typedef TileCfg<DIL, CG> K;
   constexpr int KPV = Elem<T>::kPerVec, KH = KPV / 2;
   constexpr int WC = DT_PX + 2 * DIL;
@@ -198,6 +204,10 @@ __global__ __launch_bounds__(256) void dwt_wgrad_kernel(const T* __restrict__ x,
     vec8 gcur[DT_PX], gnext[DT_PX];
     load_dy(0, gcur);
     __syncthreads();   // vmcnt(0) + barrier
+    if (pscale != nullptr) {
+      bn_transform_tile<T, K::HH, K::HW, CG>(smem, y0 - DIL, x0 - DIL, H, W, pscale, pshift, prelu, cg0, ngroups);
+      __syncthreads();
+    }
     if (cok) {
 #pragma unroll 1
       for (int k = 0; k < K::SPT; ++k) {
@@ -326,7 +336,7 @@ size_t dw_tile_wgrad_workspace(int C, int N, int H, int W) {
 
 template <typename T, int DIL, bool FLIP, int CG>
 static void launch_fwd1(const TileGrid& t, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out,
-                        int ldout, int H, int W, int C, hipStream_t st) {
+                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu) {
   constexpr int LDS = TileCfg<DIL, CG>::LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
@@ -334,23 +344,23 @@ static void launch_fwd1(const TileGrid& t, const void* in, int ldin, const float
     attr_set = true;
   }
   hipLaunchKernelGGL((dwt_kernel<T, DIL, FLIP, CG>), dim3(t.ntiles * t.ncgb), dim3(256), LDS, st, (const T*)in, ldin, wp,
-                     (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty);
+                     (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu);
 }
 
 template <typename T, int DIL, bool FLIP>
 static void launch_fwd2(const TileGrid& t, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out,
-                        int ldout, int H, int W, int C, hipStream_t st) {
-  if (t.cg == 32) launch_fwd1<T, DIL, FLIP, 32>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st);
-  else if (t.cg == 16) launch_fwd1<T, DIL, FLIP, 16>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st);
-  else launch_fwd1<T, DIL, FLIP, 8>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st);
+                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu) {
+  if (t.cg == 32) launch_fwd1<T, DIL, FLIP, 32>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu);
+  else if (t.cg == 16) launch_fwd1<T, DIL, FLIP, 16>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu);
+  else launch_fwd1<T, DIL, FLIP, 8>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu);
 }
 
 int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
-                   void* out, int ldout, int N, int H, int W, int C, hipStream_t st) {
+                   void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu) {
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const TileGrid t = tile_grid(C / kpv, N, H, W);
   DC_REQUIRE((long)t.ntiles * t.ncgb < (1L << 31) && (long)N * H * W < (1L << 31), "dc_dwconv: tensor too large for the tiled path");
-#define DWT(TT, D, F) launch_fwd2<TT, D, F>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st)
+#define DWT(TT, D, F) launch_fwd2<TT, D, F>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu)
   if (dtype == DC_BF16) {
     if (dil == 1) { if (flip) DWT(bf16, 1, true); else DWT(bf16, 1, false); }
     else          { if (flip) DWT(bf16, 2, true); else DWT(bf16, 2, false); }
@@ -365,7 +375,7 @@ int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, cons
 
 template <typename T, int DIL, int CG>
 static void launch_wg1(const TileGrid& t, int tpb, int rows, const void* x, int ldx, const void* dy, int lddy, float* slab, int H,
-                       int W, int C, hipStream_t st) {
+                       int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu) {
   constexpr int FOLD = TileCfg<DIL, CG>::NSL * 9 * CG * Elem<T>::kPerVec * (int)sizeof(float);   // red[strip lane][9][channels]
   constexpr int LDS = TileCfg<DIL, CG>::LDS_BYTES > FOLD ? TileCfg<DIL, CG>::LDS_BYTES : FOLD;
   static bool attr_set = false;
@@ -374,19 +384,19 @@ static void launch_wg1(const TileGrid& t, int tpb, int rows, const void* x, int 
     attr_set = true;
   }
   hipLaunchKernelGGL((dwt_wgrad_kernel<T, DIL, CG>), dim3(rows * t.ncgb), dim3(256), LDS, st, (const T*)x, ldx, (const T*)dy, lddy,
-                     slab, H, W, C, t.ncgb, t.ntx, t.nty, t.ntiles, tpb);
+                     slab, H, W, C, t.ncgb, t.ntx, t.nty, t.ntiles, tpb, pscale, pshift, prelu);
 }
 
 template <typename T, int DIL>
 static void launch_wg2(const TileGrid& t, int tpb, int rows, const void* x, int ldx, const void* dy, int lddy, float* slab, int H,
-                       int W, int C, hipStream_t st) {
-  if (t.cg == 32) launch_wg1<T, DIL, 32>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
-  else if (t.cg == 16) launch_wg1<T, DIL, 16>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
-  else launch_wg1<T, DIL, 8>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
+                       int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu) {
+  if (t.cg == 32) launch_wg1<T, DIL, 32>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st, pscale, pshift, prelu);
+  else if (t.cg == 16) launch_wg1<T, DIL, 16>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st, pscale, pshift, prelu);
+  else launch_wg1<T, DIL, 8>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st, pscale, pshift, prelu);
 }
 
 int launch_dw_tile_wgrad(int dtype, int dil, const void* x, int ldx, const void* dy, int lddy, float* slab, float* grad_w, int N,
-                         int H, int W, int C, hipStream_t st) {
+                         int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu) {
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const TileGrid t = tile_grid(C / kpv, N, H, W);
   const int tpb = wgrad_tpb(t);
@@ -394,11 +404,11 @@ int launch_dw_tile_wgrad(int dtype, int dil, const void* x, int ldx, const void*
   DC_REQUIRE(rows <= DWT_MAX_ROWS, "dc_dwconv_wgrad: tiles-per-workgroup override needs more slab rows than the workspace holds");
   DC_REQUIRE((long)N * H * W < (1L << 31), "dc_dwconv_wgrad: tensor too large for the tiled path");
   if (dtype == DC_BF16) {
-    if (dil == 1) launch_wg2<bf16, 1>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
-    else launch_wg2<bf16, 2>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
+    if (dil == 1) launch_wg2<bf16, 1>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st, pscale, pshift, prelu);
+    else launch_wg2<bf16, 2>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st, pscale, pshift, prelu);
   } else {
-    if (dil == 1) launch_wg2<float, 1>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
-    else launch_wg2<float, 2>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st);
+    if (dil == 1) launch_wg2<float, 1>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st, pscale, pshift, prelu);
+    else launch_wg2<float, 2>(t, tpb, rows, x, ldx, dy, lddy, slab, H, W, C, st, pscale, pshift, prelu);
   }
   DC_CHECK_LAUNCH();
   hipLaunchKernelGGL(dwt_reduce_kernel, dim3(cdiv(9 * C, 16)), dim3(256), 0, st, (const float*)slab, grad_w, rows, C);

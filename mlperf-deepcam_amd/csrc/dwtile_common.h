@@ -54,4 +54,43 @@ __device__ inline void load_taps(const float* __restrict__ wp, int ch0, int C, b
 }
 
 
+// Fused producer for the tiled kernels: the staged tile holds the RAW (pre-BatchNorm) conv output; every in-image element becomes
+// v = x*scale[c] + shift[c] (and ReLU) in place, the zero padding stays zero.  One pass over the LDS tile (each element once,
+// where the register-window kernels recomputed it per window position); a thread's channel group is fixed, so its 8 (4)
+// coefficients live in registers.  Call between two workgroup barriers.
+template <typename T, int HH, int HW, int CG>
+__device__ inline void bn_transform_tile(char* smem, int iy0, int ix0, int H, int W, const float* __restrict__ pscale,
+                                         const float* __restrict__ pshift, int prelu, int cg0, int ngroups) {
+  constexpr int KPV = Elem<T>::kPerVec;
+  constexpr int HP = HH * HW, ITER = (HP * CG + 255) / 256;
+  const int tid = threadIdx.x, g = tid % CG;
+  if (cg0 + g >= ngroups) return;
+  float sc[KPV], sh[KPV];
+#pragma unroll
+  for (int e = 0; e < KPV; ++e) {
+    sc[e] = pscale[(cg0 + g) * KPV + e];
+    sh[e] = pshift[(cg0 + g) * KPV + e];
+  }
+#pragma unroll 2
+  for (int it = 0; it < ITER; ++it) {
+    const int slot = it * 256 + tid;
+    const int hp = slot / CG;
+    const int hy = hp / HW, hx = hp - hy * HW;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    if (hp < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+      vec16* q = reinterpret_cast<vec16*>(smem) + slot;
+      float f[KPV];
+      unpack(*q, f, T());
+#pragma unroll
+      for (int e = 0; e < KPV; ++e) {
+        const float v = fmaf(f[e], sc[e], sh[e]);
+        f[e] = prelu ? fmaxf(v, 0.f) : v;
+      }
+      vec16 o;
+      pack(o, f, T());
+      *q = o;
+    }
+  }
+}
+
 }  // namespace dc

@@ -52,6 +52,9 @@ __device__ inline void stage_tile(char* smem, const T* __restrict__ in, int ldin
 
 struct S2Args {
   int Hi, Wi, Ho, Wo, C, ncgb, ntx, nty;
+  const float* pscale;   // fused BatchNorm(+ReLU) of the producer (forward / weight gradient), or null
+  const float* pshift;
+  int prelu;
 };
 
 // ---- forward ------------------------------------------------------------------------------------------------------------
@@ -77,6 +80,10 @@ __global__ __launch_bounds__(256) void dws2_fwd_kernel(const T* __restrict__ in,
   float wk[9][KH];
   load_taps<KH>(wp, ch0, a.C, false, wk);
   __syncthreads();
+  if (a.pscale != nullptr) {
+    bn_transform_tile<T, HH, HW, CG>(smem, 2 * y0 - 1, 2 * x0 - 1, a.Hi, a.Wi, a.pscale, a.pshift, a.prelu, cg0, ngroups);
+    __syncthreads();
+  }
   if (!cok) return;
   const char* tile = smem + h * 8;
 #pragma unroll 1
@@ -247,6 +254,10 @@ __global__ __launch_bounds__(256) void dws2_wgrad_kernel(const T* __restrict__ x
     vec8 gcur[DT_PX], gnext[DT_PX];
     load_dy(0, gcur);
     __syncthreads();
+    if (a.pscale != nullptr) {
+      bn_transform_tile<T, HH, HW, CG>(smem, 2 * y0 - 1, 2 * x0 - 1, a.Hi, a.Wi, a.pscale, a.pshift, a.prelu, cg0, ngroups);
+      __syncthreads();
+    }
     if (cok) {
 #pragma unroll 1
       for (int k = 0; k < K::SPT; ++k) {
@@ -341,8 +352,9 @@ static void launch2(int mode, const S2Args& a, int N, const void* p0, int ld0, c
 // mode 0: forward (p0 = x -> out = y); mode 1: data gradient (p0 = dy, p1 = addend or null -> out = dx);
 // mode 2: weight gradient partial rows (p0 = x, p1 = dy -> slab, *rows_out rows; reduce with dw_tile_reduce)
 int launch_dw_tile_s2(int dtype, int mode, int N, int Hi, int Wi, int C, const void* p0, int ld0, const float* wp, const void* p1, int ld1,
-                      void* out, int ldout, float* slab, int* rows_out, hipStream_t st) {
+                      void* out, int ldout, float* slab, int* rows_out, hipStream_t st, const float* pscale, const float* pshift, int prelu) {
   S2Args a;
+  a.pscale = mode == 1 ? nullptr : pscale; a.pshift = pshift; a.prelu = prelu;
   a.Hi = Hi; a.Wi = Wi; a.Ho = (Hi - 1) / 2 + 1; a.Wo = (Wi - 1) / 2 + 1; a.C = C;
   a.ncgb = a.ntx = a.nty = 0;
   DC_REQUIRE((long)N * Hi * Wi < (1L << 31), "dc_dwconv: tensor too large for the tiled stride-2 path");

@@ -149,7 +149,7 @@ class Engine:
         self._keep: List[torch.Tensor] = []
         # Fusing the BatchNorm(+ReLU) into the consuming depthwise conv is implemented and tested, but measured slower at B=8
         # (55.0 vs 53.8 ms/step: the 9-tap stencil becomes VALU-heavy), so it is off by default.
-        self.fuse_bn_into_dw = os.environ.get("DC_FUSE_BN_DW", "0") != "0"
+        self.fuse_bn_into_dw = os.environ.get("DC_FUSE_BN_DW", "1") != "0"   # BN(+ReLU) applied in the consumer depthwise kernel's LDS tile
         self.mask_from_y = os.environ.get("DC_MASK_FROM_Y", "1") != "0"
 
         # ---- program containers -----------------------------------------------------------------------------
