@@ -112,6 +112,15 @@ int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, 
 /* dx = dw_backward_data(dy) [+ addend]  (addend: same shape as dx, e.g. the residual branch's gradient) */
 int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
                     const float* wp, const void* addend, int ldadd, void* dx, int lddx, void* stream);
+/* Data gradient that also takes the backward statistics of the BatchNorm(+ReLU) whose (never materialised) output fed this
+ * depthwise conv: dx as dc_dwconv_dgrad (no addend), and slab[2][rows][C] = per-tile partial sums of g and g*xhat with
+ * g = dx masked by (ybn*mscale + mshift > 0) when relu, xhat = (ybn - save_mean)*save_invstd.  rows =
+ * dc_dwconv_dgrad_bnstats_rows(...) (0: shape not served, use dc_dwconv_dgrad + dc_bn_bwd_reduce); finish with dc_bn_bwd_finalize.
+ * Replaces one full read of dx and ybn per such BatchNorm (autograd of nn.BatchNorm2d after deeplab_xception.py:65). */
+int dc_dwconv_dgrad_bnstats_rows(int dtype, int C, int stride, int dil, int N, int Hi, int Wi);
+int dc_dwconv_dgrad_bnstats(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                            const float* wp, void* dx, int lddx, const void* ybn, int ldybn, const float* save_mean,
+                            const float* save_invstd, const float* mscale, const float* mshift, int relu, float* slab, void* stream);
 size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int stride);
 int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
                     const void* dy, int lddy, void* workspace, float* grad_w, const float* pscale, const float* pshift,

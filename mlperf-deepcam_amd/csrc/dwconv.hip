@@ -6,6 +6,7 @@
 
 #include "common.h"
 #include "dwtile.h"
+#include "dwtile_common.h"
 
 namespace dc {
 
@@ -512,6 +513,32 @@ extern "C" int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int
   // gather from dy [Ho,Wo] into dx [Hi,Wi]
   return dtype == DC_BF16 ? launch_dw<bf16, 1>(dy, lddy, w, addend, ldadd, dx, lddx, N, Ho, Wo, Hi, Wi, C, stride, dil, st)
                           : launch_dw<float, 1>(dy, lddy, w, addend, ldadd, dx, lddx, N, Ho, Wo, Hi, Wi, C, stride, dil, st);
+}
+
+extern "C" int dc_dwconv_dgrad_bnstats_rows(int dtype, int C, int stride, int dil, int N, int Hi, int Wi) {
+  if (!g_dw_tile || (dtype != DC_BF16 && dtype != DC_F32) || C <= 0 || N <= 0) return 0;
+  if (stride == 1 && (dil == 1 || dil == 2)) return dw_tile_rows(dtype, C, N, Hi, Wi);
+  if (stride == 2 && dil == 1) return dw_tile_s2_dgrad_rows(dtype, C, N, Hi, Wi);
+  return 0;
+}
+
+extern "C" int dc_dwconv_dgrad_bnstats(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                       const float* w, void* dx, int lddx, const void* ybn, int ldybn, const float* save_mean,
+                                       const float* save_invstd, const float* mscale, const float* mshift, int relu, float* slab,
+                                       void* stream) {
+  if (int e = dw_check(dtype, C, stride, dil, N, Hi, Wi)) return e;
+  if (int e = dc_check_view(dy, lddy, C, dtype, "dc_dwconv_dgrad_bnstats dy")) return e;
+  if (int e = dc_check_view(dx, lddx, C, dtype, "dc_dwconv_dgrad_bnstats dx")) return e;
+  if (int e = dc_check_view(ybn, ldybn, C, dtype, "dc_dwconv_dgrad_bnstats y")) return e;
+  DC_REQUIRE(w && save_mean && save_invstd && slab, "dc_dwconv_dgrad_bnstats: null argument");
+  DC_REQUIRE(!relu || (mscale && mshift), "dc_dwconv_dgrad_bnstats: the ReLU mask needs the forward scale / shift vectors");
+  DC_REQUIRE(dc_dwconv_dgrad_bnstats_rows(dtype, C, stride, dil, N, Hi, Wi) > 0, "dc_dwconv_dgrad_bnstats: shape not served by the tiled kernels");
+  DwBnStats bs;
+  bs.y = ybn; bs.ldy = ldybn; bs.mean = save_mean; bs.invstd = save_invstd; bs.mscale = mscale; bs.mshift = mshift; bs.relu = relu ? 1 : 0;
+  bs.slab = slab; bs.rows = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1) return launch_dw_tile(dtype, dil, true, dy, lddy, w, nullptr, 0, dx, lddx, N, Hi, Wi, C, st, nullptr, nullptr, 0, &bs);
+  return launch_dw_tile_s2(dtype, 1, N, Hi, Wi, C, dy, lddy, w, nullptr, 0, dx, lddx, nullptr, nullptr, st, nullptr, nullptr, 0, &bs);
 }
 
 extern "C" size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int stride) {

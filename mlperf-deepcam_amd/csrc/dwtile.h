@@ -5,11 +5,14 @@
 
 namespace dc {
 
+struct DwBnStats;   // dwtile_common.h
+
 constexpr int DWT_MAX_ROWS = 2048;   // most partial rows the weight-gradient slab may hold
 
 int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
                    void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale = nullptr,
-                   const float* pshift = nullptr, int prelu = 0);
+                   const float* pshift = nullptr, int prelu = 0, const DwBnStats* bnstats = nullptr);
+int dw_tile_rows(int dtype, int C, int N, int H, int W);   // pixel tiles of the stride-1 kernels = slab rows of the fused BN statistics
 int launch_dw_tile_wgrad(int dtype, int dil, const void* x, int ldx, const void* dy, int lddy, float* slab, float* grad_w, int N,
                          int H, int W, int C, hipStream_t st, const float* pscale = nullptr, const float* pshift = nullptr, int prelu = 0);
 size_t dw_tile_wgrad_workspace(int C, int N, int H, int W);
@@ -20,6 +23,7 @@ int dw_tile_reduce(const float* slab, float* grad_w, int rows, int C, hipStream_
 // stride-2 kernels (dwtile_s2.hip).  mode 0 forward, 1 data gradient (p1 = addend or null), 2 weight-gradient rows into the slab
 int launch_dw_tile_s2(int dtype, int mode, int N, int Hi, int Wi, int C, const void* p0, int ld0, const float* wp, const void* p1, int ld1,
                       void* out, int ldout, float* slab, int* rows_out, hipStream_t st, const float* pscale = nullptr,
-                      const float* pshift = nullptr, int prelu = 0);
+                      const float* pshift = nullptr, int prelu = 0, const DwBnStats* bnstats = nullptr);
+int dw_tile_s2_dgrad_rows(int dtype, int C, int N, int Hi, int Wi);
 
 }  // namespace dc

@@ -65,13 +65,14 @@ template <typename T, int DIL, bool FLIP, int CG>
 __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int ldin, const float* __restrict__ wp,
                                                   const T* __restrict__ addend, int ldadd, T* __restrict__ out, int ldout, int H, int W,
                                                   int C, int ncgb, int ntx, int nty, const float* __restrict__ pscale,
-                                                  const float* __restrict__ pshift, int prelu) {
+                                                  const float* __restrict__ pshift, int prelu, const DwBnStats st) {
   typedef TileCfg<DIL, CG> K;
   constexpr int KPV = Elem<T>::kPerVec, KH = KPV / 2;
   constexpr int WC = DT_PX + 2 * DIL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = xcd_remap(blockIdx.x, gridDim.x);
   const int cgb = t % ncgb;
+  const int tile_id = t / ncgb;
   int r = t / ncgb;
   const int tx = r % ntx;
   r /= ntx;
@@ -90,16 +91,29 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
     bn_transform_tile<T, K::HH, K::HW, CG>(smem, y0 - DIL, x0 - DIL, H, W, pscale, pshift, prelu, cg0, ngroups);
     __syncthreads();
   }
-  if (!cok) return;
+  const bool stats = FLIP && st.slab != nullptr;
+  if (!cok && !stats) return;
+  BnAcc<KH> bn;
+  if (stats) bn.init(st, ch0);
 
   const char* tile = smem + h * 8;
 #pragma unroll 1
-  for (int k = 0; k < K::SPT; ++k) {
+  for (int k = 0; k < (cok ? K::SPT : 0); ++k) {
     const int q = sl + K::NSL * k;
     const int row = q / K::SPR, xs = (q % K::SPR) * DT_PX;
     const int oy = y0 + row;
     // the addend (gradient already accumulated in dx by another consumer) is requested before the stencil so that its latency
-    // hides behind the arithmetic
+    // hides behind the arithmetic; so is the BatchNorm input when the statistics ride along
+    vec8 yv[DT_PX];
+    if (stats) {
+#pragma unroll
+      for (int j = 0; j < DT_PX; ++j) {
+        const int ox = x0 + xs + j;
+        vec8 z;
+        z.w[0] = z.w[1] = 0u;
+        yv[j] = (oy < H && ox < W) ? *reinterpret_cast<const vec8*>(reinterpret_cast<const T*>(st.y) + (((size_t)n * H + oy) * W + ox) * st.ldy + ch0) : z;
+      }
+    }
     vec8 av[DT_PX];
     if (FLIP && addend != nullptr) {
 #pragma unroll
@@ -146,9 +160,19 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
           vec8 v;
           pack8(v, acc[j], T());
           *reinterpret_cast<vec8*>(out + opix * ldout + ch0) = v;
+          if (stats) {
+            float gs[KH], yf[KH];
+            unpack8(v, gs, T());
+            unpack8(yv[j], yf, T());
+            bn.add(gs, yf, st.relu);
+          }
         }
       }
     }
+  }
+  if (stats) {
+    __syncthreads();   // every thread of the workgroup gets here: the staged tile is dead
+    bn_acc_store<KH, K::NSL, CG * KPV>(reinterpret_cast<float*>(smem), bn.a, bn.b, cok, h, sl, st, tile_id, cg0 * KPV, C);
   }
 }
 
@@ -322,6 +346,8 @@ static int wgrad_tpb(const TileGrid& t) {
   return (int)tpb;
 }
 
+int dw_tile_rows(int dtype, int C, int N, int H, int W) { return tile_grid(C / (dtype == DC_BF16 ? 8 : 4), N, H, W).ntiles; }
+
 size_t dw_tile_wgrad_workspace(int C, int N, int H, int W) {
   size_t best = 0;
   for (int kpv = 4; kpv <= 8; kpv += 4) {
@@ -336,7 +362,7 @@ size_t dw_tile_wgrad_workspace(int C, int N, int H, int W) {
 
 template <typename T, int DIL, bool FLIP, int CG>
 static void launch_fwd1(const TileGrid& t, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out,
-                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu) {
+                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats& bs) {
   constexpr int LDS = TileCfg<DIL, CG>::LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
@@ -344,23 +370,27 @@ static void launch_fwd1(const TileGrid& t, const void* in, int ldin, const float
     attr_set = true;
   }
   hipLaunchKernelGGL((dwt_kernel<T, DIL, FLIP, CG>), dim3(t.ntiles * t.ncgb), dim3(256), LDS, st, (const T*)in, ldin, wp,
-                     (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu);
+                     (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs);
 }
 
 template <typename T, int DIL, bool FLIP>
 static void launch_fwd2(const TileGrid& t, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out,
-                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu) {
-  if (t.cg == 32) launch_fwd1<T, DIL, FLIP, 32>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu);
-  else if (t.cg == 16) launch_fwd1<T, DIL, FLIP, 16>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu);
-  else launch_fwd1<T, DIL, FLIP, 8>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu);
+                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats& bs) {
+  if (t.cg == 32) launch_fwd1<T, DIL, FLIP, 32>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs);
+  else if (t.cg == 16) launch_fwd1<T, DIL, FLIP, 16>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs);
+  else launch_fwd1<T, DIL, FLIP, 8>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs);
 }
 
 int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
-                   void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu) {
+                   void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu,
+                   const DwBnStats* bnstats) {
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const TileGrid t = tile_grid(C / kpv, N, H, W);
   DC_REQUIRE((long)t.ntiles * t.ncgb < (1L << 31) && (long)N * H * W < (1L << 31), "dc_dwconv: tensor too large for the tiled path");
-#define DWT(TT, D, F) launch_fwd2<TT, D, F>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu)
+  DwBnStats bs;
+  if (bnstats != nullptr) bs = *bnstats; else { bs.slab = nullptr; bs.y = nullptr; bs.ldy = 0; bs.mean = bs.invstd = bs.mscale = bs.mshift = nullptr; bs.relu = 0; bs.rows = 0; }
+  if (bs.slab != nullptr) bs.rows = t.ntiles;
+#define DWT(TT, D, F) launch_fwd2<TT, D, F>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs)
   if (dtype == DC_BF16) {
     if (dil == 1) { if (flip) DWT(bf16, 1, true); else DWT(bf16, 1, false); }
     else          { if (flip) DWT(bf16, 2, true); else DWT(bf16, 2, false); }

@@ -54,6 +54,69 @@ __device__ inline void load_taps(const float* __restrict__ wp, int ch0, int C, b
 }
 
 
+// Fused consumer of a data-gradient kernel: the BatchNorm whose (never stored) output fed this depthwise conv needs
+// sum(g) and sum(g * xhat) per channel, g = dx masked by the ReLU (recomputed from the BatchNorm input y).  The kernel that
+// produces dx takes the two sums on the way out: one slab row per pixel tile, [2][rows][C].
+struct DwBnStats {
+  const void* y;        // BatchNorm input (raw conv output), same shape as dx
+  int ldy;
+  const float* mean;
+  const float* invstd;
+  const float* mscale;  // forward scale / shift: the mask is (y*mscale + mshift > 0)
+  const float* mshift;
+  int relu;
+  float* slab;          // null: statistics off
+  int rows;
+};
+
+template <int KH>
+struct BnAcc {
+  float mu[KH], is[KH], ms[KH], mh[KH], a[KH], b[KH];
+  __device__ inline void init(const DwBnStats& st, int ch0) {
+#pragma unroll
+    for (int e = 0; e < KH; ++e) {
+      mu[e] = st.mean[ch0 + e];
+      is[e] = st.invstd[ch0 + e];
+      ms[e] = st.relu ? st.mscale[ch0 + e] : 0.f;
+      mh[e] = st.relu ? st.mshift[ch0 + e] : 0.f;
+      a[e] = b[e] = 0.f;
+    }
+  }
+  // g: the gradient values as STORED (already rounded), yv: the BatchNorm input at the same pixel
+  __device__ inline void add(const float (&g)[KH], const float (&yv)[KH], int relu) {
+#pragma unroll
+    for (int e = 0; e < KH; ++e) {
+      const float gm = (!relu || fmaf(yv[e], ms[e], mh[e]) > 0.f) ? g[e] : 0.f;
+      a[e] += gm;
+      b[e] = fmaf(gm, (yv[e] - mu[e]) * is[e], b[e]);
+    }
+  }
+};
+
+// fold the strip lanes of a workgroup through LDS and write the tile's slab row; call with ALL threads, after a barrier that
+// ends the reads of the staged tile.  red needs NSL*2*CW floats.
+template <int KH, int NSL, int CW>
+__device__ inline void bn_acc_store(float* red, const float (&a)[KH], const float (&b)[KH], bool cok, int h, int sl, const DwBnStats& st,
+                                    int tile, int c_base, int C) {
+  if (cok) {
+#pragma unroll
+    for (int e = 0; e < KH; ++e) {
+      red[(sl * 2 + 0) * CW + h * KH + e] = a[e];
+      red[(sl * 2 + 1) * CW + h * KH + e] = b[e];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * CW; i += 256) {
+    const int which = i / CW, cl = i % CW;
+    if (c_base + cl < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < NSL; ++q) s += red[(q * 2 + which) * CW + cl];
+      st.slab[((size_t)which * st.rows + tile) * C + c_base + cl] = s;
+    }
+  }
+}
+
 // Fused producer for the tiled kernels: the staged tile holds the RAW (pre-BatchNorm) conv output; every in-image element becomes
 // v = x*scale[c] + shift[c] (and ReLU) in place, the zero padding stays zero.  One pass over the LDS tile (each element once,
 // where the register-window kernels recomputed it per window position); a thread's channel group is fixed, so its 8 (4)

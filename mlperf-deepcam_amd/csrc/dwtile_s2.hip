@@ -127,13 +127,15 @@ __global__ __launch_bounds__(256) void dws2_fwd_kernel(const T* __restrict__ in,
 // ---- data gradient -------------------------------------------------------------------------------------------------------
 template <typename T, int CG>
 __global__ __launch_bounds__(256) void dws2_dgrad_kernel(const T* __restrict__ dy, int lddy, const float* __restrict__ wp,
-                                                         const T* __restrict__ addend, int ldadd, T* __restrict__ dx, int lddx, S2Args a) {
+                                                         const T* __restrict__ addend, int ldadd, T* __restrict__ dx, int lddx, S2Args a,
+                                                         const DwBnStats st) {
   typedef S2Cfg<CG, 8> K;   // tile over dx (input resolution): 8 x TW
   constexpr int KPV = Elem<T>::kPerVec, KH = KPV / 2;
   constexpr int HH = K::TH / 2 + 1, HW = K::TW / 2 + 1;   // dy tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = xcd_remap(blockIdx.x, gridDim.x);
   const int cgb = t % a.ncgb;
+  const int tile_id = t / a.ncgb;
   int r = t / a.ncgb;
   const int tx = r % a.ntx;
   r /= a.ntx;
@@ -147,13 +149,26 @@ __global__ __launch_bounds__(256) void dws2_dgrad_kernel(const T* __restrict__ d
   float wk[9][KH];
   load_taps<KH>(wp, ch0, a.C, false, wk);
   __syncthreads();
-  if (!cok) return;
+  const bool stats = st.slab != nullptr;
+  if (!cok && !stats) return;
+  BnAcc<KH> bn;
+  if (stats) bn.init(st, ch0);
   const char* tile = smem + h * 8;
 #pragma unroll 1
-  for (int k = 0; k < K::SPT; ++k) {
+  for (int k = 0; k < (cok ? K::SPT : 0); ++k) {
     const int q = sl + K::NSL * k;
     const int row = q / K::SPR, xs = (q % K::SPR) * DT_PX;   // tile-local dx row, first column of the strip (a multiple of 4)
     const int iy = y0 + row;
+    vec8 yv[DT_PX];
+    if (stats) {
+#pragma unroll
+      for (int j = 0; j < DT_PX; ++j) {
+        const int ix = x0 + xs + j;
+        vec8 z;
+        z.w[0] = z.w[1] = 0u;
+        yv[j] = (iy < a.Hi && ix < a.Wi) ? *reinterpret_cast<const vec8*>(reinterpret_cast<const T*>(st.y) + (((size_t)n * a.Hi + iy) * a.Wi + ix) * st.ldy + ch0) : z;
+      }
+    }
     vec8 av[DT_PX];
     if (addend != nullptr) {
 #pragma unroll
@@ -203,9 +218,19 @@ __global__ __launch_bounds__(256) void dws2_dgrad_kernel(const T* __restrict__ d
           vec8 v;
           pack8(v, acc[j], T());
           *reinterpret_cast<vec8*>(dx + (((size_t)n * a.Hi + iy) * a.Wi + ix) * lddx + ch0) = v;
+          if (stats) {
+            float gs[KH], yf[KH];
+            unpack8(v, gs, T());
+            unpack8(yv[j], yf, T());
+            bn.add(gs, yf, st.relu);
+          }
         }
       }
     }
+  }
+  if (stats) {
+    __syncthreads();
+    bn_acc_store<KH, K::NSL, CG * KPV>(reinterpret_cast<float*>(smem), bn.a, bn.b, cok, h, sl, st, tile_id, cg0 * KPV, a.C);
   }
 }
 
@@ -310,10 +335,12 @@ static int pick_cg(int ngroups) { return ngroups <= 8 ? 8 : ngroups <= 16 ? 16 :
 
 template <typename T, int CG>
 static void launch3(int mode, S2Args a, int N, const void* p0, int ld0, const float* wp, const void* p1, int ld1, void* out, int ldout,
-                    float* slab, int* rows_out, hipStream_t st) {
+                    float* slab, int* rows_out, hipStream_t st, DwBnStats bs) {
   constexpr int TW = 8 * (32 / CG);
   constexpr int LDS_F = lds_bytes(9, 2 * TW + 1, CG);          // forward / wgrad halo
-  constexpr int LDS_D = lds_bytes(5, TW / 2 + 1, CG);          // dgrad dy tile
+  constexpr int LDS_D0 = lds_bytes(5, TW / 2 + 1, CG);         // dgrad dy tile
+  constexpr int FOLD2 = (128 / CG) * 2 * CG * Elem<T>::kPerVec * (int)sizeof(float);   // fused BN statistics fold
+  constexpr int LDS_D = LDS_D0 > FOLD2 ? LDS_D0 : FOLD2;
   constexpr int FOLD = (128 / CG) * 9 * CG * Elem<T>::kPerVec * (int)sizeof(float);
   a.ntx = cdiv(mode == 1 ? a.Wi : a.Wo, TW);
   a.nty = cdiv(mode == 1 ? a.Hi : a.Ho, mode == 1 ? 8 : 4);
@@ -325,7 +352,9 @@ static void launch3(int mode, S2Args a, int N, const void* p0, int ld0, const fl
     hipLaunchKernelGGL((dws2_fwd_kernel<T, CG>), dim3(ntiles * a.ncgb), dim3(256), LDS_F, st, (const T*)p0, ld0, wp, (T*)out, ldout, a);
   } else if (mode == 1) {
     if (!attr[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_dgrad_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D); attr[1] = true; }
-    hipLaunchKernelGGL((dws2_dgrad_kernel<T, CG>), dim3(ntiles * a.ncgb), dim3(256), LDS_D, st, (const T*)p0, ld0, wp, (const T*)p1, ld1, (T*)out, ldout, a);
+    if (bs.slab != nullptr) bs.rows = ntiles;
+    if (rows_out) *rows_out = ntiles;
+    hipLaunchKernelGGL((dws2_dgrad_kernel<T, CG>), dim3(ntiles * a.ncgb), dim3(256), LDS_D, st, (const T*)p0, ld0, wp, (const T*)p1, ld1, (T*)out, ldout, a, bs);
   } else {
     constexpr int LDS_W = LDS_F > FOLD ? LDS_F : FOLD;
     if (!attr[2]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_wgrad_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_W); attr[2] = true; }
@@ -340,11 +369,11 @@ static void launch3(int mode, S2Args a, int N, const void* p0, int ld0, const fl
 
 template <typename T>
 static void launch2(int mode, const S2Args& a, int N, const void* p0, int ld0, const float* wp, const void* p1, int ld1, void* out,
-                    int ldout, float* slab, int* rows_out, hipStream_t st) {
+                    int ldout, float* slab, int* rows_out, hipStream_t st, const DwBnStats& bs) {
   const int cg = pick_cg(a.C / Elem<T>::kPerVec);
-  if (cg == 32) launch3<T, 32>(mode, a, N, p0, ld0, wp, p1, ld1, out, ldout, slab, rows_out, st);
-  else if (cg == 16) launch3<T, 16>(mode, a, N, p0, ld0, wp, p1, ld1, out, ldout, slab, rows_out, st);
-  else launch3<T, 8>(mode, a, N, p0, ld0, wp, p1, ld1, out, ldout, slab, rows_out, st);
+  if (cg == 32) launch3<T, 32>(mode, a, N, p0, ld0, wp, p1, ld1, out, ldout, slab, rows_out, st, bs);
+  else if (cg == 16) launch3<T, 16>(mode, a, N, p0, ld0, wp, p1, ld1, out, ldout, slab, rows_out, st, bs);
+  else launch3<T, 8>(mode, a, N, p0, ld0, wp, p1, ld1, out, ldout, slab, rows_out, st, bs);
 }
 
 }  // namespace
@@ -352,18 +381,27 @@ static void launch2(int mode, const S2Args& a, int N, const void* p0, int ld0, c
 // mode 0: forward (p0 = x -> out = y); mode 1: data gradient (p0 = dy, p1 = addend or null -> out = dx);
 // mode 2: weight gradient partial rows (p0 = x, p1 = dy -> slab, *rows_out rows; reduce with dw_tile_reduce)
 int launch_dw_tile_s2(int dtype, int mode, int N, int Hi, int Wi, int C, const void* p0, int ld0, const float* wp, const void* p1, int ld1,
-                      void* out, int ldout, float* slab, int* rows_out, hipStream_t st, const float* pscale, const float* pshift, int prelu) {
+                      void* out, int ldout, float* slab, int* rows_out, hipStream_t st, const float* pscale, const float* pshift, int prelu,
+                      const DwBnStats* bnstats) {
+  DwBnStats bs;
+  if (bnstats != nullptr && mode == 1) bs = *bnstats; else { bs.slab = nullptr; bs.y = nullptr; bs.ldy = 0; bs.mean = bs.invstd = bs.mscale = bs.mshift = nullptr; bs.relu = 0; bs.rows = 0; }
   S2Args a;
   a.pscale = mode == 1 ? nullptr : pscale; a.pshift = pshift; a.prelu = prelu;
   a.Hi = Hi; a.Wi = Wi; a.Ho = (Hi - 1) / 2 + 1; a.Wo = (Wi - 1) / 2 + 1; a.C = C;
   a.ncgb = a.ntx = a.nty = 0;
   DC_REQUIRE((long)N * Hi * Wi < (1L << 31), "dc_dwconv: tensor too large for the tiled stride-2 path");
   int rows = 0;
-  if (dtype == DC_BF16) launch2<bf16>(mode, a, N, p0, ld0, wp, p1, ld1, out, ldout, slab, &rows, st);
-  else launch2<float>(mode, a, N, p0, ld0, wp, p1, ld1, out, ldout, slab, &rows, st);
+  if (dtype == DC_BF16) launch2<bf16>(mode, a, N, p0, ld0, wp, p1, ld1, out, ldout, slab, &rows, st, bs);
+  else launch2<float>(mode, a, N, p0, ld0, wp, p1, ld1, out, ldout, slab, &rows, st, bs);
   if (rows_out) *rows_out = rows;
   DC_CHECK_LAUNCH();
   return 0;
+}
+
+// pixel tiles of the stride-2 data-gradient kernel (8 x TW tiles of the input-resolution tensor) = slab rows of its fused statistics
+int dw_tile_s2_dgrad_rows(int dtype, int C, int N, int Hi, int Wi) {
+  const int cg = pick_cg(C / (dtype == DC_BF16 ? 8 : 4));
+  return N * cdiv(Hi, 8) * cdiv(Wi, 8 * (32 / cg));
 }
 
 }  // namespace dc

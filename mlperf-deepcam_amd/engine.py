@@ -149,6 +149,7 @@ class Engine:
         self._keep: List[torch.Tensor] = []
         # Fusing the BatchNorm(+ReLU) into the consuming depthwise conv is implemented and tested, but measured slower at B=8
         # (55.0 vs 53.8 ms/step: the 9-tap stencil becomes VALU-heavy), so it is off by default.
+        self.fuse_bn_reduce = os.environ.get("DC_FUSE_BN_REDUCE", "1") != "0"   # BN backward sums taken in the consumer dw data-gradient kernel
         self.fuse_bn_into_dw = os.environ.get("DC_FUSE_BN_DW", "1") != "0"   # BN(+ReLU) applied in the consumer depthwise kernel's LDS tile
         self.mask_from_y = os.environ.get("DC_MASK_FROM_Y", "1") != "0"
 
@@ -315,12 +316,23 @@ class Engine:
             dy = y.grad
             mode = x.take_grad_mode()
             dx = x.grad
+            # the producer is a never-stored BatchNorm output and this is its only consumer: take that BatchNorm's backward
+            # sums (sum g, sum g*xhat) on the way out of the data-gradient kernel instead of re-reading dx and y for them
+            srows = lib.dc_dwconv_dgrad_bnstats_rows(self.dt, Cc, stride, dil, N, H, W) if (lazy and self.fuse_bn_reduce and mode == 0) else 0
+            if srows > 0:
+                sslab = self._f32(2 * srows * Cc)
+                x.fused_bwd = (sslab, srows)
+                mean_p, invstd_p = L.dptr(x.mean), L.dptr(x.invstd)
 
             def bwd():
                 self._on_side(lambda ws: L.call("dc_dwconv_wgrad", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, dy.ptr, dy.ld, ws, gw,
                                                 ps, psh, prelu, self._st()))
-                L.call("dc_dwconv_dgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
-                       dx.ptr, dx.ld, self._st())
+                if srows > 0:
+                    L.call("dc_dwconv_dgrad_bnstats", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr, dx.ld, src.ptr, src.ld,
+                           mean_p, invstd_p, ps, psh, prelu, L.dptr(sslab), self._st())
+                else:
+                    L.call("dc_dwconv_dgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
+                           dx.ptr, dx.ld, self._st())
             return bwd, [wname]
 
         self.bwd.append(make_bwd)
@@ -358,6 +370,8 @@ class Engine:
                 L.call("dc_bn_apply", bdt, M, Cc, y.ptr, y.ld, L.dptr(scale), L.dptr(shift), rptr(), rld, relu_i, o.ptr, o.ld, self._st())
 
         lz = LazyAct(y, scale, shift, relu, (name or bname) + ".lazy") if lazy else None
+        if lz is not None:
+            lz.mean, lz.invstd, lz.fused_bwd = mean, invstd, None
 
         self.fwd_train.append(fwd_train)
         self.fwd_eval.append(fwd_eval)
@@ -380,10 +394,14 @@ class Engine:
             optr = (lambda: None) if from_y else (lambda: o.ptr)
             old_ = 0 if from_y else o.ld
 
+            fused = lz.fused_bwd if lazy else None      # set by the consumer depthwise conv (its make_bwd ran before this one)
+            rslab, rrows = (fused[0], fused[1]) if fused is not None else (bslab, brows)
+
             def bwd():
-                L.call("dc_bn_bwd_reduce", bdt, M, Cc, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, L.dptr(mean),
-                       L.dptr(invstd), L.dptr(bslab), L.dptr(scale), L.dptr(shift), self._st())
-                L.call("dc_bn_bwd_finalize", Cc, L.dptr(bslab), brows, dgam, dbet, self._st())
+                if fused is None:
+                    L.call("dc_bn_bwd_reduce", bdt, M, Cc, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, L.dptr(mean),
+                           L.dptr(invstd), L.dptr(bslab), L.dptr(scale), L.dptr(shift), self._st())
+                L.call("dc_bn_bwd_finalize", Cc, L.dptr(rslab), rrows, dgam, dbet, self._st())
                 L.call("dc_bn_bwd_apply", bdt, M, Cc, M, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, gam, L.dptr(mean),
                        L.dptr(invstd), dgam, dbet, dy.ptr, dy.ld, g_out.ptr if g_out is not None else None,
                        g_out.ld if g_out is not None else 0, L.dptr(scale), L.dptr(shift), self._st())

@@ -331,6 +331,50 @@ def test_depthwise_tiled_matches_register_window_path():
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [c for c in DW_CASES if c[0] in ("s1", "d2", "thin64", "s2_728", "s2_64", "odd")], ids=lambda c: c[0])
+@pytest.mark.parametrize("relu", [1, 0])
+def test_depthwise_dgrad_with_fused_bn_backward_statistics(case, dtype, relu):
+    """dc_dwconv_dgrad_bnstats = dc_dwconv_dgrad (same dx, bit for bit) + the per-channel sums dc_bn_bwd_reduce would produce
+    from that dx and the BatchNorm input (mask recomputed from y), finished by dc_bn_bwd_finalize."""
+    _, Cc, stride, dil, N, H, W = case
+    dt = L.dtype_code(dtype)
+    rows = L.load().dc_dwconv_dgrad_bnstats_rows(dt, Cc, stride, dil, N, H, W)
+    if rows == 0:
+        pytest.skip("shape not served by the tiled kernels")
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    gy = q(rnd(N, Cc, Ho, Wo, seed=3), dtype)
+    ybn = q(rnd(N, Cc, H, W, seed=7), dtype)
+    wm = rnd(Cc, 1, 3, 3, seed=2, scale=1 / 3).to(dev())
+    wd = torch.empty(9 * Cc, device=dev())
+    L.call("dc_dwconv_pack_weights", Cc, vptr(wm), vptr(wd), S())
+    mean, invstd = rnd(Cc, seed=8, scale=0.2).to(dev()), (torch.rand(Cc) + 0.5).to(dev())
+    sc, sh = (torch.rand(Cc) + 0.5).to(dev()), rnd(Cc, seed=9, scale=0.3).to(dev())
+    _, gyv = to_nhwc(gy, dtype)
+    _, yv = to_nhwc(ybn, dtype, ld=Cc + 8)
+    _, gx_a = empty_nhwc(N, H, W, Cc, dtype)
+    _, gx_b = empty_nhwc(N, H, W, Cc, dtype)
+    slab = torch.full((2, rows, Cc), float("nan"), device=dev())
+    L.call("dc_dwconv_dgrad_bnstats", dt, Cc, stride, dil, N, H, W, vptr(gyv), Cc, vptr(wd), vptr(gx_a), Cc, vptr(yv), Cc + 8,
+           vptr(mean), vptr(invstd), vptr(sc), vptr(sh), relu, vptr(slab), S())
+    L.call("dc_dwconv_dgrad", dt, Cc, stride, dil, N, H, W, vptr(gyv), Cc, vptr(wd), None, 0, vptr(gx_b), Cc, S())
+    torch.cuda.synchronize()
+    assert torch.equal(gx_a, gx_b)
+    dgam, dbet = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
+    L.call("dc_bn_bwd_finalize", Cc, vptr(slab), rows, vptr(dgam), vptr(dbet), S())
+    # reference sums from the stored dx and y, as dc_bn_bwd_reduce defines them
+    M = N * H * W
+    rows2 = L.load().dc_bn_stat_rows(M)
+    slab2 = torch.empty((2, rows2, Cc), device=dev())
+    dgam2, dbet2 = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
+    L.call("dc_bn_bwd_reduce", dt, M, Cc, vptr(gx_b), Cc, vptr(yv), Cc + 8, None, 0, 2 if relu else 0, vptr(mean), vptr(invstd), vptr(slab2),
+           vptr(sc), vptr(sh), S())
+    L.call("dc_bn_bwd_finalize", Cc, vptr(slab2), rows2, vptr(dgam2), vptr(dbet2), S())
+    torch.cuda.synchronize()
+    tol = dict(rtol=2e-5, atol=2e-4 * max(1.0, float(dbet2.abs().max())))
+    assert torch.allclose(dbet, dbet2, **tol) and torch.allclose(dgam, dgam2, **tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", DW_CASES, ids=[c[0] for c in DW_CASES])
 @pytest.mark.parametrize("prelu", [1, 0])
 def test_depthwise_with_fused_bn_prologue(case, dtype, prelu):
