@@ -317,6 +317,7 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ssum[h][e] = ssq[h][e] = 0.f;
   bf16* __restrict__ yg = reinterpret_cast<bf16*>(p.y);
+  const bool do_stats = p.slab != nullptr;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll 2
@@ -344,10 +345,12 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
           unpack(v, f, bf16());
         }
         stg16(dst, v);
+        if (do_stats) {   // (uniform) the data-gradient and plain forward launches skip the BatchNorm sums
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          ssum[h][e] += f[e];
-          ssq[h][e] = fmaf(f[e], f[e], ssq[h][e]);
+          for (int e = 0; e < 8; ++e) {
+            ssum[h][e] += f[e];
+            ssq[h][e] = fmaf(f[e], f[e], ssq[h][e]);
+          }
         }
       }
     }
