@@ -73,9 +73,10 @@ class KernelTimer:
     """HIP-event timing of every launch of the two MFMA kernel families on the stream they run on:
        igemm  dc::igemm256_kernel / dc::igemm_kernel<T> / dc::tiny_gemm_kernel<T>  (dc_conv_fwd + dc_conv_dgrad: dense conv forward
               and data gradient; the library's planner picks the tile shape per layer)
-       wgrad  dc::wgrad256_kernel / dc::wgrad_dma_kernel<T>  (+ the slab reduction; dc_conv_wgrad: dense conv weight gradient)"""
+       wgrad  dc::wgrad256_kernel / dc::wgrad_dma_kernel<T>  (+ the slab reduction; dc_conv_wgrad / dc_conv_wgrad_group: dense conv
+              weight gradient; a grouped call is ONE launch of the kernel for up to four layers and counts as one)"""
 
-    FAMILY = {"dc_conv_fwd": "igemm", "dc_conv_dgrad": "igemm", "dc_conv_wgrad": "wgrad"}
+    FAMILY = {"dc_conv_fwd": "igemm", "dc_conv_dgrad": "igemm", "dc_conv_wgrad": "wgrad", "dc_conv_wgrad_group": "wgrad"}
 
     def __init__(self, lib_module):
         self.L = lib_module
@@ -93,6 +94,7 @@ class KernelTimer:
                 return timer._orig(name, *args)
             d = args[0]._obj
             N, Hi, Wi = args[1], args[2], args[3]
+            layers = args[4] if name == "dc_conv_wgrad_group" else 1      # one launch serves `layers` layers of one geometry
             k = 3 if d.transposed else d.k
             if d.transposed:
                 macs = N * Hi * Wi * d.cin * d.cout * 9
@@ -103,13 +105,13 @@ class KernelTimer:
                 macs = N * Ho * Wo * d.cin * d.cout * k * k
             esz = 2 if d.dtype == timer.L.DC_BF16 else 4
             wbytes = k * k * d.cin * d.cout * (4 if fam == "wgrad" else esz)        # the weight gradient leaves as fp32
-            timer.bytes[fam] += (N * Hi * Wi * d.cin + N * Ho * Wo * d.cout) * esz + wbytes
+            timer.bytes[fam] += layers * ((N * Hi * Wi * d.cin + N * Ho * Wo * d.cout) * esz + wbytes)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             timer._orig(name, *args)
             e1.record()
             timer.events[fam].append((e0, e1))
-            timer.flops[fam] += 2.0 * macs
+            timer.flops[fam] += 2.0 * macs * layers
 
         self.L.call = call
         return self

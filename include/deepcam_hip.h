@@ -38,6 +38,13 @@ int dc_version(void);
  * "dw_tile" 0/1, "dw_wgrad_tpb", "bn_cgw", "bn_rows": depthwise / BatchNorm kernel variants (see the .hip files). */
 int dc_set_option(const char* name, int value);
 
+/* Streams for the host runtime.  The reference leaves stream management to PyTorch/apex (its DDP overlaps the all-reduce
+ * on a side stream, train_hdf5_ddp.py:227,363); here the weight-gradient kernels run beside the backward chain on a stream
+ * of the LOWEST priority (level < 0; 0 = default, > 0 = highest), created non-blocking.  The caller owns the stream. */
+int dc_stream_create(int level, void** stream);
+int dc_stream_destroy(void* stream);
+int dc_stream_priority_range(int* least, int* greatest);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense convolution family: nn.Conv2d (k=1 or 3, stride 1|2, dilation, zero padding) and
  * nn.ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1), all lowered to one gather-form
@@ -94,6 +101,16 @@ int dc_conv_dgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, 
 size_t dc_conv_wgrad_workspace(const dc_conv_desc* d, int N, int Hi, int Wi);
 int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* dy,
                   int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream);
+
+/* The same for `count` (<= 4) layers of ONE geometry in one launch: xs / dys / grad_ws are host arrays of `count` device
+ * pointers (same ldx / lddy).  Replaces the per-layer conv_backward_weight calls autograd makes for the three pointwise
+ * convs of a middle-flow Block (deeplab_xception.py:69-122, 211-226): the layers share the launch, so each is cut into fewer,
+ * longer pixel splits.  Results are bit-identical run to run (fixed-order reduction); layers the grouped kernel does not serve
+ * are computed by `count` plain dc_conv_wgrad calls. */
+size_t dc_conv_wgrad_group_workspace(const dc_conv_desc* d, int N, int Hi, int Wi, int count);
+int dc_conv_wgrad_group(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const void* const* xs, int ldx,
+                        const void* const* dys, int lddy, void* workspace, size_t workspace_bytes,
+                        float* const* grad_ws, void* stream);
 
 /* grad_bias[c] = sum over M rows of dy (the one biased conv, deeplab_xception.py:366). */
 int dc_colsum(int dtype, long M, int C, const void* dy, int lddy, float* out, void* workspace, void* stream);

@@ -13,8 +13,10 @@ struct IgemmParams {
   GatherGeom g;
   int N, ldx, ldy;
   int ldw;     // K stride of a packed weight row: Cin rounded up to 32 elements, so every row starts on a 64-byte boundary
-  int M;       // pixels per phase = N*Qh*Qw
-  int mtiles;  // tiles per phase
+  int M;       // END of this launch's pixel range (per phase); N*Qh*Qw when the launch covers the layer
+  int m_beg;   // first pixel of this launch's range (a multiple of 256): the mixed plan of run_gather cuts a layer into a
+               // 256-tile launch over [0, m_beg') and a 128-tile launch over [m_beg', M)
+  int mtiles;  // 128-pixel tiles per phase of the WHOLE layer (= rows per phase of the statistics slab)
   int accumulate;
   const void* zero_page;   // 256 zero bytes in device memory (set by the 256-tile launcher)
 };
@@ -24,7 +26,7 @@ struct IgemmParams {
 int launch_igemm256(const IgemmParams& p, hipStream_t st);
 // workgroups the 256-tile kernel would launch for this problem
 inline long igemm256_tiles(const IgemmParams& p) {
-  return (long)((p.g.Cout + 255) / 256) * ((p.M + 255) / 256) * p.g.os * p.g.os;
+  return (long)((p.g.Cout + 255) / 256) * ((p.M - p.m_beg + 255) / 256) * p.g.os * p.g.os;
 }
 
 // thinconv.hip: the thin 3x3 stem convolutions (forward and data gradient) without LDS staging of the pixel operand

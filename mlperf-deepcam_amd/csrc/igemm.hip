@@ -112,10 +112,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + xslot;
   const int ntile_n = tile % ntn;
   const int rest = tile / ntn;
-  const int mtile = rest % p.mtiles;
-  const int phase = rest / p.mtiles;
+  const int mtl = (p.M - p.m_beg + BM - 1) / BM;   // pixel tiles of this launch
+  const int mtile = rest % mtl;
+  const int phase = rest / mtl;
   const int n0 = ntile_n * BN;
-  const int m0 = mtile * BM;
+  const int m0 = p.m_beg + mtile * BM;
   const int py = phase / g.os, px = phase % g.os;
 
   // this phase's taps -> LDS (one thread per tap; the list is already sorted by phase on the host)
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int r = 0; r < RPP; ++r) a += red[(which * RPP + r) * BN + c];
       const int rows = p.mtiles * g.os * g.os;
-      const int srow = phase * p.mtiles + mtile;
+      const int srow = phase * p.mtiles + m0 / BM;
       p.slab[((size_t)which * rows + srow) * g.Cout + n0 + c] = a;
     }
   }
@@ -472,7 +473,7 @@ static int launch_igemm2(const IgemmParams& p, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, OUT32, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(cdiv(p.g.Cout, BN) * p.mtiles * p.g.os * p.g.os);
+  dim3 grid(cdiv(p.g.Cout, BN) * cdiv(p.M - p.m_beg, BM) * p.g.os * p.g.os);
   hipLaunchKernelGGL((igemm_kernel<T, OUT32, MODE>), grid, dim3(256), lds, st, p);
   DC_CHECK_LAUNCH();
   return 0;
@@ -491,6 +492,9 @@ static int launch_igemm(const IgemmParams& p, hipStream_t st) {
 // (>= 64 steps of 32), about the same at 20-60 steps (the 728-channel layers) and 1.1-1.2 when it is short (its prologue and
 // 132 KiB epilogue are not hidden by a co-resident workgroup) -- for 4/3 of the work per round.  When both fit one round the
 // small tile (finer tail, three workgroups hiding each other's latencies) keeps the layer unless the K loop is long.
+static int g_igemm_mix = 0;        // mixed 256-tile / 128-tile plan (off: bit-equal and +6 % alone on 1536 -> 2048, but +1.5 ms per step beside the weight-gradient stream)
+static int g_mix_cus = 256;        // workgroup slots of a 256-tile round (tuning / test switch: a small value cuts small problems)
+static int g_mix_tail_pct = 40;    // largest fill of the last round (percent) that is handed to the 128-tile kernel
 static int g_rel256 = 0;   // 0: model below; otherwise cost of a 256-tile round in percent of a 128-tile round (tuning switch)
 static bool igemm256_wins(const IgemmParams& p) {
   const long t128 = (long)cdiv(p.g.Cout, BN) * p.mtiles * p.g.os * p.g.os;
@@ -526,6 +530,7 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   const long M = (long)N * p.g.Qh * p.g.Qw;
   DC_REQUIRE(M < (1L << 31) - BM, "dc_conv: too many pixels for 32-bit indexing");
   p.M = (int)M;
+  p.m_beg = 0;
   p.mtiles = cdiv(M, BM);
   p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
@@ -538,7 +543,29 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   if (g_thin_fwd && thin_fwd_eligible(p.g, d->dtype, bias != nullptr, accumulate, out32))
     return launch_thin_fwd(p.g, N, in, ldin, w, p.ldw, out, ldout, slab, p.mtiles * p.g.os * p.g.os, st);
   if (d->dtype == DC_BF16 && !out32 && g_igemm256 != 0) {
-    if (g_igemm256 == 2 || igemm256_wins(p)) return launch_igemm256(p, st);
+    if (g_igemm256 == 2 || igemm256_wins(p)) {
+      // Mixed plan.  The 256-tile kernel holds one workgroup per CU, so a layer of r.f rounds pays for r+1 (the 728 -> 728
+      // pointwise layers at B = 8: 324 tiles on 256 CUs).  When the last round is mostly empty the pixel range is cut at a
+      // 256-pixel boundary: whole rounds of 256-tiles, then the rest on the 128-tile kernel, whose workgroups are a quarter
+      // of the work, three to a CU, and all resident at once.  Same arithmetic per output element in both kernels (bit-equal
+      // outputs, scripts/gemm256_bench.py), and both write the statistics slab by 128-pixel row, so the cut is invisible.
+      const long ntn = cdiv(p.g.Cout, 256), phases = (long)p.g.os * p.g.os;
+      const long t256 = igemm256_tiles(p);
+      const long full = t256 / g_mix_cus, tail = t256 % g_mix_cus;
+      if (g_igemm_mix && full >= 1 && tail > 0 && tail * 100 <= (long)g_mix_cus * g_mix_tail_pct) {
+        const long rows_a = full * g_mix_cus / (ntn * phases);          // 256-pixel row tiles that fit the whole rounds
+        const long m_cut = rows_a * 256;
+        const long small = (long)cdiv(p.g.Cout, BN) * cdiv(M - m_cut, BM) * phases;
+        if (rows_a >= 1 && m_cut < M && small <= 3L * g_mix_cus) {
+          IgemmParams a = p, b = p;
+          a.M = (int)m_cut;
+          b.m_beg = (int)m_cut;
+          if (int e = launch_igemm256(a, st)) return e;
+          return launch_igemm<bf16, false>(b, st);
+        }
+      }
+      return launch_igemm256(p, st);
+    }
   }
   if (d->dtype == DC_BF16) return out32 ? launch_igemm<bf16, true>(p, st) : launch_igemm<bf16, false>(p, st);
   return launch_igemm<float, false>(p, st);
@@ -671,6 +698,7 @@ extern "C" int dc_wgrad_set_target_blocks(int n);
 extern "C" int dc_wgrad_set_mode(int m);
 extern "C" int dc_wgrad_set_256(int m);
 extern "C" int dc_wgrad_set_thin(int m);
+extern "C" int dc_wgrad_set_slots(int n);
 extern "C" int dc_head_set_fused(int v);
 extern "C" int dc_dw_set_option(const char* name, int value);
 extern "C" int dc_bn_set_option(const char* name, int value);
@@ -683,10 +711,18 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm256") == 0) { g_igemm256 = value; return 0; }
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }
+  if (name != nullptr && strcmp(name, "igemm_mix") == 0) { g_igemm_mix = value != 0; return 0; }
+  if (name != nullptr && strcmp(name, "igemm_mix_cus") == 0) {
+    if (value < 1) return dc_fail("dc_set_option: igemm_mix_cus must be positive", __FILE__, __LINE__);
+    g_mix_cus = value;
+    return 0;
+  }
+  if (name != nullptr && strcmp(name, "igemm_mix_tail") == 0) { g_mix_tail_pct = value; return 0; }
   if (name != nullptr && strcmp(name, "wgrad_target_blocks") == 0) return dc_wgrad_set_target_blocks(value);
   if (name != nullptr && strcmp(name, "wgrad_mode") == 0) return dc_wgrad_set_mode(value);
   if (name != nullptr && strcmp(name, "wgrad256") == 0) return dc_wgrad_set_256(value);
   if (name != nullptr && strcmp(name, "thin_wgrad") == 0) return dc_wgrad_set_thin(value);
+  if (name != nullptr && strcmp(name, "wgrad256_slots") == 0) return dc_wgrad_set_slots(value);
   if (name != nullptr && strcmp(name, "head_fused") == 0) return dc_head_set_fused(value);
   if (name != nullptr && dc_dw_set_option(name, value) == 0) return 0;
   if (name != nullptr && dc_bn_set_option(name, value) == 0) return 0;

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
 
   // XCD-aware tile order (see igemm.hip): consecutive tiles of an XCD walk the channel tiles of one pixel tile first
   const int ntn = (g.Cout + TN - 1) / TN;
-  const int mt256 = (p.M + TM - 1) / TM;
+  const int mt256 = (p.M - p.m_beg + TM - 1) / TM;
   const int nwg = gridDim.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + xslot;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
   const int rest = tile / ntn;
   const int mtile = rest % mt256;
   const int phase = rest / mt256;
-  const int n0 = ntile_n * TN, m0 = mtile * TM;
+  const int n0 = ntile_n * TN, m0 = p.m_beg + mtile * TM;
   const int py = phase / g.os, px = phase % g.os;
 
   const int tap_beg = g.phase_beg[phase], ntap = g.phase_beg[phase + 1] - tap_beg;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
     for (int i = tid; i < 4 * TN; i += 512) {
       const int c = i % TN, hw = i / TN;       // hw = half*2 + which
       const int h = hw >> 1, which = hw & 1;
-      const int mt128 = mtile * 2 + h;
+      const int mt128 = (m0 >> 7) + h;
       if (n0 + c < g.Cout && mt128 < p.mtiles) {
         float a = 0.f;
 #pragma unroll

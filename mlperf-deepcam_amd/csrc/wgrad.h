@@ -17,8 +17,12 @@ struct WgradParams {
 
 // 256 x 256 tile kernel (bf16 only): split plan and launch.  The slab layout [split][tap][Co][Ci] is the same as the small
 // kernel's, so wgrad_reduce_kernel serves both.
-void wgrad256_plan(const GatherGeom& g, long M, int* splits, int* chunk);
-int launch_wgrad256(const WgradParams& p, hipStream_t st);
+constexpr int WG_MAXGROUP = 4;   // layers of one geometry per grouped launch (dc_conv_wgrad_group)
+void wgrad256_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group = 1);
+void wgrad256_set_slots(int n);   // workgroups a launch of the 256-tile kernel aims for (default 256 = one per CU)
+// group > 1: xs / dys / slabs hold `group` pointers (entry 0 repeats p.x / p.dy / p.slab)
+int launch_wgrad256(const WgradParams& p, hipStream_t st, int group = 1, const void* const* xs = nullptr, const void* const* dys = nullptr,
+                    float* const* slabs = nullptr);
 
 // thinconv.hip: all nine taps of the 16->32 (stride 2) and 32->64 stem convolutions in one pass over x and dy
 bool thin_wgrad_eligible(const dc_conv_desc& d, int Hi, int Wi);

@@ -436,6 +436,12 @@ extern "C" int dc_wgrad_set_256(int m) {
   return 0;
 }
 
+extern "C" int dc_wgrad_set_slots(int n) {
+  if (n < 1) return dc_fail("dc_set_option: wgrad256_slots must be positive", __FILE__, __LINE__);
+  wgrad256_set_slots(n);
+  return 0;
+}
+
 extern "C" int dc_wgrad_set_thin(int m) {
   g_thin_wgrad = m ? 1 : 0;
   return 0;
@@ -448,6 +454,15 @@ static bool wgrad256_wins(const GatherGeom& g) {
   const long pad256 = (long)cdiv(g.Cin, 256) * 256 * cdiv(g.Cout, 256) * 256;
   const long pad128 = (long)cdiv(g.Cin, 128) * 128 * cdiv(g.Cout, 128) * 128;
   return pad256 * 100 <= pad128 * 115;   // at most 15 % more padded work than the small tile
+}
+
+static int launch_wgrad_reduce(const float* slab, float* grad_w, int splits, const GatherGeom& g, int transposed, hipStream_t st) {
+  const long per = (long)g.Cout * g.Cin;
+  const long work = (per >> 2) * g.ntaps;
+  const int blocks = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, grad_w, splits, g.ntaps, g.Cout, g.Cin, transposed);
+  DC_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int dc_wgrad_set_target_blocks(int n) {
@@ -519,10 +534,55 @@ extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const
     hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), lds, st, p);
   }
   DC_CHECK_LAUNCH();
-  const long per = (long)p.g.Cout * p.g.Cin;
-  const long work = (per >> 2) * p.g.ntaps;
-  const int blocks = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, grad_w, p.splits, p.g.ntaps, p.g.Cout, p.g.Cin, d->transposed);
-  DC_CHECK_LAUNCH();
+  return launch_wgrad_reduce(p.slab, grad_w, p.splits, p.g, d->transposed, st);
+}
+
+// Grouped form: `count` layers of ONE geometry (same descriptor, extents and row strides) in one launch of the 256-tile
+// kernel and one reduction per layer.  Layers the 256-tile kernel does not serve fall back to `count` plain calls.
+static bool wgrad_group_eligible(const dc_conv_desc& d, const GatherGeom& g, int Hi, int Wi) {
+  return d.dtype == DC_BF16 && !(g_thin_wgrad && thin_wgrad_eligible(d, Hi, Wi)) && wgrad256_wins(g);
+}
+
+extern "C" size_t dc_conv_wgrad_group_workspace(const dc_conv_desc* d, int N, int Hi, int Wi, int count) {
+  GatherGeom g;
+  if (d == nullptr || count < 1 || !build_geom(*d, Hi, Wi, kFwd, &g)) return 0;
+  const size_t single = dc_conv_wgrad_workspace(d, N, Hi, Wi);
+  if (count == 1 || count > WG_MAXGROUP || !wgrad_group_eligible(*d, g, Hi, Wi)) return single;
+  int splits, chunk;
+  wgrad256_plan(g, (long)N * g.Qh * g.Qw, &splits, &chunk, count);
+  const size_t grouped = (size_t)count * splits * g.ntaps * g.Cout * g.Cin * sizeof(float);
+  return grouped > single ? grouped : single;
+}
+
+extern "C" int dc_conv_wgrad_group(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const void* const* xs, int ldx,
+                                   const void* const* dys, int lddy, void* workspace, size_t workspace_bytes, float* const* grad_ws,
+                                   void* stream) {
+  DC_REQUIRE(d != nullptr && xs != nullptr && dys != nullptr && grad_ws != nullptr && workspace != nullptr, "dc_conv_wgrad_group: null argument");
+  DC_REQUIRE(count >= 1, "dc_conv_wgrad_group: empty group");
+  WgradParams p;
+  if (!build_geom(*d, Hi, Wi, kFwd, &p.g)) return dc_fail("dc_conv_wgrad_group: unsupported geometry", __FILE__, __LINE__);
+  if (count == 1 || count > WG_MAXGROUP || !wgrad_group_eligible(*d, p.g, Hi, Wi)) {
+    for (int l = 0; l < count; ++l)
+      if (int e = dc_conv_wgrad(d, N, Hi, Wi, xs[l], ldx, dys[l], lddy, workspace, workspace_bytes, grad_ws[l], stream)) return e;
+    return 0;
+  }
+  for (int l = 0; l < count; ++l) {
+    DC_REQUIRE(grad_ws[l] != nullptr, "dc_conv_wgrad_group: null gradient pointer");
+    if (int e = dc_check_view(xs[l], ldx, p.g.Cin, d->dtype, "dc_conv_wgrad_group x")) return e;
+    if (int e = dc_check_view(dys[l], lddy, p.g.Cout, d->dtype, "dc_conv_wgrad_group dy")) return e;
+  }
+  const long M = (long)N * p.g.Qh * p.g.Qw;
+  DC_REQUIRE(M < (1L << 31) - 256, "dc_conv_wgrad_group: too many pixels for 32-bit indexing");
+  wgrad256_plan(p.g, M, &p.splits, &p.chunk, count);
+  const size_t per_layer = (size_t)p.splits * p.g.ntaps * p.g.Cout * p.g.Cin;   // floats
+  DC_REQUIRE(workspace_bytes >= per_layer * count * sizeof(float), "dc_conv_wgrad_group: workspace too small");
+  float* slabs[WG_MAXGROUP];
+  for (int l = 0; l < count; ++l) slabs[l] = (float*)workspace + per_layer * l;
+  p.x = xs[0]; p.dy = dys[0]; p.slab = slabs[0];
+  p.N = N; p.ldx = ldx; p.lddy = lddy; p.M = (int)M;
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = launch_wgrad256(p, st, count, xs, dys, slabs)) return e;
+  for (int l = 0; l < count; ++l)
+    if (int e = launch_wgrad_reduce(slabs[l], grad_ws[l], p.splits, p.g, d->transposed, st)) return e;
   return 0;
 }

@@ -32,9 +32,16 @@ typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef __attribute__((address_space(3))) short4v lds_s4;
 
+// Up to WG_MAXGROUP layers of identical geometry share one launch (dc_conv_wgrad_group): the pixel axis of each is then cut
+// into fewer, longer splits (the 728 -> 728 pointwise layers at B = 8: 9 tiles x 28 splits of 31 stages each alone,
+// 27 tiles x 9 splits of 96 stages as a group of three), which divides both the prologue/epilogue share of a workgroup and
+// the fp32 slab traffic (256 KiB per workgroup, written once and read once by the reduction) by the group size.
 struct Wgrad256Params {
-  WgradParams w;
+  WgradParams w;           // w.x / w.dy / w.slab belong to layer 0
   const void* zero_page;
+  const void* xs[WG_MAXGROUP - 1];    // layers 1..: the same geometry, strides and split plan
+  const void* dys[WG_MAXGROUP - 1];
+  float* slabs[WG_MAXGROUP - 1];
 };
 
 __device__ inline int swz_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -66,14 +73,27 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_)
   tile /= nci;
   const int co0 = (tile % nco) * WT;
   tile /= nco;
-  const int tapi = tile % g.ntaps, split = tile / g.ntaps;
+  const int tapi = tile % g.ntaps;
+  tile /= g.ntaps;
+  const int split = tile % p.splits, layer = tile / p.splits;   // layer: wave-uniform index into the group
   const Tap tap = g.taps[tapi];
   const int py = tap.phase / g.os, px = tap.phase % g.os;
   const int mbeg = split * p.chunk;
   const int mend = min(p.M, mbeg + p.chunk);
   const int steps = mend > mbeg ? (mend - mbeg + WBP - 1) / WBP : 0;
-  const bf16* __restrict__ xg = reinterpret_cast<const bf16*>(p.x);
-  const bf16* __restrict__ dg = reinterpret_cast<const bf16*>(p.dy);
+  // a chain of scalar selects, not an indexed read: indexing the by-value argument struct would move it to scratch memory
+  const void* xsel = p.x;
+  const void* dsel = p.dy;
+  float* ssel = p.slab;
+#pragma unroll
+  for (int l = 1; l < WG_MAXGROUP; ++l)
+    if (layer == l) {
+      xsel = pp_.xs[l - 1];
+      dsel = pp_.dys[l - 1];
+      ssel = pp_.slabs[l - 1];
+    }
+  const bf16* __restrict__ xg = reinterpret_cast<const bf16*>(xsel);
+  const bf16* __restrict__ dg = reinterpret_cast<const bf16*>(dsel);
   const uintptr_t zp = (uintptr_t)pp_.zero_page;
 
   // ---- DMA bookkeeping: instruction j = 2*wave + i of a stage fills pixel rows 2j, 2j+1 (1 KiB); lane -> (row, 16-byte slot).
@@ -230,7 +250,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_)
   else k_loop(std::false_type{});
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the fills of the last three slots
 
-  float* out = p.slab + ((size_t)split * g.ntaps + tap.widx) * g.Cout * g.Cin;
+  float* out = ssel + ((size_t)split * g.ntaps + tap.widx) * g.Cout * g.Cin;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -247,10 +267,12 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_)
 
 }  // namespace
 
-// About one workgroup per CU; every split at least four stages long.
-void wgrad256_plan(const GatherGeom& g, long M, int* splits, int* chunk) {
-  const long tiles = (long)cdiv(g.Cin, WT) * cdiv(g.Cout, WT) * g.ntaps;
-  long want = 256 / tiles;
+// About one workgroup per CU (g_wgrad256_slots of them); every split at least four stages long.  `group` layers share the launch.
+static int g_wgrad256_slots = 192;   // 64 CUs stay free for the HBM-bound kernels of the backward chain (step -0.3 ms vs 256)
+void wgrad256_set_slots(int n) { g_wgrad256_slots = n; }
+void wgrad256_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group) {
+  const long tiles = (long)cdiv(g.Cin, WT) * cdiv(g.Cout, WT) * g.ntaps * group;
+  long want = g_wgrad256_slots / tiles;
   const long maxs = (M + 4 * WBP - 1) / (4 * WBP);
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -260,7 +282,7 @@ void wgrad256_plan(const GatherGeom& g, long M, int* splits, int* chunk) {
   *splits = (int)((M + c - 1) / c);
 }
 
-int launch_wgrad256(const WgradParams& p, hipStream_t st) {
+int launch_wgrad256(const WgradParams& p, hipStream_t st, int group, const void* const* xs, const void* const* dys, float* const* slabs) {
   const size_t lds = (size_t)WNST * WSTAGE;
   static bool attr_set = false;
   static const void* zero_dev = nullptr;
@@ -275,7 +297,13 @@ int launch_wgrad256(const WgradParams& p, hipStream_t st) {
   Wgrad256Params pp;
   pp.w = p;
   pp.zero_page = zero_dev;
-  const long blocks = (long)cdiv(p.g.Cin, WT) * cdiv(p.g.Cout, WT) * p.g.ntaps * p.splits;
+  if (group < 1 || group > WG_MAXGROUP) return dc_fail("launch_wgrad256: group size out of range", __FILE__, __LINE__);
+  for (int l = 1; l < WG_MAXGROUP; ++l) {
+    pp.xs[l - 1] = l < group ? xs[l] : nullptr;
+    pp.dys[l - 1] = l < group ? dys[l] : nullptr;
+    pp.slabs[l - 1] = l < group ? slabs[l] : nullptr;
+  }
+  const long blocks = (long)cdiv(p.g.Cin, WT) * cdiv(p.g.Cout, WT) * p.g.ntaps * p.splits * group;
   hipLaunchKernelGGL(wgrad256_kernel, dim3((unsigned)blocks), dim3(512), lds, st, pp);
   DC_CHECK_LAUNCH();
   return 0;

@@ -152,6 +152,12 @@ class Engine:
         self.fuse_bn_reduce = os.environ.get("DC_FUSE_BN_REDUCE", "1") != "0"   # BN backward sums taken in the consumer dw data-gradient kernel
         self.fuse_bn_into_dw = os.environ.get("DC_FUSE_BN_DW", "1") != "0"   # BN(+ReLU) applied in the consumer depthwise kernel's LDS tile
         self.mask_from_y = os.environ.get("DC_MASK_FROM_Y", "1") != "0"
+        self.wgrad_group = max(1, min(4, int(os.environ.get("DC_WGRAD_GROUP", "1"))))   # layers per grouped weight-gradient launch
+        self._wg_recs: List[dict] = []
+        self.shift_side = os.environ.get("DC_SIDE_SCHEDULE", "eager") == "shift"   # complementary pairing of the two streams
+        self._side_deferred: List = []
+        self._deferred_names: List[str] = []
+        self._ready_now: List[str] = []
 
         # ---- program containers -----------------------------------------------------------------------------
         self.fwd_train: List[Callable[[], None]] = []
@@ -178,10 +184,21 @@ class Engine:
         # Weight gradients are off the critical path of backward (nothing downstream reads them until the optimizer) and
         # are MFMA-bound, while the chain they branch off (BN backward, depthwise data gradient) is HBM-bound: they run
         # on a side HIP stream with a private workspace and overlap it.  backward() joins the streams at the end.
-        self.side = torch.cuda.Stream(device=self.device)
+        # DC_SIDE_PRIORITY=low puts the weight gradients on a lowest-priority HIP stream (dc_stream_create); measured the same
+        # step time as a plain stream (41.3-41.6 ms): workgroups are not preempted, so priority only orders the dispatch.
+        self._side_raw = None
+        if os.environ.get("DC_SIDE_PRIORITY", "normal") == "low":
+            raw = C.c_void_p()
+            with torch.cuda.device(self.device):
+                L.call("dc_stream_create", -1, C.byref(raw))
+            self._side_raw = raw
+            self.side = torch.cuda.ExternalStream(raw.value, device=self.device)
+        else:
+            self.side = torch.cuda.Stream(device=self.device)
         self.workspace2 = torch.empty(max(self.ws_bytes, 256), dtype=torch.uint8, device=self.device)
         self.use_side_stream = os.environ.get("DC_SIDE_STREAM", "1") != "0"
         self.on_grad_ready: Optional[Callable[[List[str]], None]] = None
+        self._debug_skip_side = os.environ.get("DC_DEBUG_SKIP_SIDE", "0") == "1"
 
     # ------------------------------------------------------------------------------------------------ helpers
     def pptr(self, name: str) -> C.c_void_p:
@@ -215,12 +232,26 @@ class Engine:
 
     def _on_side(self, fn: Callable[[C.c_void_p], None]) -> None:
         """Run fn(workspace_ptr) on the side stream, ordered after everything enqueued so far on the current stream."""
+        if self._debug_skip_side:      # timing experiments only (DC_DEBUG_SKIP_SIDE=1): the weight gradients are NOT computed
+            return
         if not self.use_side_stream:
             fn(self._wsptr())
             return
         self.side.wait_event(torch.cuda.current_stream().record_event())
         with torch.cuda.stream(self.side):
             fn(C.c_void_p(self.workspace2.data_ptr()))
+
+    def _flush_deferred(self) -> None:
+        """Submit the deferred depthwise weight gradients to the side stream, ordered behind the main stream's current position.
+        Backward alternates HBM-bound kernels (BatchNorm backward, depthwise data gradient) and MFMA-bound ones (dense data
+        gradient) on the main stream; a weight gradient submitted the moment its operands exist meets a kernel of its OWN kind
+        there (pointwise weight gradient beside pointwise data gradient, depthwise beside depthwise) and the two take turns on the
+        same resource.  Deferred by half a unit they meet the other kind."""
+        if self._side_deferred:
+            pending, self._side_deferred = self._side_deferred, []
+            for fn, names in pending:
+                self._on_side(fn)
+                self._ready_now += names
 
     @staticmethod
     def _st():
@@ -275,10 +306,34 @@ class Engine:
             if bias:
                 self._need_ws(lib.dc_colsum_workspace(y.M, cout))
 
+            # Weight gradients of consecutive layers of ONE geometry (the 728 -> 728 pointwise convs of the middle flow) are
+            # deferred and launched together (dc_conv_wgrad_group): _group_wgrads() fixes the roles once the program is resolved.
+            rec = {"key": (dt, d.k, stride, pad, dil, d.transposed, x.C, cout, N, H, W, x.ld, dy.ld), "d": d, "x": x, "dy": dy,
+                   "gw": gw, "wname": wname, "ready": ready, "role": "solo", "group": None, "bias": bool(bias)}
+            self._wg_recs.append(rec)
+
+            def wgrad():
+                if rec["role"] == "defer":
+                    return
+                if rec["role"] == "solo":
+                    self._on_side(lambda ws: L.call("dc_conv_wgrad", C.byref(d), N, H, W, x.ptr, x.ld, dy.ptr, dy.ld, ws, wsb, gw, self._st()))
+                    return
+                cnt, xs, dys, gws, gbytes = rec["group"]
+                self._on_side(lambda ws: L.call("dc_conv_wgrad_group", C.byref(d), N, H, W, cnt, xs, x.ld, dys, dy.ld, ws, gbytes, gws, self._st()))
+
             def bwd():
                 if bias:
                     L.call("dc_colsum", dt, y.M, cout, dy.ptr, dy.ld, self.gptr(bias), self._wsptr(), self._st())
-                self._on_side(lambda ws: L.call("dc_conv_wgrad", C.byref(d), N, H, W, x.ptr, x.ld, dy.ptr, dy.ld, ws, wsb, gw, self._st()))
+                if self.shift_side:
+                    # complementary pairing (see _flush_deferred): the deferred depthwise weight gradients (HBM-bound) start beside
+                    # this MFMA-bound data gradient; this layer's own MFMA-bound weight gradient is submitted behind the data
+                    # gradient, so it runs beside the HBM-bound kernels that follow on the main stream
+                    self._flush_deferred()
+                    if need_dx:
+                        L.call("dc_conv_dgrad", C.byref(d), N, H, W, dy.ptr, dy.ld, L.dptr(wb), dx.ptr, dx.ld, mode, self._st())
+                    wgrad()
+                    return
+                wgrad()
                 if need_dx:
                     L.call("dc_conv_dgrad", C.byref(d), N, H, W, dy.ptr, dy.ld, L.dptr(wb), dx.ptr, dx.ld, mode, self._st())
             return bwd, ready
@@ -324,15 +379,23 @@ class Engine:
                 x.fused_bwd = (sslab, srows)
                 mean_p, invstd_p = L.dptr(x.mean), L.dptr(x.invstd)
 
+            def dw_wgrad(ws):
+                L.call("dc_dwconv_wgrad", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, dy.ptr, dy.ld, ws, gw, ps, psh, prelu, self._st())
+
             def bwd():
-                self._on_side(lambda ws: L.call("dc_dwconv_wgrad", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, dy.ptr, dy.ld, ws, gw,
-                                                ps, psh, prelu, self._st()))
+                if self.shift_side:
+                    self._side_deferred.append((dw_wgrad, [wname]))
+                else:
+                    self._on_side(dw_wgrad)
                 if srows > 0:
                     L.call("dc_dwconv_dgrad_bnstats", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr, dx.ld, src.ptr, src.ld,
                            mean_p, invstd_p, ps, psh, prelu, L.dptr(sslab), self._st())
                 else:
                     L.call("dc_dwconv_dgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
                            dx.ptr, dx.ld, self._st())
+            if self.shift_side:
+                self._deferred_names.append(wname)
+                return bwd, []
             return bwd, [wname]
 
         self.bwd.append(make_bwd)
@@ -592,8 +655,40 @@ class Engine:
             fn, ready = mk()
             self.bwd.append(fn)
             self.grad_ready.append(ready)
-        seen = [n for r in self.grad_ready for n in r]
+        self._group_wgrads()
+        seen = [n for r in self.grad_ready for n in r] + self._deferred_names
         assert sorted(seen) == sorted(self.layout.params), "every parameter must receive its gradient exactly once"
+
+    def _group_wgrads(self) -> None:
+        """Runs of consecutive dense-conv weight gradients with one geometry (in backward order) become groups of up to
+        `wgrad_group` layers: all but the last member defer, the last one launches the group and reports every member's
+        gradient as ready (on_grad_ready feeds the all-reduce buckets)."""
+        lib = L.load()
+        G = self.wgrad_group
+        recs = self._wg_recs            # make_bwd ran in backward order, so this list is in execution order
+        i = 0
+        while G > 1 and i < len(recs):
+            j = i
+            while j + 1 < len(recs) and j + 1 - i < G and recs[j + 1]["key"] == recs[i]["key"] and not recs[j + 1]["bias"]:
+                j += 1
+            r0 = recs[i]
+            if j > i and not r0["bias"] and self.dt == L.DC_BF16 and r0["key"][0] == L.DC_BF16:
+                members = recs[i:j + 1]
+                cnt = len(members)
+                d, x = r0["d"], r0["x"]
+                gbytes = lib.dc_conv_wgrad_group_workspace(C.byref(d), x.N, x.H, x.W, cnt)
+                self._need_ws(gbytes)
+                xs = (C.c_void_p * cnt)(*[m["x"].ptr.value for m in members])
+                dys = (C.c_void_p * cnt)(*[m["dy"].ptr.value for m in members])
+                gws = (C.c_void_p * cnt)(*[m["gw"].value for m in members])
+                last = members[-1]
+                for m in members[:-1]:
+                    m["role"] = "defer"
+                    m["ready"].remove(m["wname"])
+                    last["ready"].append(m["wname"])
+                last["role"] = "flush"
+                last["group"] = (cnt, xs, dys, gws, gbytes)
+            i = j + 1
 
     # ------------------------------------------------------------------------------------------------ execution
     def pack_weights(self) -> None:
@@ -641,7 +736,14 @@ class Engine:
         cb = self.on_grad_ready
         for op, ready in zip(self.bwd, self.grad_ready):
             op()
+            if self._ready_now:           # gradients whose (deferred) kernels this op has just submitted
+                ready, self._ready_now = ready + self._ready_now, []
             if cb is not None and ready:
+                cb(ready)
+        self._flush_deferred()
+        if self._ready_now:
+            ready, self._ready_now = self._ready_now, []
+            if cb is not None:
                 cb(ready)
         if self.use_side_stream:
             torch.cuda.current_stream().wait_stream(self.side)

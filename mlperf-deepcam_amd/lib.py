@@ -36,6 +36,9 @@ _SIGS = {
     "dc_last_error": (C.c_char_p, []),
     "dc_version": (I, []),
     "dc_set_option": (I, [C.c_char_p, I]),
+    "dc_stream_create": (I, [I, P]),
+    "dc_stream_destroy": (I, [P]),
+    "dc_stream_priority_range": (I, [P, P]),
     "dc_conv_out_hw": (I, [CD, I, I, C.POINTER(I), C.POINTER(I)]),
     "dc_conv_packed_elems": (I, [CD, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "dc_conv_pack_weights": (I, [CD, P, P, P, P]),
@@ -46,6 +49,8 @@ _SIGS = {
     "dc_conv_dgrad": (I, [CD, I, I, I, P, I, P, P, I, I, P]),
     "dc_conv_wgrad_workspace": (SZ, [CD, I, I, I]),
     "dc_conv_wgrad": (I, [CD, I, I, I, P, I, P, I, P, SZ, P, P]),
+    "dc_conv_wgrad_group_workspace": (SZ, [CD, I, I, I, I]),
+    "dc_conv_wgrad_group": (I, [CD, I, I, I, I, P, I, P, I, P, SZ, P, P]),
     "dc_colsum": (I, [I, L, I, P, I, P, P, P]),
     "dc_colsum_workspace": (SZ, [L, I]),
     "dc_dwconv_pack_weights": (I, [I, P, P, P]),

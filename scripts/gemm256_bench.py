@@ -9,7 +9,7 @@ r32 = lambda c: (c + 31) // 32 * 32
 shapes = [(1, 1, 0,  1, 0, 728,  728,  8, 48,  72), (1, 1, 0, 1, 0, 728, 1024, 8, 48, 72), (1, 1, 0, 1, 0, 1536, 2048, 8, 48, 72),
           (3, 1, 6,  6, 0, 2048, 256,  8, 48,  72), (1, 1, 0, 1, 0, 1280, 256, 8, 48, 72),
           (3, 1, 1,  1, 0, 256,  256,  8, 192, 288), (3, 1, 1, 1, 0, 304, 256, 8, 192, 288), (1, 1, 0, 1, 0, 256, 256, 8, 192, 288),
-          (3, 2, 1,  1, 1, 256,  256,  8, 96,  144), (1, 1, 0, 1, 0, 728, 728, 8, 96, 144), (1, 1, 0, 1, 0, 128, 128, 8, 384, 576)]
+          (3, 2, 1,  1, 1, 256,  256,  8, 96,  144), (3, 2, 1, 1, 1, 256, 256, 8, 192, 288), (3, 2, 1, 1, 1, 256, 256, 8, 48, 72), (1, 1, 0, 1, 0, 2048, 256, 8, 48, 72), (1, 1, 0, 1, 0, 728, 728, 8, 96, 144), (1, 1, 0, 1, 0, 128, 128, 8, 384, 576)]
 lib = L.load()
 for (k, s, p, d, tr, cin, cout, N, H, W) in shapes:
     desc = L.ConvDesc(L.DC_BF16, k, s, p, d, tr, cin, cout)

@@ -196,6 +196,117 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     assert_close(gw.cpu(), gw_ref, dtype, f32=3e-4, bf16=1e-2)
 
 
+MIX_CASES = [
+    # name, k, stride, pad, dil, transposed, cin, cout, N, H, W, cus, tail_pct
+    ("pw_3_tiles_on_2", 1, 1, 0, 1, 0, 64, 256, 2, 20, 16, 2, 60),          # 640 px: 512 on the 256-tile kernel, 128 on the small one
+    ("pw728_ragged", 1, 1, 0, 1, 0, 728, 728, 3, 19, 17, 4, 80),            # 969 px x 3 channel tiles = 12 tiles on 4 "CUs" + ragged rest
+    ("dense3x3", 3, 1, 1, 1, 0, 96, 256, 2, 24, 20, 3, 70),                 # halo taps across the cut
+    ("convT_phases", 3, 2, 1, 1, 1, 256, 256, 2, 16, 12, 3, 70),            # four sub-pixel phases, each cut at the same pixel
+]
+
+
+@pytest.mark.parametrize("case", MIX_CASES, ids=[c[0] for c in MIX_CASES])
+def test_conv_mixed_tile_plan_is_invisible(case):
+    """run_gather's mixed plan (whole rounds on the 256-tile kernel, the rest on the 128-tile kernel) gives the same bits as the
+    single-kernel launch: outputs, BatchNorm statistics slab, data gradient, also in accumulate mode."""
+    name, k, stride, pad, dil, tr, cin, cout, N, H, W, cus, pct = case
+    dtype = torch.bfloat16
+    d = desc(dtype, k, stride, pad, dil, tr, cin, cout)
+    kk = 3 if tr else k
+    wshape = (cin, cout, kk, kk) if tr else (cout, cin, kk, kk)
+    x = q(rnd(N, cin, H, W, seed=1), dtype)
+    w = rnd(*wshape, seed=2, scale=(cin * kk * kk) ** -0.5)
+    Ho, Wo = C.c_int(), C.c_int()
+    L.call("dc_conv_out_hw", C.byref(d), H, W, C.byref(Ho), C.byref(Wo))
+    Ho, Wo = Ho.value, Wo.value
+    yref = conv_ref(x, q(w, dtype), None, k, stride, pad, dil, tr)
+    gy = q(rnd(N, cout, Ho, Wo, seed=3), dtype)
+    nwf, nwb = C.c_size_t(), C.c_size_t()
+    L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
+    wf = torch.empty(nwf.value, dtype=dtype, device=dev())
+    wb = torch.empty(nwb.value, dtype=dtype, device=dev())
+    L.call("dc_conv_pack_weights", C.byref(d), vptr(w.to(dev())), vptr(wf), vptr(wb), S())
+    _, xv = to_nhwc(x, dtype, ld=cin + 16, off=8)
+    _, gyv = to_nhwc(gy, dtype)
+    rows = L.load().dc_conv_stat_rows(C.byref(d), N, H, W)
+    got = []
+    try:
+        L.call("dc_set_option", b"igemm256", 2)
+        L.call("dc_set_option", b"igemm_mix_cus", cus)
+        L.call("dc_set_option", b"igemm_mix_tail", pct)
+        for mix in (0, 1):
+            L.call("dc_set_option", b"igemm_mix", mix)
+            ybuf, yv = empty_nhwc(N, Ho, Wo, cout, dtype, ld=cout + 24, off=16)
+            slab = torch.full((2, rows, cout), float("nan"), device=dev())
+            L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, vptr(slab), 0, S())
+            L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, None, 1, S())
+            _, gxv = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
+            L.call("dc_conv_dgrad", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(gxv), cin + 8, 0, S())
+            torch.cuda.synchronize()
+            assert torch.isnan(ybuf[..., :16].float()).all() and torch.isnan(ybuf[..., 16 + cout:].float()).all()
+            got.append((from_nhwc(yv), slab.cpu(), from_nhwc(gxv)))
+    finally:
+        L.call("dc_set_option", b"igemm256", 1)
+        L.call("dc_set_option", b"igemm_mix", 1)
+        L.call("dc_set_option", b"igemm_mix_cus", 256)
+        L.call("dc_set_option", b"igemm_mix_tail", 40)
+    assert_close(got[1][0], 2 * yref, dtype, bf16=4e-2)
+    assert not torch.isnan(got[1][1]).any()
+    for a, b in zip(got[0], got[1]):
+        assert torch.equal(a, b)
+
+
+GROUP_CASES = [
+    # name, k, stride, pad, dil, transposed, cin, cout, N, H, W, layers
+    ("pw728_x3", 1, 1, 0, 1, 0, 728, 728, 2, 24, 20, 3),       # the middle-flow Block: three pointwise convs, one launch
+    ("pw728_x4", 1, 1, 0, 1, 0, 728, 728, 3, 17, 13, 4),       # ragged pixel count, the largest group
+    ("dense3x3_x2", 3, 1, 1, 1, 0, 256, 256, 2, 10, 12, 2),
+    ("thin_x2_falls_back", 1, 1, 0, 1, 0, 64, 48, 2, 9, 7, 2),  # not served by the 256-tile kernel: plain calls
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", GROUP_CASES, ids=[c[0] for c in GROUP_CASES])
+def test_conv_wgrad_group(case, dtype):
+    """dc_conv_wgrad_group == `layers` independent conv_backward_weight calls (fp32 falls back to the per-layer path)."""
+    name, k, stride, pad, dil, tr, cin, cout, N, H, W, layers = case
+    d = desc(dtype, k, stride, pad, dil, tr, cin, cout)
+    wshape = (cout, cin, k, k)
+    Ho, Wo = C.c_int(), C.c_int()
+    L.call("dc_conv_out_hw", C.byref(d), H, W, C.byref(Ho), C.byref(Wo))
+    Ho, Wo = Ho.value, Wo.value
+    xs, gys, refs, keep = [], [], [], []
+    for l in range(layers):
+        x = q(rnd(N, cin, H, W, seed=10 + l), dtype)
+        gy = q(rnd(N, cout, Ho, Wo, seed=20 + l), dtype)
+        wr = torch.zeros(wshape, requires_grad=True)
+        yref = F.conv2d(x, wr, None, stride, pad, dil)
+        refs.append(torch.autograd.grad(yref, wr, gy)[0])
+        xb, xv = to_nhwc(x, dtype, ld=cin + 16, off=8)
+        gb, gyv = to_nhwc(gy, dtype)
+        keep += [xb, gb]
+        xs.append(xv)
+        gys.append(gyv)
+    lib = L.load()
+    wsb = lib.dc_conv_wgrad_group_workspace(C.byref(d), N, H, W, layers)
+    assert wsb >= lib.dc_conv_wgrad_workspace(C.byref(d), N, H, W)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev())
+    gws = [torch.full(wshape, float("nan"), device=dev()) for _ in range(layers)]
+    pa = lambda ts: (C.c_void_p * layers)(*[t.data_ptr() for t in ts])
+    L.call("dc_conv_wgrad_group", C.byref(d), N, H, W, layers, pa(xs), cin + 16, pa(gys), cout, vptr(ws), wsb, pa(gws), S())
+    torch.cuda.synchronize()
+    for l in range(layers):
+        assert_close(gws[l].cpu(), refs[l], dtype, f32=3e-4, bf16=1e-2)
+    # deterministic: a second run gives the same bits
+    gws2 = [torch.full(wshape, float("nan"), device=dev()) for _ in range(layers)]
+    L.call("dc_conv_wgrad_group", C.byref(d), N, H, W, layers, pa(xs), cin + 16, pa(gys), cout, vptr(ws), wsb, pa(gws2), S())
+    torch.cuda.synchronize()
+    for l in range(layers):
+        assert torch.equal(gws[l], gws2[l])
+    with pytest.raises(L.DeepcamHipError):
+        L.call("dc_conv_wgrad_group", C.byref(d), N, H, W, layers, pa(xs), cin + 16, pa(gys), cout, vptr(ws), 16, pa(gws), S())
+
+
 def test_conv_rejects_bad_arguments():
     d = desc(torch.bfloat16, 5, 1, 0, 1, 0, 64, 64)
     x = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device=dev())
