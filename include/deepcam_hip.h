@@ -248,7 +248,9 @@ int dc_adam_step(int kind, long n, float* p, const float* g, float* m, float* v,
                  float beta1, float beta2, float eps, float weight_decay, const int* step_dev, float grad_scale,
                  void* stream);
 /* LAMB: tensor t occupies [offsets[t], offsets[t+1]) of the arena (device int64[ntensors+1]).
- * workspace: 4-byte words [3*ntensors + 4] (global norm, per-tensor norms, chunk plan) */
+ * workspace: dc_lamb_workspace_words(ntensors, n) 4-byte words (partial sums of the global norm, chunk plan, per-chunk
+ * norms).  No atomics: the update is bit-identical from run to run. */
+size_t dc_lamb_workspace_words(int ntensors, long n);
 int dc_lamb_step(int ntensors, const int64_t* offsets_dev, long n, float* p, const float* g, float* m, float* v,
                  const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                  const int* step_dev, float max_grad_norm, float grad_scale, float* workspace, void* stream);

@@ -124,7 +124,11 @@ __global__ __launch_bounds__(256) void adam_kernel(int kind, long n, float* __re
   }
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* __restrict__ g, float scale, float* out) {
+// Sum of squares of the scaled gradient arena, in two deterministic stages: SUMSQ_BLOCKS partial sums here, their fixed-order
+// total in every workgroup of lamb_stage1_kernel (the first version added the partials with atomicAdd: the clip factor then
+// differed in the last bit from run to run, and this network amplifies a 1e-7 perturbation into 1e-3 of the loss in ten steps).
+constexpr int SUMSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* __restrict__ g, float scale, float* __restrict__ partial) {
   __shared__ float s[4];
   float a = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -134,7 +138,19 @@ __global__ __launch_bounds__(256) void sumsq_kernel(long n, const float* __restr
   a = wave_sum(a);
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, s[0] + s[1] + s[2] + s[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+// fixed-order sum of `count` floats by one 256-thread workgroup (double accumulation); every thread returns the total
+__device__ inline double block_sum_fixed(const float* __restrict__ v, int count, int stride, double* sh) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < count; i += 256) a += (double)v[(size_t)i * stride];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  const double t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return t;
 }
 
 // LAMB works on fixed-size chunks that never straddle a tensor: a tensor of n elements owns ceil(n / LAMB_CHUNK) consecutive
@@ -169,20 +185,21 @@ __device__ inline bool lamb_locate(const int64_t* __restrict__ offs, const int* 
   return true;
 }
 
-// stage 1: moments, update direction u (written over g), per-tensor ||w||^2 and ||u||^2
+// stage 1: moments, update direction u (written over g), per-CHUNK ||w||^2 and ||u||^2 (part[chunk][2], no atomics)
 __global__ __launch_bounds__(256) void lamb_stage1_kernel(const int64_t* __restrict__ offs, const int* __restrict__ chunk_prefix,
                                                           int ntensors, float* __restrict__ p, float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, float beta1, float beta2,
                                                           float eps, float wd, const int* step_dev, float max_grad_norm,
-                                                          float grad_scale, float* ws) {
+                                                          float grad_scale, const float* __restrict__ gpartial, float* __restrict__ part) {
   __shared__ float s[2][4];
+  __shared__ double sh[4];
   int t;
   long beg, end;
   if (!lamb_locate(offs, chunk_prefix, ntensors, t, beg, end)) return;
   const int step = *step_dev;
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
-  const float gnorm = sqrtf(ws[0]);
+  const float gnorm = (float)sqrt(block_sum_fixed(gpartial, SUMSQ_BLOCKS, 1, sh));
   const float clip = gnorm > max_grad_norm ? gnorm / max_grad_norm : 1.f;
   const float gs = grad_scale / clip;
   float wn = 0.f, un = 0.f;
@@ -206,18 +223,22 @@ __global__ __launch_bounds__(256) void lamb_stage1_kernel(const int64_t* __restr
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&ws[2 + 2 * t], s[0][0] + s[0][1] + s[0][2] + s[0][3]);
-    atomicAdd(&ws[3 + 2 * t], s[1][0] + s[1][1] + s[1][2] + s[1][3]);
+    part[2 * (size_t)blockIdx.x] = (s[0][0] + s[0][1]) + (s[0][2] + s[0][3]);
+    part[2 * (size_t)blockIdx.x + 1] = (s[1][0] + s[1][1]) + (s[1][2] + s[1][3]);
   }
 }
 
+// stage 2: every workgroup adds the chunk sums of its tensor in the same fixed order (at most ~1200 chunks), then updates its chunk
 __global__ __launch_bounds__(256) void lamb_stage2_kernel(const int64_t* __restrict__ offs, const int* __restrict__ chunk_prefix,
                                                           int ntensors, float* __restrict__ p, const float* __restrict__ u,
-                                                          const float* lr_dev, const float* __restrict__ ws) {
+                                                          const float* lr_dev, const float* __restrict__ part) {
+  __shared__ double sh[4];
   int t;
   long beg, end;
   if (!lamb_locate(offs, chunk_prefix, ntensors, t, beg, end)) return;
-  const float wn = sqrtf(ws[2 + 2 * t]), un = sqrtf(ws[3 + 2 * t]);
+  const int c0 = chunk_prefix[t], nc = chunk_prefix[t + 1] - c0;
+  const float wn = (float)sqrt(block_sum_fixed(part + 2 * (size_t)c0, nc, 2, sh));
+  const float un = (float)sqrt(block_sum_fixed(part + 2 * (size_t)c0 + 1, nc, 2, sh));
   const float ratio = (wn > 0.f && un > 0.f) ? wn / un : 1.f;
   const float a = *lr_dev * ratio;
   for (long i = beg + threadIdx.x; i < end; i += 256) p[i] = fmaf(-a, u[i], p[i]);
@@ -309,27 +330,32 @@ extern "C" int dc_adam_step(int kind, long n, float* p, const float* g, float* m
   return 0;
 }
 
+extern "C" size_t dc_lamb_workspace_words(int ntensors, long n) {
+  return (size_t)SUMSQ_BLOCKS + (size_t)ntensors + 1 + 2 * (size_t)(n / LAMB_CHUNK + ntensors);
+}
+
 extern "C" int dc_lamb_step(int ntensors, const int64_t* offsets_dev, long n, float* p, const float* g, float* m,
                             float* v, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                             const int* step_dev, float max_grad_norm, float grad_scale, float* workspace, void* stream) {
   DC_REQUIRE(ntensors > 0 && offsets_dev && p && g && m && v && lr_dev && step_dev && workspace && n > 0, "dc_lamb_step: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, sizeof(float) * (2 * (size_t)ntensors + 2), st);
-  if (e != hipSuccess) return dc_set_error(e, __FILE__, __LINE__);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, st, n, g, grad_scale, workspace);
+  const long max_chunks = n / LAMB_CHUNK + ntensors;   // every tensor rounds up by less than one chunk
+  DC_REQUIRE(max_chunks < (1L << 30), "dc_lamb_step: arena too large");
+  // workspace words: [SUMSQ_BLOCKS] gradient partial sums | [ntensors + 1] chunk plan | [2 * max_chunks] per-chunk norms
+  float* gpartial = workspace;
+  int* chunk_prefix = reinterpret_cast<int*>(workspace + SUMSQ_BLOCKS);
+  float* part = workspace + SUMSQ_BLOCKS + ntensors + 1;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, n, g, grad_scale, gpartial);
   DC_CHECK_LAUNCH();
   // the update direction is staged in the gradient arena (it is dead after this step)
   float* gw = const_cast<float*>(g);
-  int* chunk_prefix = reinterpret_cast<int*>(workspace + 2 * (size_t)ntensors + 2);
   hipLaunchKernelGGL(lamb_plan_kernel, dim3(1), dim3(64), 0, st, offsets_dev, ntensors, chunk_prefix);
   DC_CHECK_LAUNCH();
-  const long max_chunks = n / LAMB_CHUNK + ntensors;   // every tensor rounds up by less than one chunk
-  DC_REQUIRE(max_chunks < (1L << 31), "dc_lamb_step: arena too large");
   hipLaunchKernelGGL(lamb_stage1_kernel, dim3((unsigned)max_chunks), dim3(256), 0, st, offsets_dev, chunk_prefix, ntensors, p, gw, m,
-                     v, beta1, beta2, eps, weight_decay, step_dev, max_grad_norm, grad_scale, workspace);
+                     v, beta1, beta2, eps, weight_decay, step_dev, max_grad_norm, grad_scale, gpartial, part);
   DC_CHECK_LAUNCH();
   hipLaunchKernelGGL(lamb_stage2_kernel, dim3((unsigned)max_chunks), dim3(256), 0, st, offsets_dev, chunk_prefix, ntensors, p, gw,
-                     lr_dev, workspace);
+                     lr_dev, part);
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -85,6 +85,7 @@ _SIGS = {
     "dc_sum_hw": (I, [I, I, I, I, P, I, P, P]),
     "dc_copy_view": (I, [I, L, I, P, I, P, I, P]),
     "dc_adam_step": (I, [I, L, P, P, P, P, P, F, F, F, F, P, F, P]),
+    "dc_lamb_workspace_words": (SZ, [I, C.c_long]),
     "dc_lamb_step": (I, [I, P, L, P, P, P, P, P, F, F, F, F, P, F, F, P, P]),
 }
 EXPORTS = sorted(_SIGS)

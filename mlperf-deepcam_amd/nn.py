@@ -281,7 +281,7 @@ class ArenaOptimizer:
         self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self._offsets = torch.tensor(lay.offsets(), dtype=torch.int64, device=dev)
-        self._lamb_ws = torch.zeros(3 * len(lay.params) + 4, dtype=torch.float32, device=dev)
+        self._lamb_ws = torch.zeros(L.load().dc_lamb_workspace_words(len(lay.params), lay.n_params), dtype=torch.float32, device=dev)
         self.state = {}
 
     def zero_grad(self, set_to_none: bool = True):

@@ -804,7 +804,7 @@ def test_lamb_matches_oracle():
     m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
     lr = torch.tensor([1e-2], device=dev())
     step = torch.zeros(1, dtype=torch.int32, device=dev())
-    ws = torch.empty(3 * len(sizes) + 4, device=dev())
+    ws = torch.full((L.load().dc_lamb_workspace_words(len(sizes), n),), float("nan"), device=dev())
     od = torch.from_numpy(offs).to(dev())
     for s in range(1, 4):
         gs = g / s
@@ -815,3 +815,25 @@ def test_lamb_matches_oracle():
                1.0, 1.0, vptr(ws), S())
         torch.cuda.synchronize()
         np.testing.assert_allclose(p.cpu().numpy(), torch.cat(cpu_p).numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_lamb_is_bit_reproducible():
+    """No atomics in the norms: the same step from the same state gives the same bits (many chunks per tensor, odd sizes)."""
+    sizes = [300000, 7, 4096, 1234567, 10001]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offs[-1])
+    p0, g = rnd(n, seed=1).to(dev()), rnd(n, seed=2, scale=3.0).to(dev())
+    od = torch.from_numpy(offs).to(dev())
+    lr = torch.tensor([1e-2], device=dev())
+    step = torch.ones(1, dtype=torch.int32, device=dev())
+    outs = []
+    for _ in range(3):
+        p, gd = p0.clone(), g.clone()
+        m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+        ws = torch.full((L.load().dc_lamb_workspace_words(len(sizes), n),), float("nan"), device=dev())
+        L.call("dc_lamb_step", len(sizes), vptr(od), n, vptr(p), vptr(gd), vptr(m), vptr(v), vptr(lr), 0.9, 0.999, 1e-6, 1e-2, vptr(step),
+               1.0, 1.0, vptr(ws), S())
+        torch.cuda.synchronize()
+        assert torch.isfinite(p).all()
+        outs.append(p)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -209,3 +209,30 @@ def test_golden_full_size_step0(golden_dir, dtype, tol):
         got = float(eng.grad_view(k).double().abs().sum())
         assert got == pytest.approx(d["abs"], rel=5e-3 if dtype == torch.float32 else 0.5), k
     assert torch.isfinite(eng.grads).all()
+
+
+@pytest.mark.parametrize("optname", ["LAMB", "AdamW"])
+def test_train_step_is_bit_reproducible(optname):
+    """Two independently built models, the same batch, three steps (weight gradients on the side stream): no kernel that feeds
+    the update uses an order-dependent reduction, so parameters, BatchNorm buffers and IoU agree bit for bit.  (The network amplifies a 1e-7
+    perturbation into 1e-3 of the loss within ten steps, so anything less would show up as diverging loss curves.)"""
+    x, y = make_inputs(4, 96, 160)
+    dev = torch.device("cuda", 0)
+
+    def run():
+        net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=torch.bfloat16, seed=333)
+        net.materialize(4, 96, 160)
+        net.train()
+        opt = dnn.make_optimizer(optname, net, 1e-3, 1e-8, 1e-2)
+        step = dnn.TrainStep(net, opt, olm.class_weights(-0.125), 4, 96, 160, with_metrics=True)
+        out = []
+        for _ in range(3):
+            step(x.to(dev), y.to(dev))
+            torch.cuda.synchronize()
+            out.append((step.loss(), step.iou(), net.engine.params.clone(), net.engine.buffers.clone()))
+        return out
+
+    a, b = run(), run()
+    for (la, ia, pa, ba), (lb, ib, pb, bb) in zip(a, b):
+        assert abs(la - lb) <= 1e-12 * abs(la) and ia == ib      # the reported loss is a double-precision atomic sum (1e-16 jitter)
+        assert torch.equal(pa, pb) and torch.equal(ba, bb)
