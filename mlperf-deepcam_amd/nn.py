@@ -278,6 +278,7 @@ class ArenaOptimizer:
         self.grad_scale = 1.0
         self._lr_host = torch.zeros(1, dtype=torch.float32).pin_memory()
         self._step_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._scalars_copied = None
         self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self._offsets = torch.tensor(lay.offsets(), dtype=torch.int64, device=dev)
@@ -289,11 +290,18 @@ class ArenaOptimizer:
         return None
 
     def sync_scalars(self) -> None:
-        """Push lr / step count to the device scalars the kernels read (keeps a captured hipGraph in step)."""
+        """Push lr / step count to the device scalars the kernels read (keeps a captured hipGraph in step).
+        The copies are asynchronous and the host enqueues steps ahead of the GPU, so the pinned source words must not be
+        rewritten before the copy that reads them has run: wait for the previous copy's event first.  (Without the wait the
+        device could pick up the step count of a LATER step -- wrong bias corrections, different from run to run.)  The host
+        can still run one whole step ahead."""
+        if self._scalars_copied is not None:
+            self._scalars_copied.synchronize()
         self._lr_host[0] = float(self.param_groups[0]["lr"])
         self._step_host[0] = self.step_count
         self.lr_dev.copy_(self._lr_host, non_blocking=True)
         self.step_dev.copy_(self._step_host, non_blocking=True)
+        self._scalars_copied = torch.cuda.current_stream().record_event()
 
     def launch(self) -> None:
         g = self.param_groups[0]

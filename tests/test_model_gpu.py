@@ -236,3 +236,28 @@ def test_train_step_is_bit_reproducible(optname):
     for (la, ia, pa, ba), (lb, ib, pb, bb) in zip(a, b):
         assert abs(la - lb) <= 1e-12 * abs(la) and ia == ib      # the reported loss is a double-precision atomic sum (1e-16 jitter)
         assert torch.equal(pa, pb) and torch.equal(ba, bb)
+
+
+def test_steps_enqueued_ahead_match_synchronised_steps():
+    """The host may enqueue steps far ahead of the GPU (bench.py does): the optimizer's device scalars (lr, step count) must be
+    the ones of THEIR step.  Six steps enqueued back to back == six steps with a device synchronisation after each."""
+    B, H, W = 4, 192, 288
+    x, y = make_inputs(B, H, W)
+    dev = torch.device("cuda", 0)
+    xd, yd = x.to(dev), y.to(dev)
+
+    def run(sync_each):
+        net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=torch.bfloat16, seed=333)
+        net.materialize(B, H, W)
+        net.train()
+        opt = dnn.make_optimizer("LAMB", net, 1e-3, 1e-8, 1e-2)
+        step = dnn.TrainStep(net, opt, olm.class_weights(-0.125), B, H, W)
+        for _ in range(6):
+            step(xd, yd)
+            if sync_each:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return net.engine.params.clone(), opt.m.clone(), opt.v.clone()
+
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a, b)
