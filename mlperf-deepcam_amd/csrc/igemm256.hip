@@ -55,6 +55,18 @@ __device__ unsigned long long* dc_stamp_buf256 = nullptr;
 
 __device__ inline int swz64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 1) & 3)) << 4); }
 
+// ---- helpers of the register epilogue ---------------------------------------------------------------------------------------
+// lane ^ 16 exchange (the two 16-lane rows of a 32-lane half swap): ds_swizzle in bit-mask mode, no LDS memory involved
+__device__ inline uint32_t swap_rows16(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); }
+// sum over the 16 lanes of a DPP row (xor 1, xor 2, half mirror, mirror): every lane ends with the same bits
+__device__ inline float row_sum16(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
 __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_tap = reinterpret_cast<int*>(smem + MAIN_BYTES);
@@ -280,6 +292,108 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
     o[7] = (unsigned long long)steps;
   }
 #endif
+  if (p.reg_epilogue) {
+    // ---- epilogue from the accumulator registers (no LDS, no workgroup barrier) -------------------------------------------
+    // A lane holds, per MFMA tile (i, j), channels fg*4 .. +3 of channel block i for pixel fr of pixel block j: 8 bytes.  Lanes
+    // l and l ^ 16 (fg and fg ^ 1) trade halves so that the even-fg lane keeps 8 consecutive channels of block i and the odd-fg
+    // lane 8 consecutive channels of block i + 1: 16-byte stores, 64 contiguous bytes per pixel and store instruction (the
+    // LDS epilogue stores whole 512-byte rows but costs 13 k of a 63 k-cycle 23-stage tile: scripts/igemm_stamps.py).
+    // BatchNorm sums of the STORED values: over the lane's 8 pixels in registers, over the 16 pixel lanes by DPP; the wave's
+    // 128 pixels x 64 channels are exactly its segment of one slab row.
+    const bool odd = fg & 1;
+    bf16* __restrict__ yg = reinterpret_cast<bf16*>(p.y);
+    const bool do_stats = p.slab != nullptr;
+    size_t opix[8];
+    bool pok[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = m0 + grp * 128 + j * 16 + fr;
+      pok[j] = m < p.M;
+      opix[j] = (size_t)m;
+      if (g.os != 1) {
+        const int mm = pok[j] ? m : 0;
+        const int n = fast_div(mm, g.div_hw);
+        const int rem = mm - n * (g.Qh * g.Qw);
+        const int qy = fast_div(rem, g.div_w), qx = rem - qy * g.Qw;
+        opix[j] = (size_t)(n * g.Hout + qy * g.os + py) * g.Wout + qx * g.os + px;
+      }
+    }
+    float st[2][2][8];   // [channel-block pair][sum, sum of squares][channel]
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int i0 = 2 * pr;
+      const int chl = wc * 64 + (i0 + (odd ? 1 : 0)) * 16 + (fg >> 1) * 8;   // first of this lane's 8 channels after the trade
+      const int ch0 = n0 + chl;
+      const bool chok = ch0 < g.Cout;                                        // Cout is a multiple of 8: all or nothing
+      float ba[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};      // bias of the channels this lane COMPUTED
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ca = n0 + wc * 64 + i0 * 16 + fg * 4 + r, cb = ca + 16;
+          if (ca < g.Cout) ba[r] = p.bias[ca];
+          if (cb < g.Cout) bb[r] = p.bias[cb];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) st[pr][0][e] = st[pr][1][e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        uint32_t a0 = pack2_bf16(acc[i0][j][0] + ba[0], acc[i0][j][1] + ba[1]);
+        uint32_t a1 = pack2_bf16(acc[i0][j][2] + ba[2], acc[i0][j][3] + ba[3]);
+        uint32_t b0 = pack2_bf16(acc[i0 + 1][j][0] + bb[0], acc[i0 + 1][j][1] + bb[1]);
+        uint32_t b1 = pack2_bf16(acc[i0 + 1][j][2] + bb[2], acc[i0 + 1][j][3] + bb[3]);
+        const uint32_t r0 = swap_rows16(odd ? a0 : b0), r1 = swap_rows16(odd ? a1 : b1);
+        vec16 v;
+        v.w[0] = odd ? r0 : a0;
+        v.w[1] = odd ? r1 : a1;
+        v.w[2] = odd ? b0 : r0;
+        v.w[3] = odd ? b1 : r1;
+        if (pok[j] && chok) {
+          bf16* dst = yg + opix[j] * p.ldy + ch0;
+          float f[8];
+          unpack(v, f, bf16());
+          if (p.accumulate) {
+            float o[8];
+            unpack(ldg16(dst), o, bf16());
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += o[e];
+            pack(v, f, bf16());
+            unpack(v, f, bf16());
+          }
+          stg16(dst, v);
+          if (do_stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              st[pr][0][e] += f[e];
+              st[pr][1][e] = fmaf(f[e], f[e], st[pr][1][e]);
+            }
+          }
+        }
+      }
+    }
+    if (do_stats) {
+      const int rows = p.mtiles * g.os * g.os;
+      const int mt128 = (m0 >> 7) + grp;
+      // value idx = pr*16 + which*8 + e; lane fr of a row writes idx = fr and idx = fr + 16 (i.e. pair 0 and pair 1)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        float mine = 0.f;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float t = row_sum16(st[pr][w][e]);
+            if (fr == w * 8 + e) mine = t;
+          }
+        const int which = fr >> 3, e = fr & 7;
+        const int c = n0 + wc * 64 + (2 * pr + (odd ? 1 : 0)) * 16 + (fg >> 1) * 8 + e;
+        if (c < g.Cout && mt128 < p.mtiles)
+          p.slab[((size_t)which * rows + phase * p.mtiles + mt128) * g.Cout + c] = mine;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // LDS-DMA fills of the last slots must land before the LDS is released
+    return;
+  }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the zero-page fills of the last three slots
   __builtin_amdgcn_s_barrier();
 
@@ -396,6 +510,13 @@ extern "C" int dc_debug_stamp_buf256(void* buf) {
 }
 #endif
 
+// 0: epilogue through an LDS C tile (512-byte rows), 1: from the accumulator registers (A/B switch "igemm256_epi").  Measured
+// the same per step (41.0 vs 41.1 ms) and per layer within +-4 % (worse by 13 % on the HBM-bound 256 -> 256 pointwise layer at
+// 192 x 288): the 13 k cycles the stamps show for the epilogue of a 23-stage tile are the write burst of 256 workgroups
+// finishing together (32 MB at HBM speed), not LDS or instruction time.
+static int g_reg_epilogue = 0;
+void igemm256_set_epilogue(int v) { g_reg_epilogue = v ? 1 : 0; }
+
 int launch_igemm256(const IgemmParams& p_in, hipStream_t st) {
   const size_t lds = (size_t)MAIN_BYTES + 128;
   static bool attr_set = false;
@@ -410,6 +531,7 @@ int launch_igemm256(const IgemmParams& p_in, hipStream_t st) {
   }
   IgemmParams p = p_in;
   p.zero_page = zero_dev;
+  p.reg_epilogue = g_reg_epilogue;
   hipLaunchKernelGGL(igemm256_kernel, dim3((unsigned)igemm256_tiles(p)), dim3(512), lds, st, p);
   DC_CHECK_LAUNCH();
   return 0;

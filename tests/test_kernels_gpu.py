@@ -96,6 +96,19 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_256_tile_kernel_register_epilogue(case):
+    """The 256-tile kernel with the epilogue from the accumulator registers (lane-pair exchange, 16-byte stores, BatchNorm sums
+    by DPP row reductions), an A/B switch: same outputs, statistics equal up to the order of the additions."""
+    L.call("dc_set_option", b"igemm256", 2)
+    L.call("dc_set_option", b"igemm256_epi", 1)
+    try:
+        test_conv_fwd_dgrad_wgrad(case, torch.bfloat16)
+    finally:
+        L.call("dc_set_option", b"igemm256", 1)
+        L.call("dc_set_option", b"igemm256_epi", 0)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv_256_tile_kernel(case):
     """The eight-wave 256 x 256 tile kernel (forced on every eligible call) passes the same checks as the 128 x 128 one."""
     L.call("dc_set_option", b"igemm256", 2)
@@ -252,8 +265,9 @@ def test_conv_mixed_tile_plan_is_invisible(case):
         L.call("dc_set_option", b"igemm_mix_tail", 40)
     assert_close(got[1][0], 2 * yref, dtype, bf16=4e-2)
     assert not torch.isnan(got[1][1]).any()
-    for a, b in zip(got[0], got[1]):
-        assert torch.equal(a, b)
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][2], got[1][2])       # outputs and data gradient: same bits
+    # the statistics rows past the cut come from the other kernel, which adds the same stored values in another order
+    np.testing.assert_allclose(got[0][1].numpy(), got[1][1].numpy(), rtol=2e-5, atol=1e-4)
 
 
 GROUP_CASES = [
