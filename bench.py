@@ -22,6 +22,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FLOP_PER_SAMPLE = 1963.97e9      # conv fwd + dgrad + wgrad, 2*MAC, BASELINE.md section 2
+ENCODER_FLOP_PER_SAMPLE = 934.9e9   # the Xception encoder's share, forward + backward
 PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}
 CLASS_FREQ = (0.986267818390377, 0.0004578708870701058, 0.01327431072255291)
 
@@ -222,6 +223,22 @@ def main():
     side = eng.use_side_stream
     eng.use_side_stream = False                  # second pass: every kernel alone on the GPU (standalone kernel efficiency)
     fams_alone = timed_pass()
+    # third pass, same serial mode: the Xception encoder region on its own (forward up to the ASPP, backward from the point where
+    # the gradient re-enters the encoder), ALL its kernels: convs, depthwise, BatchNorm.  north_star quotes its roofline target
+    # (40 % of the bf16 MFMA peak) on this region.
+    enc = None
+    if rank == 0:
+        eng.region_marks = []
+    for _ in range(nroof):
+        step(x, y)
+    if rank == 0:
+        torch.cuda.synchronize()
+        ev = eng.region_marks
+        eng.region_marks = None
+        per = [dict(ev[i:i + 4]) for i in range(0, len(ev) - len(ev) % 4, 4)]
+        t_fwd = sum(m["fwd_begin"].elapsed_time(m["fwd_enc_end"]) for m in per) / len(per)
+        t_bwd = sum(m["bwd_enc_begin"].elapsed_time(m["bwd_end"]) for m in per) / len(per)
+        enc = (t_fwd, t_bwd)
     eng.use_side_stream = side
     step.graphed = graphed
     barrier()
@@ -255,6 +272,12 @@ def main():
                         "side stream; 'standalone' repeats the measurement with one kernel on the GPU at a time",
                 "standalone": {f: {k: v for k, v in entry(f, fams_alone).items() if k != "kernel"} for f in fams_alone},
                 "whole_step_frac": round(sps / world * FLOP_PER_SAMPLE * (H * W) / (768 * 1152) / peak, 4)}
+        if enc is not None:
+            enc_flop = ENCODER_FLOP_PER_SAMPLE * B * (H * W) / (768 * 1152)
+            roof["encoder_region"] = {
+                "what": "Xception encoder forward + backward, every kernel of the region (convs, depthwise, BatchNorm), one stream",
+                "fwd_ms": round(enc[0], 3), "bwd_ms": round(enc[1], 3), "gflop_per_sample": ENCODER_FLOP_PER_SAMPLE / 1e9,
+                "achieved": round(enc_flop / ((enc[0] + enc[1]) * 1e-3) / 1e12, 2), "frac": round(enc_flop / ((enc[0] + enc[1]) * 1e-3) / peak, 4)}
     if world > 1:
         dist.barrier()
 

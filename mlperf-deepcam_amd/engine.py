@@ -201,6 +201,7 @@ class Engine:
         self.use_side_stream = os.environ.get("DC_SIDE_STREAM", "1") != "0"
         self.on_grad_ready: Optional[Callable[[List[str]], None]] = None
         self._debug_skip_side = os.environ.get("DC_DEBUG_SKIP_SIDE", "0") == "1"
+        self.region_marks: Optional[list] = None      # bench.py sets a list to collect (name, event) at the encoder boundaries
 
     # ------------------------------------------------------------------------------------------------ helpers
     def pptr(self, name: str) -> C.c_void_p:
@@ -599,6 +600,10 @@ class Engine:
             x = self._sep(x, s, lazy=i + 1 < len(S.EXIT_SEPS))
         e = x
         h16, w16 = e.H, e.W
+        # end of the Xception encoder (deeplab_xception.py:195-242) in the forward program / its share of the backward makers:
+        # bench.py times the region on its own (north_star quotes a roofline fraction for the encoder)
+        self._enc_fwd_end = len(self.fwd_train)
+        self._enc_bwd_makers = len(self.bwd)
 
         # ---- ASPP: five branches write channel slices of one buffer (torch.cat is free)
         cat1 = Act(self, "aspp_cat", B, h16, w16, 1280)
@@ -774,14 +779,23 @@ class Engine:
             raise ValueError("Expected more than 1 value per channel when training, got input size torch.Size([1, 256, 1, 1])")
         if self.packed_version != self.version[0]:
             self.pack_weights()
-        for op in (self.fwd_train if train else self.fwd_eval):
+        marks = self.region_marks if train else None      # measurement hook: events at the encoder's boundaries
+        if marks is not None:
+            marks.append(("fwd_begin", torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))))
+        for i, op in enumerate(self.fwd_train if train else self.fwd_eval):
+            if marks is not None and i == self._enc_fwd_end:
+                marks.append(("fwd_enc_end", torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))))
             op()
         return self.logits
 
     def backward(self) -> None:
         """Consumes self.dlogits (NCHW fp32); leaves every parameter gradient in self.grads."""
         cb = self.on_grad_ready
-        for op, ready in zip(self.bwd, self.grad_ready):
+        marks = self.region_marks
+        enc_begin = len(self.bwd) - self._enc_bwd_makers      # the backward program is the reversed maker list
+        for i, (op, ready) in enumerate(zip(self.bwd, self.grad_ready)):
+            if marks is not None and i == enc_begin:
+                marks.append(("bwd_enc_begin", torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))))
             op()
             if self._ready_now:           # gradients whose (deferred) kernels this op has just submitted
                 ready, self._ready_now = ready + self._ready_now, []
@@ -794,3 +808,5 @@ class Engine:
                 cb(ready)
         if self.use_side_stream:
             torch.cuda.current_stream().wait_stream(self.side)
+        if marks is not None:
+            marks.append(("bwd_end", torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))))
