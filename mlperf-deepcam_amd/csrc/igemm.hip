@@ -618,59 +618,100 @@ __device__ inline void pack_store_run(T* dst, float v0, float v1);
 template <>
 __device__ inline void pack_store_run<bf16>(bf16* dst, float v0, float v1) { *reinterpret_cast<uint32_t*>(dst) = pack2_bf16(v0, v1); }
 
-template <typename T>
-__global__ __launch_bounds__(256) void pack_all_kernel(const PackEntry* __restrict__ table) {
-  __shared__ float lds[PACK_LDS_FLOATS];
-  const PackEntry e = table[blockIdx.y];
-  if (e.kind == 2) {
-    const int n = 9 * e.cout;
-    float* out = reinterpret_cast<float*>(e.wf);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[(size_t)(i % 9) * e.cout + i / 9] = e.master[i];
-    return;
-  }
-  const int taps = e.taps;
+// one TS x TS x TAPS tile of a dense entry through LDS; TAPS is a template parameter so that the index arithmetic of the three
+// passes divides by constants (with a run-time tap count the kernel was bound by integer division: 0.3 ms for 450 MB)
+template <typename T, int TAPS>
+__device__ inline void pack_dense_tile(const PackEntry& e, int tile, float* lds) {
   const int A = e.kind == 1 ? e.cin : e.cout, B = e.kind == 1 ? e.cout : e.cin;
   T* P = reinterpret_cast<T*>(e.kind == 1 ? e.wb : e.wf);   // [t][a][b], row stride r32(B)
   T* Q = reinterpret_cast<T*>(e.kind == 1 ? e.wf : e.wb);   // [t][b][a], row stride r32(A)
   const int ldp = (B + 31) / 32 * 32, ldq = (A + 31) / 32 * 32;
-  const int TS = taps == 1 ? 64 : 32;           // tile edge
-  const int rowf = TS * taps + 1;               // padded LDS row (floats): odd stride -> conflict-free column reads
-  const int nta = (A + TS - 1) / TS, ntb = (B + TS - 1) / TS;
+  constexpr int TS = TAPS == 1 ? 64 : 32;       // tile edge
+  constexpr int ROWF = TS * TAPS + 1;           // padded LDS row (floats): odd stride -> conflict-free column reads
+  const int ntb = (B + TS - 1) / TS;
   constexpr int EPU = 4 / (int)sizeof(T);       // elements per 4-byte store unit
-  for (int tile = blockIdx.x; tile < nta * ntb; tile += gridDim.x) {
-    const int a0 = (tile / ntb) * TS, b0 = (tile % ntb) * TS;
-    const int run = min(TS, B - b0) * taps;     // contiguous floats per master row of this tile
-    __syncthreads();                            // previous tile fully written out
-    for (int idx = threadIdx.x; idx < TS * TS * taps; idx += 256) {
-      const int al = idx / (TS * taps), j = idx - al * (TS * taps);
-      float v = 0.f;
-      if (a0 + al < A && j < run) v = e.master[((size_t)(a0 + al) * B + b0) * taps + j];
-      lds[al * rowf + j] = v;
-    }
-    __syncthreads();
-    const int upr = TS / EPU;                   // store units per output row
-    if (P != nullptr) {
-      for (int idx = threadIdx.x; idx < taps * TS * upr; idx += 256) {
-        const int u = idx % upr, al = (idx / upr) % TS, t = idx / (upr * TS);
-        const int bl = u * EPU;
-        if (a0 + al < A && b0 + bl < B) {       // B is a multiple of EPU for every layer of the network; the row pad absorbs a tail
-          T* dst = P + ((size_t)t * A + a0 + al) * ldp + b0 + bl;
-          if constexpr (EPU == 2) pack_store_run<T>(dst, lds[al * rowf + bl * taps + t], lds[al * rowf + (bl + 1) * taps + t]);
-          else *reinterpret_cast<float*>(dst) = lds[al * rowf + bl * taps + t];
-        }
+  const int a0 = (tile / ntb) * TS, b0 = (tile % ntb) * TS;
+  const int run = min(TS, B - b0) * TAPS;       // contiguous floats per master row of this tile
+  __syncthreads();                              // previous tile fully written out
+#pragma unroll 4
+  for (int idx = threadIdx.x; idx < TS * TS * TAPS; idx += 256) {
+    const int al = idx / (TS * TAPS), j = idx - al * (TS * TAPS);
+    float v = 0.f;
+    if (a0 + al < A && j < run) v = e.master[((size_t)(a0 + al) * B + b0) * TAPS + j];
+    lds[al * ROWF + j] = v;
+  }
+  __syncthreads();
+  constexpr int UPR = TS / EPU;                 // store units per output row
+  if (P != nullptr) {
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < TAPS * TS * UPR; idx += 256) {
+      const int u = idx % UPR, al = (idx / UPR) % TS, t = idx / (UPR * TS);
+      const int bl = u * EPU;
+      if (a0 + al < A && b0 + bl < B) {         // B is a multiple of EPU for every layer of the network; the row pad absorbs a tail
+        T* dst = P + ((size_t)t * A + a0 + al) * ldp + b0 + bl;
+        if constexpr (EPU == 2) pack_store_run<T>(dst, lds[al * ROWF + bl * TAPS + t], lds[al * ROWF + (bl + 1) * TAPS + t]);
+        else *reinterpret_cast<float*>(dst) = lds[al * ROWF + bl * TAPS + t];
       }
     }
-    if (Q != nullptr) {
-      for (int idx = threadIdx.x; idx < taps * TS * upr; idx += 256) {
-        const int u = idx % upr, bl = (idx / upr) % TS, t = idx / (upr * TS);
-        const int al = u * EPU;
-        if (b0 + bl < B && a0 + al < A) {
-          T* dst = Q + ((size_t)t * B + b0 + bl) * ldq + a0 + al;
-          if constexpr (EPU == 2) pack_store_run<T>(dst, lds[al * rowf + bl * taps + t], lds[(al + 1) * rowf + bl * taps + t]);
-          else *reinterpret_cast<float*>(dst) = lds[al * rowf + bl * taps + t];
-        }
+  }
+  if (Q != nullptr) {
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < TAPS * TS * UPR; idx += 256) {
+      const int u = idx % UPR, bl = (idx / UPR) % TS, t = idx / (UPR * TS);
+      const int al = u * EPU;
+      if (b0 + bl < B && a0 + al < A) {
+        T* dst = Q + ((size_t)t * B + b0 + bl) * ldq + a0 + al;
+        if constexpr (EPU == 2) pack_store_run<T>(dst, lds[al * ROWF + bl * TAPS + t], lds[(al + 1) * ROWF + bl * TAPS + t]);
+        else *reinterpret_cast<float*>(dst) = lds[al * ROWF + bl * TAPS + t];
       }
     }
+  }
+}
+
+// tiles of one table entry (dense: TS x TS x taps tiles of the master tensor; depthwise: runs of 256 channels)
+__device__ inline int pack_entry_tiles(const PackEntry& e) {
+  if (e.kind == 2) return (e.cout + 255) / 256;
+  const int A = e.kind == 1 ? e.cin : e.cout, B = e.kind == 1 ? e.cout : e.cin;
+  const int TS = e.taps == 1 ? 64 : 32;
+  return ((A + TS - 1) / TS) * ((B + TS - 1) / TS);
+}
+
+constexpr int PACK_MAX_ENTRIES = 1024;
+
+// One flat grid over ALL tiles of all entries: every workgroup first builds the prefix sums of the per-entry tile counts in LDS
+// (a few hundred entries: one scan), then walks tiles b, b + G, ... and finds the owning entry by binary search.  (The first
+// version gave every entry 128 workgroups: the 728-element depthwise entries wasted theirs and the 4.7 M-element ASPP kernels
+// waited for 128 workgroups to chew through 512 tiles each -- 0.28 ms for 450 MB.)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackEntry* __restrict__ table, int nentries) {
+  __shared__ float lds[PACK_LDS_FLOATS];
+  __shared__ int prefix[PACK_MAX_ENTRIES + 1];
+  for (int i = threadIdx.x; i < nentries; i += 256) prefix[i + 1] = pack_entry_tiles(table[i]);
+  if (threadIdx.x == 0) prefix[0] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int i = 1; i <= nentries; ++i) prefix[i] += prefix[i - 1];
+  __syncthreads();
+  const int total = prefix[nentries];
+  for (int gt = blockIdx.x; gt < total; gt += gridDim.x) {
+    int lo = 0, hi = nentries;              // invariant: prefix[lo] <= gt < prefix[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (prefix[mid] <= gt) lo = mid; else hi = mid;
+    }
+    const PackEntry e = table[lo];
+    const int tile = gt - prefix[lo];
+    if (e.kind == 2) {
+      float* out = reinterpret_cast<float*>(e.wf);
+      const int c = tile * 256 + threadIdx.x;
+      if (c < e.cout) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) out[(size_t)t * e.cout + c] = e.master[(size_t)c * 9 + t];
+      }
+      continue;
+    }
+    if (e.taps == 1) pack_dense_tile<T, 1>(e, tile, lds);
+    else pack_dense_tile<T, 9>(e, tile, lds);
   }
 }
 
@@ -685,12 +726,14 @@ extern "C" int dc_debug_stamp_buf(void* buf) {
 }
 #endif
 
+static int g_pack_blocks = 2048;   // workgroups of the flat dc_pack_all grid (tuning switch "pack_blocks")
 extern "C" int dc_pack_all(int dtype, const void* table_dev, int nentries, void* stream) {
   DC_REQUIRE(table_dev != nullptr && nentries > 0, "dc_pack_all: bad argument");
   DC_REQUIRE(sizeof(PackEntry) == 40, "dc_pack_all: entry layout changed");
-  dim3 grid(128, nentries);
-  if (dtype == DC_BF16) hipLaunchKernelGGL(pack_all_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev);
-  else hipLaunchKernelGGL(pack_all_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev);
+  DC_REQUIRE(nentries <= PACK_MAX_ENTRIES, "dc_pack_all: too many entries for one launch");
+  dim3 grid(g_pack_blocks);
+  if (dtype == DC_BF16) hipLaunchKernelGGL(pack_all_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev, nentries);
+  else hipLaunchKernelGGL(pack_all_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const PackEntry*)table_dev, nentries);
   DC_CHECK_LAUNCH();
   return 0;
 }
@@ -714,6 +757,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm_mix") == 0) { g_igemm_mix = value != 0; return 0; }
+  if (name != nullptr && strcmp(name, "pack_blocks") == 0 && value > 0) { g_pack_blocks = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_epi") == 0) { igemm256_set_epilogue(value); return 0; }
   if (name != nullptr && strcmp(name, "igemm_mix_cus") == 0) {
     if (value < 1) return dc_fail("dc_set_option: igemm_mix_cus must be positive", __FILE__, __LINE__);
