@@ -20,12 +20,14 @@ struct IgemmParams {
   int accumulate;
   const void* zero_page;   // 256 zero bytes in device memory (set by the 256-tile launcher)
   int reg_epilogue;        // 256-tile kernel: epilogue from the accumulator registers (set by its launcher)
+  int phase_fast;          // 256-tile kernel: consecutive tiles walk the sub-pixel phases of one pixel tile (set by its launcher)
 };
 // OUT32: the epilogue stores fp32 regardless of T (used by the classifier head, whose logits must not be rounded to bf16)
 
 // 256 x 256 tile kernel (bf16 only).  Returns 0 after launching.
 int launch_igemm256(const IgemmParams& p, hipStream_t st);
 void igemm256_set_epilogue(int v);
+void igemm256_set_phase_fast(int v);
 // workgroups the 256-tile kernel would launch for this problem
 inline long igemm256_tiles(const IgemmParams& p) {
   return (long)((p.g.Cout + 255) / 256) * ((p.M - p.m_beg + 255) / 256) * p.g.os * p.g.os;

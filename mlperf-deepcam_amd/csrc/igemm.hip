@@ -532,6 +532,7 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   p.M = (int)M;
   p.m_beg = 0;
   p.reg_epilogue = 0;
+  p.phase_fast = 0;
   p.zero_page = nullptr;
   p.mtiles = cdiv(M, BM);
   p.accumulate = accumulate;
@@ -759,6 +760,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm_mix") == 0) { g_igemm_mix = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "pack_blocks") == 0 && value > 0) { g_pack_blocks = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_epi") == 0) { igemm256_set_epilogue(value); return 0; }
+  if (name != nullptr && strcmp(name, "igemm256_phase_fast") == 0) { igemm256_set_phase_fast(value); return 0; }
   if (name != nullptr && strcmp(name, "igemm_mix_cus") == 0) {
     if (value < 1) return dc_fail("dc_set_option: igemm_mix_cus must be positive", __FILE__, __LINE__);
     g_mix_cus = value;

@@ -85,8 +85,12 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + xslot;
   const int ntile_n = tile % ntn;
   const int rest = tile / ntn;
-  const int mtile = rest % mt256;
-  const int phase = rest / mt256;
+  // phase fastest: the sub-pixel phases of a transposed conv have K loops of different length (1/2/2/4 taps), so neighbouring
+  // workgroups finish at different times (their write bursts interleave with the others' K loops), and the four phases of one
+  // pixel tile read the same input rows through one XCD's L2
+  const int nph = g.os * g.os;
+  const int phase = p.phase_fast ? rest % nph : rest / mt256;
+  const int mtile = p.phase_fast ? rest / nph : rest % mt256;
   const int n0 = ntile_n * TN, m0 = p.m_beg + mtile * TM;
   const int py = phase / g.os, px = phase % g.os;
 
@@ -516,6 +520,8 @@ extern "C" int dc_debug_stamp_buf256(void* buf) {
 // finishing together (32 MB at HBM speed), not LDS or instruction time.
 static int g_reg_epilogue = 0;
 void igemm256_set_epilogue(int v) { g_reg_epilogue = v ? 1 : 0; }
+static int g_phase_fast = 1;     // tile order of multi-phase (transposed / strided) launches: phase fastest (A/B switch "igemm256_phase_fast")
+void igemm256_set_phase_fast(int v) { g_phase_fast = v ? 1 : 0; }
 
 int launch_igemm256(const IgemmParams& p_in, hipStream_t st) {
   const size_t lds = (size_t)MAIN_BYTES + 128;
@@ -532,6 +538,7 @@ int launch_igemm256(const IgemmParams& p_in, hipStream_t st) {
   IgemmParams p = p_in;
   p.zero_page = zero_dev;
   p.reg_epilogue = g_reg_epilogue;
+  p.phase_fast = g_phase_fast;
   hipLaunchKernelGGL(igemm256_kernel, dim3((unsigned)igemm256_tiles(p)), dim3(512), lds, st, p);
   DC_CHECK_LAUNCH();
   return 0;
