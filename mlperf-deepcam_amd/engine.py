@@ -201,6 +201,7 @@ class Engine:
         self.use_side_stream = os.environ.get("DC_SIDE_STREAM", "1") != "0"
         self.on_grad_ready: Optional[Callable[[List[str]], None]] = None
         self._debug_skip_side = os.environ.get("DC_DEBUG_SKIP_SIDE", "0") == "1"
+        self._debug_skip_kind = os.environ.get("DC_DEBUG_SKIP_KIND", "")     # "_conv" / "_dw": skip that kind of weight gradient (timing only)
         self.region_marks: Optional[list] = None      # bench.py sets a list to collect (name, event) at the encoder boundaries
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -236,6 +237,8 @@ class Engine:
     def _on_side(self, fn: Callable[[C.c_void_p], None]) -> None:
         """Run fn(workspace_ptr) on the side stream, ordered after everything enqueued so far on the current stream."""
         if self._debug_skip_side:      # timing experiments only (DC_DEBUG_SKIP_SIDE=1): the weight gradients are NOT computed
+            return
+        if self._debug_skip_kind and self._debug_skip_kind in getattr(fn, "__qualname__", ""):
             return
         if not self.use_side_stream:
             fn(self._wsptr())
