@@ -34,40 +34,43 @@ def synthetic_batch(B, H, W, seed, device):
     return x.to(device), y.to(device)
 
 
-def cpu_baseline(local_batch, H, W, budget_s=30.0):
-    """Oracle train step (forward, loss, backward, Adam) on the host cores.  Bounded: a quarter-area step is timed first;
-    the full-size step is run only if it is predicted to fit the budget, otherwise the quarter-area rate is scaled by area."""
+def cpu_baseline(H, W, local_batch=2, timed_steps=3, step_budget_s=60.0):
+    """SURVEY 8d / BASELINE.md section 3: the oracle's train step (forward, fp_loss, zero_grad, backward, Adam step) on the node's
+    host cores at the reference's canonical local batch (2, run_training_dgx2.sh:70), fp32, full size, 1 warm-up + 3 timed steps,
+    forward / backward / optimizer split.  Bounded: if the warm-up step alone takes longer than step_budget_s only ONE step is
+    timed, and the sample string says so."""
     from oracle import loss_metric as olm, model as omodel, optim as ooptim     # timed as the baseline, never shipped
     cw = olm.class_weights(-0.125)
     threads = torch.get_num_threads()
+    sd = omodel.init_state(333)
+    keys = omodel.param_keys(sd)
+    params = [sd[k].requires_grad_(True) for k in keys]
+    opt = ooptim.OracleOptimizer([p.detach() for p in params], "Adam", lr=1e-3, eps=1e-8, weight_decay=1e-6)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(local_batch, 16, H, W, generator=g)
+    y = torch.randint(0, 3, (local_batch, H, W), generator=g)
 
-    def one(h, w, warm):
-        sd = omodel.init_state(333)
-        keys = omodel.param_keys(sd)
-        params = [sd[k].requires_grad_(True) for k in keys]
-        opt = ooptim.OracleOptimizer([p.detach() for p in params], "Adam", lr=1e-3, eps=1e-8, weight_decay=1e-6)
-        g = torch.Generator().manual_seed(1234)
-        x = torch.rand(local_batch, 16, h, w, generator=g)
-        y = torch.randint(0, 3, (local_batch, h, w), generator=g)
-        ts = []
-        for _ in range(warm + 1):
-            t0 = time.perf_counter()
-            for p in params:
-                p.grad = None
-            loss = olm.fp_loss(omodel.forward(sd, x, training=True), y, cw)
-            loss.backward()
-            opt.step([p.grad for p in params])
-            ts.append(time.perf_counter() - t0)
-        return ts[-1]
+    def one():
+        t0 = time.perf_counter()
+        loss = olm.fp_loss(omodel.forward(sd, x, training=True), y, cw)
+        t1 = time.perf_counter()
+        for p in params:
+            p.grad = None
+        loss.backward()
+        t2 = time.perf_counter()
+        opt.step([p.grad for p in params])
+        t3 = time.perf_counter()
+        return t1 - t0, t2 - t1, t3 - t2
 
-    one(64, 96, 0)                                     # thread-pool / allocator warm-up
-    tq = one(H // 2, W // 2, 1)
-    if 4.0 * tq * 1.2 <= budget_s:
-        tf = one(H, W, 0)
-        return {"value": local_batch / tf, "unit": "samples/s", "cores": threads, "kind": "port",
-                "sample": f"1 full train step (fwd+loss+bwd+Adam) of the oracle, B={local_batch} {H}x{W} fp32, {tf:.2f} s"}
-    return {"value": local_batch / (4.0 * tq), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"1 warmed train step of the oracle at B={local_batch} {H // 2}x{W // 2} fp32 ({tq:.2f} s), scaled x4 by pixel count"}
+    warm = sum(one())
+    n = timed_steps if warm <= step_budget_s else 1
+    runs = [one() for _ in range(n)]
+    fwd, bwd, opt_s = (sum(r[i] for r in runs) / n for i in range(3))
+    total = fwd + bwd + opt_s
+    return {"value": local_batch / total, "unit": "samples/s", "cores": threads, "os_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": f"oracle train step (fwd + fp_loss + zero_grad + bwd + Adam), B={local_batch} {H}x{W} fp32, 1 warm-up "
+                      f"({warm:.1f} s) + {n} timed step(s), mean {total:.2f} s/step",
+            "seconds_per_step": round(total, 3), "forward_s": round(fwd, 3), "backward_s": round(bwd, 3), "optimizer_s": round(opt_s, 3)}
 
 
 class KernelTimer:
@@ -143,6 +146,12 @@ def main():
                     "measured faster once weight gradients moved to a side stream: 55.3 vs 59.5 ms at B=8)")
     a = ap.parse_args()
 
+    # timing-experiment switches that make backward skip work must never produce a bench line
+    skipping = {k: v for k, v in os.environ.items() if k.startswith("DC_DEBUG_") and v not in ("", "0")}
+    if skipping:
+        raise SystemExit(f"bench.py refuses to run with work-skipping debug switches set: {skipping}")
+    switches = {k: v for k, v in sorted(os.environ.items()) if k == "DEEPCAM_HIP_OPTIONS" or k == "DEEPCAM_HIP_LIB" or k.startswith("DC_")}
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
@@ -173,8 +182,7 @@ def main():
     if world > 1:
         reducer = ddist.GradReducer(net.engine, world)
         reducer.broadcast_parameters()
-        step.after_backward = reducer.finish
-        opt.grad_scale = 1.0 / world
+        step.attach_reducer(reducer)
     x, y = synthetic_batch(B, H, W, 1234 + rank, dev)
     graphed = False
     if world == 1 and a.graph:
@@ -256,15 +264,23 @@ def main():
                     "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 2), "algorithmic_bytes_per_launch": round(nbytes / max(n, 1))}
         e = entry(dom)
         # HBM bytes per launch come from PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs of this very command) that
-        # cannot be taken from inside the process; the committed measurement is attached when it matches this configuration.
-        traffic = None
+        # cannot be taken from inside the process; the newest committed measurement of this configuration is attached and named.
+        traffic, traffic_source = None, None
         try:
-            if (B, a.dtype, H, W) == (8, "bf16", 768, 1152):
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                    traffic = round(json.load(f)["kernels"][dom]["hbm_bytes_per_launch"])
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                with open(path) as f:
+                    rec = json.load(f)
+                cfg = rec.get("config", {"local_batch": 8, "dtype": "bf16", "height": 768, "width": 1152})
+                if (cfg.get("local_batch"), cfg.get("dtype"), cfg.get("height"), cfg.get("width")) == (B, a.dtype, H, W):
+                    traffic = round(rec["kernels"][dom]["hbm_bytes_per_launch"])
+                    traffic_source = (f"profiles/{os.path.basename(path)}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                      "this command (FETCH doubled per the gfx950 guide); not measured inside this run")
+                    break
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
         roof = {"bound": "mfma", "achieved": e["achieved"], "peak": peak / 1e12, "unit": "TFLOP/s", "frac": e["frac"], "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel": e["kernel"], "launches_timed": e["launches_timed"], "avg_launch_us": e["avg_launch_us"],
                 "ms_per_step": e["ms_per_step"], "algorithmic_gflop_per_launch": e["algorithmic_gflop_per_launch"],
                 "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"], "other_mfma_kernel": entry([f for f in fams if f != dom][0]),
@@ -289,11 +305,11 @@ def main():
                                       f"{' + RCCL grad all-reduce' if world > 1 else ''}), {H}x{W}x16, local_batch={B}, "
                                       f"{a.dtype} activations / fp32 master weights, random-init seed 333",
                           "local_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": a.optimizer,
-                          "hip_graph": graphed},
+                          "hip_graph": graphed, "switches": switches},
                "loss_last_step": round(loss, 6), "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(B, H, W)
+                out["cpu_baseline"] = cpu_baseline(H, W)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
                                        "sample": f"failed: {e}"}

@@ -208,6 +208,11 @@ int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, 
 int dc_input_normalize_hwc(int dtype, long npix, int Cfile, int C, const int* channels, const float* x_hwc,
                            const float* shift, const float* scale, void* out, int ldo, void* stream);
 
+/* The same arithmetic written as the reference's NCHW fp32 batch [N][C][HW] (any C >= 1): for --channels subsets
+ * (train_hdf5_ddp.py:561) whose count is not a multiple of the 16-byte vector, which run dc_stem_fwd on NCHW fp32 input. */
+int dc_input_normalize_hwc_to_nchw(int N, long HW, int Cfile, int C, const int* channels, const float* x_hwc,
+                                   const float* shift, const float* scale, float* out_nchw, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Loss and metric: utils/losses.py:28-52 (fp_loss == plain mean of weighted CE), torch.max(.,1)[1]
  * (train_hdf5_ddp.py:406,458) and utils/utils.py:32-60 (compute_score) in one pass over the logits.
@@ -215,7 +220,8 @@ int dc_input_normalize_hwc(int dtype, long npix, int Cfile, int C, const int* ch
  *   dlogits    fp32 NCHW   = w[y]*(softmax - onehot)*grad_scale                 (NULL to skip)
  *   pred       int64 [B,H,W] first-max argmax                                   (NULL to skip)
  *   counts     int64[9]    += tp[3], fp[3], fn[3]                               (NULL to skip)
- * label_dtype_bytes: 1 (uint8), 4 (int32) or 8 (int64) labels.
+ * label_dtype_bytes: 1 (uint8), 4 (int32) or 8 (int64) labels.  A label outside [0,3) -- for which the reference's
+ * nn.CrossEntropyLoss raises -- makes loss_sum and that pixel's dlogits NaN (nothing here synchronises, so nothing can raise).
  * ------------------------------------------------------------------------------------------------ */
 int dc_wce_fused(int B, int H, int W, const float* logits_nchw, const void* labels, int label_dtype_bytes,
                  const float* class_weights /*device float[3]*/, float grad_scale, double* loss_sum,
@@ -249,7 +255,9 @@ int dc_adam_step(int kind, long n, float* p, const float* g, float* m, float* v,
                  void* stream);
 /* LAMB: tensor t occupies [offsets[t], offsets[t+1]) of the arena (device int64[ntensors+1]).
  * workspace: dc_lamb_workspace_words(ntensors, n) 4-byte words (partial sums of the global norm, chunk plan, per-chunk
- * norms).  No atomics: the update is bit-identical from run to run. */
+ * norms and the n-element update direction; 16-byte aligned).  `g` is only read (as apex FusedLAMB leaves .grad intact).
+ * As apex with use_nvlamb=False, the per-tensor trust ratio is applied only when weight_decay != 0.
+ * No atomics: the update is bit-identical from run to run. */
 size_t dc_lamb_workspace_words(int ntensors, long n);
 int dc_lamb_step(int ntensors, const int64_t* offsets_dev, long n, float* p, const float* g, float* m, float* v,
                  const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,

@@ -8,10 +8,13 @@ namespace dc {
 
 constexpr int NC = 3;
 
+// labels outside [0, NC) come back as -1 (the full 64-bit value is compared, not its low half)
 __device__ inline int load_label(const void* labels, int bytes, long i) {
-  if (bytes == 8) return (int)reinterpret_cast<const int64_t*>(labels)[i];
-  if (bytes == 4) return reinterpret_cast<const int32_t*>(labels)[i];
-  return (int)reinterpret_cast<const uint8_t*>(labels)[i];
+  long long v;
+  if (bytes == 8) v = reinterpret_cast<const int64_t*>(labels)[i];
+  else if (bytes == 4) v = reinterpret_cast<const int32_t*>(labels)[i];
+  else v = reinterpret_cast<const uint8_t*>(labels)[i];
+  return (v >= 0 && v < NC) ? (int)v : -1;
 }
 
 __device__ inline unsigned long long wave_count(bool pred) { return __popcll(__ballot(pred)); }
@@ -63,9 +66,15 @@ __global__ __launch_bounds__(256) void wce_kernel(int B, long HW, const float* _
           gp[HW] = s * (e1 * inv - (y == 1 ? 1.f : 0.f));
           gp[2 * HW] = s * (e2 * inv - (y == 2 ? 1.f : 0.f));
         }
-      } else if (dlogits != nullptr) {
-        float* gp = dlogits + (size_t)b * NC * HW + p;
-        gp[0] = gp[HW] = gp[2 * HW] = 0.f;
+      } else {
+        // A label outside [0, 3): nn.CrossEntropyLoss raises for it in the reference (losses.py:36).  A kernel cannot raise and
+        // this ABI never synchronises, so the result is poisoned instead of silently dropping the pixel: the loss and this
+        // pixel's gradient become NaN, which reaches every weight in the same step.
+        lsum += (double)__builtin_nanf("");
+        if (dlogits != nullptr) {
+          float* gp = dlogits + (size_t)b * NC * HW + p;
+          gp[0] = gp[HW] = gp[2 * HW] = __builtin_nanf("");
+        }
       }
       if (pred != nullptr) pred[i] = am;
     }

@@ -185,10 +185,11 @@ __device__ inline bool lamb_locate(const int64_t* __restrict__ offs, const int* 
   return true;
 }
 
-// stage 1: moments, update direction u (written over g), per-CHUNK ||w||^2 and ||u||^2 (part[chunk][2], no atomics)
+// stage 1: moments, update direction u (its own buffer: the gradient arena is read-only), per-CHUNK ||w||^2 and ||u||^2
+// (part[chunk][2], no atomics)
 __global__ __launch_bounds__(256) void lamb_stage1_kernel(const int64_t* __restrict__ offs, const int* __restrict__ chunk_prefix,
-                                                          int ntensors, float* __restrict__ p, float* __restrict__ g,
-                                                          float* __restrict__ m, float* __restrict__ v, float beta1, float beta2,
+                                                          int ntensors, const float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ uo, float* __restrict__ m, float* __restrict__ v, float beta1, float beta2,
                                                           float eps, float wd, const int* step_dev, float max_grad_norm,
                                                           float grad_scale, const float* __restrict__ gpartial, float* __restrict__ part) {
   __shared__ float s[2][4];
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void lamb_stage1_kernel(const int64_t* __restr
     m[i] = mv;
     v[i] = vv;
     const float u = (mv / bc1) / (sqrtf(vv / bc2) + eps) + wd * pv;
-    g[i] = u;
+    uo[i] = u;
     wn = fmaf(pv, pv, wn);
     un = fmaf(u, u, un);
   }
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256) void lamb_stage1_kernel(const int64_t* __restr
 // stage 2: every workgroup adds the chunk sums of its tensor in the same fixed order (at most ~1200 chunks), then updates its chunk
 __global__ __launch_bounds__(256) void lamb_stage2_kernel(const int64_t* __restrict__ offs, const int* __restrict__ chunk_prefix,
                                                           int ntensors, float* __restrict__ p, const float* __restrict__ u,
-                                                          const float* lr_dev, const float* __restrict__ part) {
+                                                          const float* lr_dev, const float* __restrict__ part, float wd) {
   __shared__ double sh[4];
   int t;
   long beg, end;
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(256) void lamb_stage2_kernel(const int64_t* __restr
   const int c0 = chunk_prefix[t], nc = chunk_prefix[t + 1] - c0;
   const float wn = (float)sqrt(block_sum_fixed(part + 2 * (size_t)c0, nc, 2, sh));
   const float un = (float)sqrt(block_sum_fixed(part + 2 * (size_t)c0 + 1, nc, 2, sh));
-  const float ratio = (wn > 0.f && un > 0.f) ? wn / un : 1.f;
+  // apex FusedLAMB (use_nvlamb = False, its default): the trust ratio applies only to tensors with non-zero weight decay
+  const float ratio = (wd != 0.f && wn > 0.f && un > 0.f) ? wn / un : 1.f;
   const float a = *lr_dev * ratio;
   for (long i = beg + threadIdx.x; i < end; i += 256) p[i] = fmaf(-a, u[i], p[i]);
 }
@@ -331,7 +333,9 @@ extern "C" int dc_adam_step(int kind, long n, float* p, const float* g, float* m
 }
 
 extern "C" size_t dc_lamb_workspace_words(int ntensors, long n) {
-  return (size_t)SUMSQ_BLOCKS + (size_t)ntensors + 1 + 2 * (size_t)(n / LAMB_CHUNK + ntensors);
+  // [SUMSQ_BLOCKS] gradient partial sums | [ntensors + 1] chunk plan | [2 * max_chunks] per-chunk norms | pad to 4 | [n] update
+  const size_t head = (size_t)SUMSQ_BLOCKS + (size_t)ntensors + 1 + 2 * (size_t)(n / LAMB_CHUNK + ntensors);
+  return (head + 3) / 4 * 4 + (size_t)n;
 }
 
 extern "C" int dc_lamb_step(int ntensors, const int64_t* offsets_dev, long n, float* p, const float* g, float* m,
@@ -341,21 +345,23 @@ extern "C" int dc_lamb_step(int ntensors, const int64_t* offsets_dev, long n, fl
   hipStream_t st = (hipStream_t)stream;
   const long max_chunks = n / LAMB_CHUNK + ntensors;   // every tensor rounds up by less than one chunk
   DC_REQUIRE(max_chunks < (1L << 30), "dc_lamb_step: arena too large");
-  // workspace words: [SUMSQ_BLOCKS] gradient partial sums | [ntensors + 1] chunk plan | [2 * max_chunks] per-chunk norms
+  // workspace words: [SUMSQ_BLOCKS] gradient partial sums | [ntensors + 1] chunk plan | [2 * max_chunks] per-chunk norms |
+  // (padded to a multiple of 4 words) [n] the update direction u.  The gradient arena is only read: a caller may keep using it
+  // (gradient logging, accumulation) after the step, as with apex FusedLAMB.
   float* gpartial = workspace;
   int* chunk_prefix = reinterpret_cast<int*>(workspace + SUMSQ_BLOCKS);
   float* part = workspace + SUMSQ_BLOCKS + ntensors + 1;
+  const size_t head = (size_t)SUMSQ_BLOCKS + (size_t)ntensors + 1 + 2 * (size_t)max_chunks;
+  float* upd = workspace + (head + 3) / 4 * 4;
   hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, n, g, grad_scale, gpartial);
   DC_CHECK_LAUNCH();
-  // the update direction is staged in the gradient arena (it is dead after this step)
-  float* gw = const_cast<float*>(g);
   hipLaunchKernelGGL(lamb_plan_kernel, dim3(1), dim3(64), 0, st, offsets_dev, ntensors, chunk_prefix);
   DC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(lamb_stage1_kernel, dim3((unsigned)max_chunks), dim3(256), 0, st, offsets_dev, chunk_prefix, ntensors, p, gw, m,
-                     v, beta1, beta2, eps, weight_decay, step_dev, max_grad_norm, grad_scale, gpartial, part);
+  hipLaunchKernelGGL(lamb_stage1_kernel, dim3((unsigned)max_chunks), dim3(256), 0, st, offsets_dev, chunk_prefix, ntensors, p, g, upd,
+                     m, v, beta1, beta2, eps, weight_decay, step_dev, max_grad_norm, grad_scale, gpartial, part);
   DC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(lamb_stage2_kernel, dim3((unsigned)max_chunks), dim3(256), 0, st, offsets_dev, chunk_prefix, ntensors, p, gw,
-                     lr_dev, part);
+  hipLaunchKernelGGL(lamb_stage2_kernel, dim3((unsigned)max_chunks), dim3(256), 0, st, offsets_dev, chunk_prefix, ntensors, p, upd,
+                     lr_dev, part, weight_decay);
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -456,6 +456,23 @@ __global__ __launch_bounds__(256) void input_normalize_kernel(long npix, int Cfi
   }
 }
 
+// The same normalisation written as the reference's NCHW fp32 batch (one thread per pixel: the sample's channels are read as one
+// contiguous run, each channel plane is written coalesced).  For --channels subsets whose count the MFMA stem does not take: the
+// direct stem kernel reads NCHW fp32.
+__global__ __launch_bounds__(256) void input_normalize_nchw_kernel(int N, long HW, int Cfile, int Cc, const int* __restrict__ channels,
+                                                                   const float* __restrict__ x, const float* __restrict__ shift,
+                                                                   const float* __restrict__ scale, float* __restrict__ out) {
+  const long total = (long)N * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / HW, p = i - n * HW;
+    const float* px = x + (size_t)i * Cfile;
+    for (int j = 0; j < Cc; ++j) {
+      const int src = channels != nullptr ? channels[j] : j;
+      out[((size_t)n * Cc + j) * HW + p] = scale[j] * (px[src] - shift[j]);
+    }
+  }
+}
+
 static int g_head_fused = 1;   // bf16 forward: products + combination in one kernel (0: GEMM + combine kernels)
 extern "C" int dc_head_set_fused(int v) { g_head_fused = v ? 1 : 0; return 0; }
 
@@ -564,6 +581,17 @@ extern "C" int dc_input_normalize_hwc(int dtype, long npix, int Cfile, int C, co
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DC_BF16) hipLaunchKernelGGL(input_normalize_kernel<bf16>, dim3((int)blocks), dim3(256), 0, st, npix, Cfile, C, channels, x_hwc, shift, scale, (bf16*)out, ldo);
   else hipLaunchKernelGGL(input_normalize_kernel<float>, dim3((int)blocks), dim3(256), 0, st, npix, Cfile, C, channels, x_hwc, shift, scale, (float*)out, ldo);
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dc_input_normalize_hwc_to_nchw(int N, long HW, int Cfile, int C, const int* channels, const float* x_hwc,
+                                              const float* shift, const float* scale, float* out_nchw, void* stream) {
+  DC_REQUIRE(x_hwc && shift && scale && out_nchw && N > 0 && HW > 0 && C > 0 && Cfile >= C, "dc_input_normalize_hwc_to_nchw: bad argument");
+  long blocks = ((long)N * HW + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(input_normalize_nchw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, N, HW, Cfile, C, channels, x_hwc,
+                     shift, scale, out_nchw);
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -151,11 +151,13 @@ class SyntheticHWC:
 # device half
 # ---------------------------------------------------------------------------------------------------------------------
 class _Slot:
-    def __init__(self, B, H, W, cfile, C_, dtype, device):
+    def __init__(self, B, H, W, cfile, C_, dtype, device, nchw=False):
         self.data_host = torch.empty((B, H, W, cfile), dtype=torch.float32).pin_memory()
         self.label_host = torch.empty((B, H, W), dtype=torch.int64).pin_memory()
         self.data_dev = torch.empty((B, H, W, cfile), dtype=torch.float32, device=device)
-        self.x = torch.empty((B, H, W, C_), dtype=dtype, device=device)          # NHWC activations, consumed in place by the stem
+        # NHWC activations, consumed in place by the MFMA stem; or the reference's NCHW fp32 batch for the direct stem kernel
+        self.x = torch.empty((B, C_, H, W), dtype=torch.float32, device=device) if nchw else \
+            torch.empty((B, H, W, C_), dtype=dtype, device=device)
         self.label = torch.empty((B, H, W), dtype=torch.int64, device=device)
         self.ready = torch.cuda.Event()
         self.consumed = torch.cuda.Event()
@@ -171,7 +173,7 @@ class InputPipeline:
     tensors were last used (the consumer calls release(), or simply asks for the next batch)."""
 
     def __init__(self, dataset, batch_size: int, dtype=torch.bfloat16, device=None, depth: int = 3, drop_last: bool = True,
-                 workers: int = 4):
+                 workers: int = 4, layout: str = "nhwc"):
         if not torch.cuda.is_available():
             raise L.DeepcamHipError("InputPipeline needs a HIP device")
         self.ds, self.B, self.dtype = dataset, batch_size, dtype
@@ -181,13 +183,19 @@ class InputPipeline:
         self.H, self.W, self.cfile = H, W, cfile
         self.C = len(dataset.channels)
         self.copy_stream = torch.cuda.Stream(device=self.device)
-        self.slots = [_Slot(batch_size, H, W, cfile, self.C, dtype, self.device) for _ in range(max(2, depth))]
+        # layout "nchw": batches leave as the reference's NCHW fp32 tensors (any channel count).  An engine whose channel count
+        # the MFMA stem does not take (--channels subsets that are not a multiple of 8 in bf16 / 4 in fp32) reads those.
+        if layout not in ("nhwc", "nchw"):
+            raise ValueError(f"layout must be 'nhwc' or 'nchw', got {layout!r}")
+        self.nchw = layout == "nchw"
+        self.slots = [_Slot(batch_size, H, W, cfile, self.C, dtype, self.device, self.nchw) for _ in range(max(2, depth))]
         self.shift = torch.from_numpy(np.asarray(dataset.data_shift, np.float32)).to(self.device)
         self.scale = torch.from_numpy(np.asarray(dataset.data_scale, np.float32)).to(self.device)
         ident = list(dataset.channels) == list(range(cfile))
         self.channels = None if ident else torch.tensor(list(dataset.channels), dtype=torch.int32, device=self.device)
         self.nbatches = len(dataset) // batch_size if drop_last else -(-len(dataset) // batch_size)
         self._prev: Optional[_Slot] = None
+        self._reader_thread: Optional[threading.Thread] = None
         # one 56.6 MB sample is ~10 ms of host copy/decoding: a single reader caps the pipeline near 100 samples/s, below the
         # train step's rate, so the samples of a batch are read by `workers` threads (numpy / h5py release the GIL while copying)
         self.workers = max(1, int(workers))
@@ -195,13 +203,13 @@ class InputPipeline:
     def __len__(self):
         return self.nbatches
 
-    def _reader(self, free_q: "queue.Queue", full_q: "queue.Queue"):
+    def _reader(self, free_q: "queue.Queue", full_q: "queue.Queue", stop: "threading.Event"):
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(self.workers) if self.workers > 1 else None
         try:
             for b in range(self.nbatches):
                 slot = free_q.get()
-                if slot is None:
+                if slot is None or stop.is_set():
                     return
                 slot.consumed.synchronize()                       # host wait: the GPU is done with this slot's tensors
                 dn, ln = slot.data_host.numpy(), slot.label_host.numpy()
@@ -218,12 +226,24 @@ class InputPipeline:
                 pool.shutdown(wait=False)
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, List[str]]]:
+        # An iteration abandoned half way (train.py breaks out of the validation loop at --max_validation_steps) leaves its
+        # reader possibly still writing a slot's pinned buffer: it has been told to stop (finally: below); wait for it before
+        # any slot is handed out again, and forget the slot the abandoned iteration had out.
+        if self._reader_thread is not None:
+            self._reader_thread.join()
+            self._reader_thread = None
+        self._prev = None
         free_q: "queue.Queue" = queue.Queue()
         full_q: "queue.Queue" = queue.Queue()
+        stop = threading.Event()
+        # in-flight H2D copies / normalise kernels of an abandoned iteration are on the copy stream: order the new ones and
+        # the slots' reuse behind them
+        torch.cuda.current_stream().wait_stream(self.copy_stream)
         for s in self.slots:
             s.consumed.record(torch.cuda.current_stream())
             free_q.put(s)
-        t = threading.Thread(target=self._reader, args=(free_q, full_q), daemon=True)
+        t = threading.Thread(target=self._reader, args=(free_q, full_q, stop), daemon=True)
+        self._reader_thread = t
         t.start()
         staged: List[_Slot] = []
 
@@ -236,9 +256,14 @@ class InputPipeline:
             with torch.cuda.stream(self.copy_stream):
                 item.data_dev.copy_(item.data_host, non_blocking=True)
                 item.label.copy_(item.label_host, non_blocking=True)
-                L.call("dc_input_normalize_hwc", self.dt, self.B * self.H * self.W, self.cfile, self.C, L.dptr(self.channels),
-                       L.dptr(item.data_dev), L.dptr(self.shift), L.dptr(self.scale), L.dptr(item.x), self.C,
-                       C.c_void_p(self.copy_stream.cuda_stream))
+                if self.nchw:
+                    L.call("dc_input_normalize_hwc_to_nchw", self.B, self.H * self.W, self.cfile, self.C, L.dptr(self.channels),
+                           L.dptr(item.data_dev), L.dptr(self.shift), L.dptr(self.scale), L.dptr(item.x),
+                           C.c_void_p(self.copy_stream.cuda_stream))
+                else:
+                    L.call("dc_input_normalize_hwc", self.dt, self.B * self.H * self.W, self.cfile, self.C, L.dptr(self.channels),
+                           L.dptr(item.data_dev), L.dptr(self.shift), L.dptr(self.scale), L.dptr(item.x), self.C,
+                           C.c_void_p(self.copy_stream.cuda_stream))
                 item.ready.record(self.copy_stream)
             staged.append(item)
             return True
@@ -261,6 +286,8 @@ class InputPipeline:
                 self._release(self._prev, free_q)
                 self._prev = None
         finally:
+            self._prev = None
+            stop.set()
             free_q.put(None)
 
     @staticmethod

@@ -6,8 +6,11 @@ arena in parameter order, and backward finishes them roughly from the arena's en
 plain contiguous arena ranges (no gather/scatter copies): as soon as the last gradient of a range has been written, the
 range is handed to RCCL (``all_reduce(SUM)`` on the process group's own stream, which first waits for the compute stream's
 current position) while backward keeps running.  ``finish()`` makes the compute stream wait for the outstanding
-collectives; the 1/world averaging is folded into the optimizer kernel (grad_scale).  BatchNorm statistics stay per
-rank, as in the reference (no SyncBN).
+collectives and re-arms the buckets for the next backward.  The 1/world averaging is either folded into the optimizer kernel
+(``TrainStep.attach_reducer``: grad_scale, no extra pass) or, on the reference's own loop through ``DistributedDataParallel``
+(``loss.backward(); optimizer.step()``), applied to the arena by ``finish(average=True)`` at the end of backward, so that
+``p.grad`` is the averaged gradient exactly as under apex / torch DDP.  BatchNorm statistics stay per rank, as in the
+reference (no SyncBN).
 """
 from __future__ import annotations
 
@@ -32,15 +35,17 @@ def get_size() -> int:
 def get_local_rank() -> int:
     if not (dist.is_available() and dist.is_initialized()):
         return 0
-    if "LOCAL_RANK" in os.environ:
-        return int(os.environ["LOCAL_RANK"])
     n = torch.cuda.device_count()
+    if "LOCAL_RANK" in os.environ:
+        return int(os.environ["LOCAL_RANK"]) % n if n > 0 else 0
     return dist.get_rank() % n if n > 0 else 0                       # comm.py:45-46
 
 
 def init(method: str, backend: Optional[str] = None) -> None:
     """comm.init: derive rank / world / master from the launcher's environment and bring up the process group.
-    'nccl' is RCCL on ROCm.  `backend` overrides (tests use gloo on CPU)."""
+    'nccl' is RCCL on ROCm.  `backend` (or the environment variable DC_DIST_BACKEND) overrides: tests use gloo, on the CPU
+    and for several ranks sharing one GPU."""
+    backend = backend or os.environ.get("DC_DIST_BACKEND") or None
     if method == "nccl-openmpi":
         addrport = os.getenv("PMIX_SERVER_URI2").split("//")[1]
         os.environ["MASTER_ADDR"] = addrport.split(":")[0]
@@ -136,13 +141,19 @@ class GradReducer:
                     b.work = dist.all_reduce(self.eng.grads[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self.launched += 1
 
-    def finish(self) -> None:
-        """Order the optimizer behind all outstanding collectives (stream-side wait on GPU; blocking on CPU/gloo)."""
+    def finish(self, average: bool = False) -> None:
+        """Order the optimizer behind all outstanding collectives (stream-side wait on GPU; blocking on CPU/gloo) and re-arm
+        the buckets.  average=True also divides the reduced arena by the world size in place (the DDP wrapper's path, where
+        the caller's optimizer knows nothing about the reduction); with average=False the arena holds the SUM and the
+        optimizer kernel applies 1/world (grad_scale)."""
         for b in self.buckets:
-            assert b.remaining == 0, f"bucket [{b.lo},{b.hi}) never completed: {b.remaining} gradients missing"
+            if b.remaining != 0:
+                raise RuntimeError(f"gradient bucket [{b.lo},{b.hi}) never completed: {b.remaining} gradients missing")
             if b.work is not None:
                 b.work.wait()
         self.reset()
+        if average and self.world > 1:
+            self.eng.grads.mul_(1.0 / self.world)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """DDP construction semantics (train_hdf5_ddp.py:227): every rank starts from rank 0's weights and BN buffers."""
@@ -168,6 +179,9 @@ class DistributedDataParallel(torch.nn.Module):
     def _attach(self):
         self.reducer = GradReducer(self.module.engine, get_size(), self._bucket_mb)
         self.reducer.broadcast_parameters()
+        # loss.backward() through the module (nn._NetFn.backward) ends with reducer.finish(average=True): the gradients the
+        # caller's optimizer.step() then reads are final and averaged, as apex / torch DDP guarantee at train_hdf5_ddp.py:363-364
+        self.module._ddp_reducer = self.reducer
 
     def forward(self, *args, **kw):
         if self.reducer is None and get_size() > 1 and self.module.engine is not None:

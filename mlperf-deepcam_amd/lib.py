@@ -77,6 +77,7 @@ _SIGS = {
     "dc_head_bwd": (I, [I, I, I, I, I, P, I, P, P, P, I, P, P, P]),
     "dc_nchw_to_nhwc": (I, [I, I, I, I, I, P, P, I, P]),
     "dc_input_normalize_hwc": (I, [I, L, I, I, P, P, P, P, P, I, P]),
+    "dc_input_normalize_hwc_to_nchw": (I, [I, L, I, I, P, P, P, P, P, P]),
     "dc_wce_fused": (I, [I, I, I, P, P, I, P, F, P, P, P, P, P]),
     "dc_confusion_counts": (I, [L, P, P, I, P, P]),
     "dc_avgpool_fwd": (I, [I, I, I, I, P, I, P, P]),

@@ -136,6 +136,11 @@ class _NetFn(torch.autograd.Function):
         if dlogits.data_ptr() != eng.dlogits.data_ptr():
             eng.dlogits.copy_(dlogits)
         eng.backward()
+        red = ctx.module._ddp_reducer
+        if red is not None:
+            # under dist.DistributedDataParallel: wait for the bucketed all-reduces launched during backward, re-arm the
+            # buckets and leave the AVERAGED gradient in the arena (train_hdf5_ddp.py:227,363)
+            red.finish(average=True)
         ctx.module._attach_grads()
         return None, None, None
 
@@ -161,6 +166,7 @@ class DeepLabv3_plus(torch.nn.Module):
         self._engines: Dict[tuple, Engine] = {}
         self._primary: Optional[Engine] = None
         self._anchor = None
+        self._ddp_reducer = None      # set by dist.DistributedDataParallel
         self._init_seed_state = torch.random.get_rng_state() if seed is None else None
 
     # -- engines are shape-specialised and built lazily; all of them share one parameter store
@@ -352,7 +358,8 @@ class ArenaOptimizer:
             n = math.prod(p.shape)
             self.m[p.offset:p.offset + n].copy_(s["exp_avg"].reshape(-1).to(self.m.device, torch.float32))
             self.v[p.offset:p.offset + n].copy_(s["exp_avg_sq"].reshape(-1).to(self.v.device, torch.float32))
-            self.step_count = int(float(s["step"]))
+            # torch.optim keeps 'step' per parameter; apex FusedLAMB keeps it in the param group
+            self.step_count = int(float(s["step"])) if "step" in s else int(g.get("step", 0))
 
 
 class Adam(ArenaOptimizer):
@@ -413,8 +420,9 @@ def get_lr_schedule(start_lr, scheduler_arg, optimizer, last_step=-1):
 
 class GradualWarmupScheduler:
     """PARITY UNPINNED stand-in for ildoonet/pytorch-gradual-warmup-lr (train_hdf5_ddp.py:251-253): linear ramp of the lr
-    from base to base*multiplier over total_epoch steps, then hands over to after_scheduler (whose lr is scaled by
-    multiplier at the hand-over, as that package does)."""
+    from base to base*multiplier over total_epoch steps -- or, for multiplier == 1.0 (the reference's default
+    --lr_warmup_factor), from 0 to base as that package's get_lr does -- then hands over to after_scheduler (whose lr is
+    scaled by multiplier at the hand-over)."""
 
     def __init__(self, optimizer, multiplier, total_epoch, after_scheduler=None):
         if multiplier < 1.0:
@@ -433,7 +441,10 @@ class GradualWarmupScheduler:
                 self.finished = True
             return
         for g, b in zip(self.optimizer.param_groups, self.base_lrs):
-            g["lr"] = b * ((self.multiplier - 1.0) * self.last_epoch / self.total_epoch + 1.0)
+            if self.multiplier == 1.0:
+                g["lr"] = b * (float(self.last_epoch) / self.total_epoch)
+            else:
+                g["lr"] = b * ((self.multiplier - 1.0) * self.last_epoch / self.total_epoch + 1.0)
 
     def get_last_lr(self):
         return [g["lr"] for g in self.optimizer.param_groups]
@@ -464,7 +475,13 @@ class TrainStep:
         self.pred = torch.empty((batch, height, width), dtype=torch.int64, device=dev) if with_metrics else None
         self.counts = torch.zeros(9, dtype=torch.int64, device=dev) if with_metrics else None
         self.npix = batch * height * width
-        self.after_backward = None      # e.g. dist.GradReducer.finish
+        self.after_backward = None      # set by attach_reducer
+
+    def attach_reducer(self, reducer) -> None:
+        """Data parallelism for the fused step: the reducer's buckets are all-reduced (SUM) while backward runs, the step
+        waits for them before the optimizer and the 1/world averaging rides in the optimizer kernel (no extra pass)."""
+        self.after_backward = reducer.finish
+        self.opt.grad_scale = 1.0 / reducer.world
 
     def launch(self, x: torch.Tensor, labels: torch.Tensor) -> None:
         eng = self.eng

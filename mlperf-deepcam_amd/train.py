@@ -153,8 +153,6 @@ def main(pargs):
     class_weights = dnn.class_weights(pargs.loss_weight_pow)
     optimizer = dnn.make_optimizer(pargs.optimizer, net, pargs.start_lr, pargs.adam_eps, pargs.weight_decay)
     ddp = comm.DistributedDataParallel(net)
-    if ddp.reducer is not None:
-        optimizer.grad_scale = 1.0 / size
 
     if pargs.checkpoint:
         checkpoint = torch.load(pargs.checkpoint, map_location=device, weights_only=False)
@@ -192,8 +190,10 @@ def main(pargs):
                                           allow_uneven_distribution=True, shuffle=(pargs.max_validation_steps is not None),
                                           preprocess=True, comm_size=size, comm_rank=rank)
         assert tuple(train_set.data_shape[:2]) == (H, W), "pass --height/--width matching the files"
-    train_loader = ddata.InputPipeline(train_set, B, dtype=dtype, device=device)
-    validation_loader = ddata.InputPipeline(validation_set, 1, dtype=dtype, device=device)
+    # channel counts the MFMA stem does not take go through the direct stem kernel, which reads the reference's NCHW fp32 batch
+    layout = "nhwc" if net.engine.x0 is not None else "nchw"
+    train_loader = ddata.InputPipeline(train_set, B, dtype=dtype, device=device, layout=layout)
+    validation_loader = ddata.InputPipeline(validation_set, 1, dtype=dtype, device=device, layout=layout)
     logger.log_event(key="train_samples", value=train_set.global_size)
     val_size = validation_set.global_size if pargs.max_validation_steps is None else \
         min([validation_set.global_size, pargs.max_validation_steps * B * size])
@@ -203,7 +203,7 @@ def main(pargs):
 
     train_step = dnn.TrainStep(net, optimizer, class_weights, B, H, W, with_metrics=True)
     if ddp.reducer is not None:
-        train_step.after_backward = ddp.reducer.finish
+        train_step.attach_reducer(ddp.reducer)
     step, epoch = start_step, start_epoch
     current_lr = pargs.start_lr if scheduler is None else scheduler.get_last_lr()[0]
     stop_training = False

@@ -8,7 +8,7 @@ vectors produced with torch.optim itself through the reference model (tests/gold
 LAMB and warm-up are PARITY UNPINNED: apex and pytorch-gradual-warmup-lr are neither vendored
 in the reference nor installable here.  Their definition below is this project's own, taken from
 You et al. 2019 and apex's documented FusedLAMB defaults (bias correction on, max_grad_norm 1.0,
-adam_w_mode on, betas (0.9, 0.999)).
+adam_w_mode on, betas (0.9, 0.999), use_nvlamb off: trust ratio only where weight_decay != 0).
 """
 from __future__ import annotations
 
@@ -57,7 +57,9 @@ class OracleOptimizer:
                 upd = (m / bc1) / ((v / bc2).sqrt() + self.eps) + self.wd * p
                 wn = float(p.double().norm())
                 un = float(upd.double().norm())
-                ratio = wn / un if (wn > 0 and un > 0) else 1.0
+                # apex multi_tensor_lamb stage 2 with use_nvlamb=False (FusedLAMB's default): the trust ratio is applied only to
+                # tensors whose weight decay is non-zero
+                ratio = wn / un if (self.wd != 0 and wn > 0 and un > 0) else 1.0
                 p.add_(upd, alpha=-self.lr * ratio)
 
 
@@ -91,8 +93,11 @@ class MultiStepSchedule:
 
 
 def warmup_lr(start_lr: float, factor: float, warmup_steps: int, step: int, after_lr: float) -> float:
-    """PARITY UNPINNED.  Linear ramp start_lr -> start_lr*factor over warmup_steps, then the wrapped schedule * factor."""
+    """PARITY UNPINNED.  Linear ramp start_lr -> start_lr*factor over warmup_steps (0 -> start_lr when factor == 1.0, as
+    pytorch-gradual-warmup-lr's get_lr does), then the wrapped schedule * factor."""
     if warmup_steps > 0 and step <= warmup_steps:
+        if factor == 1.0:
+            return start_lr * (float(step) / warmup_steps)
         return start_lr * (1.0 + (factor - 1.0) * step / warmup_steps)
     return after_lr * factor
 

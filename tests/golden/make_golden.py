@@ -14,6 +14,7 @@ regenerated from seeds by the tests; expected outputs are stored here):
   block_kat.npz        G3  reference Block forward/backward at small channel counts (in-place ReLU quirk)
   model_small.json     G4  64x96 B=2: logits samples, loss, IoU, grad checksums, 3 steps Adam and AdamW, eval B=1
   model_full.json      G4  768x1152 B=2 (only with --full)
+  model_full_b4.json   G4  768x1152 B=4, two Adam steps (only with --full or --only full_b4)
   lr_schedule.json     G5  MultiStepLR sequences through the reference's get_lr_schedule
 """
 import argparse
@@ -163,14 +164,14 @@ def g3_blocks():
     np.savez_compressed(os.path.join(HERE, "block_kat.npz"), **out)
 
 
-def run_model_steps(H, W, optimizer_name, nsteps, wd):
+def run_model_steps(H, W, optimizer_name, nsteps, wd, B=2):
     net = build_ref_model()
     net.train()
     if optimizer_name == "Adam":
         opt = torch.optim.Adam(net.parameters(), lr=1e-3, eps=1e-8, weight_decay=wd)
     else:
         opt = torch.optim.AdamW(net.parameters(), lr=1e-3, eps=1e-8, weight_decay=wd)
-    x, y = make_inputs(2, H, W)
+    x, y = make_inputs(B, H, W)
     idx = None
     steps = []
     for s in range(nsteps):
@@ -245,6 +246,13 @@ def g4_model_full():
     json.dump(out, open(os.path.join(HERE, "model_full.json"), "w"), indent=0)
 
 
+def g4_model_full_b4():
+    """BASELINE configs[2]'s batch (local_batch 4) at full size: two Adam steps of the reference."""
+    out = {"recipe": "as model_small.json with B=4", "H": 768, "W": 1152, "B": 4}
+    out["adam_wd1e-6"], _ = run_model_steps(768, 1152, "Adam", 2, 1e-6, B=4)
+    json.dump(out, open(os.path.join(HERE, "model_full_b4.json"), "w"), indent=0)
+
+
 def g5_lr():
     out = {}
     arg = {"type": "multistep", "milestones": "3 6", "decay_rate": "0.1"}
@@ -288,4 +296,6 @@ if __name__ == "__main__":
         g4_model_small()
     if a.full or a.only == "full":
         g4_model_full()
+    if a.full or a.only == "full_b4":
+        g4_model_full_b4()
     print("golden fixtures written to", HERE)

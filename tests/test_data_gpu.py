@@ -93,3 +93,49 @@ def test_pipeline_over_real_hdf5_files_matches_host_normalisation(tmp_path):
         assert names == ds.files[2 * b:2 * b + 2]
         nb += 1
     assert nb == 2
+
+
+def test_abandoned_iteration_does_not_corrupt_the_next_one():
+    """train.py breaks out of the validation loader at --max_validation_steps: the next iteration must hand out every batch
+    once, with the right contents (a slot of the abandoned iteration used to be queued twice)."""
+    ds = ddata.SyntheticHWC(12, 16, 24)
+    pipe = ddata.InputPipeline(ds, 2, dtype=torch.float32, depth=2, workers=2)
+    for rounds in range(3):
+        for b, (x, y, names) in enumerate(pipe):
+            if b == 1:
+                break                                                     # abandon with a batch staged and one handed out
+        seen = []
+        for b, (x, y, names) in enumerate(pipe):
+            xr, yr = _reference_batch(ds, 2 * b, 2)
+            assert torch.equal(x.cpu().permute(0, 3, 1, 2), xr) and torch.equal(y.cpu(), yr), (rounds, b)
+            seen += names
+        assert seen == ds.files[:12]
+
+
+@pytest.mark.parametrize("channels", [[0, 1, 2], [0, 1, 2, 3, 4, 5, 6, 10, 12, 15]], ids=["c3", "c10"])
+def test_channel_subsets_the_mfma_stem_does_not_take(channels):
+    """--channels subsets are legal in the reference (train_hdf5_ddp.py:561): counts that are not a multiple of 8 run the direct
+    stem kernel; batches from the pipeline (NHWC) and the reference's NCHW batches give the same step."""
+    H, W, B = 32, 48, 2
+    ds = ddata.SyntheticHWC(4, H, W, channels=channels)
+    cw = dnn.class_weights()
+    res = []
+    for use_pipe in (True, False):
+        net = dnn.DeepLabv3_plus(len(channels), 3, os=16, _print=False, dtype=torch.bfloat16, seed=333)
+        net.materialize(B, H, W)
+        assert net.engine.x0 is None
+        opt = dnn.make_optimizer("Adam", net, 1e-3, 1e-8, 1e-6)
+        step = dnn.TrainStep(net, opt, cw, B, H, W)
+        if use_pipe:
+            for b, (x, y, _) in enumerate(ddata.InputPipeline(ds, B, dtype=torch.bfloat16, depth=2, layout="nchw")):
+                assert x.shape == (B, len(channels), H, W) and x.dtype == torch.float32
+                assert torch.equal(x.cpu(), _reference_batch(ds, b * B, B)[0])
+                step(x, y)
+        else:
+            for b in range(2):
+                x, y = _reference_batch(ds, b * B, B)
+                step(x.to(DEV), y.to(DEV))
+        torch.cuda.synchronize()
+        assert np.isfinite(step.loss())
+        res.append(net.engine.params.clone())
+    assert torch.equal(res[0], res[1])

@@ -209,6 +209,30 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
     assert_close(gw.cpu(), gw_ref, dtype, f32=3e-4, bf16=1e-2)
 
 
+# The shapes that carry the FLOPs of the benchmarked step, at their real extents: the cases above are tiny.
+FULL_CASES = [
+    # name, k, stride, pad, dil, transposed, cin, cout, N, H, W
+    ("full_pw728_b8", 1, 1, 0, 1, 0, 728, 728, 8, 48, 72),            # M = 27 648: the middle-flow pointwise conv at local batch 8
+    ("full_aspp_d18", 3, 1, 18, 18, 0, 2048, 256, 2, 48, 72),         # ASPP, dilation 18 (most taps of border pixels fall outside)
+    ("full_aspp_d6", 3, 1, 6, 6, 0, 2048, 256, 1, 48, 72),
+    ("full_dec304", 3, 1, 1, 1, 0, 304, 256, 1, 192, 288),            # decoder conv over the 256+48 concat
+    ("full_convT256", 3, 2, 1, 1, 1, 256, 256, 1, 192, 288),          # the 192x288 -> 384x576 transposed conv
+    ("full_pw1536_2048", 1, 1, 0, 1, 0, 1536, 2048, 2, 48, 72),
+    ("full_pw128_thin", 1, 1, 0, 1, 0, 128, 128, 1, 384, 576),
+]
+
+
+@pytest.mark.parametrize("case", FULL_CASES, ids=[c[0] for c in FULL_CASES])
+def test_conv_full_shapes(case):
+    """Forward (+ BatchNorm partial sums, accumulate, bias), data gradient and weight gradient at the benchmark's real layer
+    shapes against F.conv2d / autograd on the CPU, bf16 storage (the benchmarked dtype), default tile planner."""
+    test_conv_fwd_dgrad_wgrad(case, torch.bfloat16)
+
+
+def test_conv_full_shape_pw728_fp32():
+    test_conv_fwd_dgrad_wgrad(("full_pw728_b2_f32", 1, 1, 0, 1, 0, 728, 728, 2, 48, 72), torch.float32)
+
+
 MIX_CASES = [
     # name, k, stride, pad, dil, transposed, cin, cout, N, H, W, cus, tail_pct
     ("pw_3_tiles_on_2", 1, 1, 0, 1, 0, 64, 256, 2, 20, 16, 2, 60),          # 640 px: 512 on the 256-tile kernel, 128 on the small one
@@ -805,7 +829,9 @@ def test_adam_matches_torch_optim(kind, wd):
         np.testing.assert_allclose(p[:n].cpu().numpy(), pr.detach().numpy(), rtol=2e-6, atol=2e-7)
 
 
-def test_lamb_matches_oracle():
+@pytest.mark.parametrize("wd", [1e-2, 0.0], ids=["wd1e-2", "wd0_no_trust_ratio"])
+def test_lamb_matches_oracle(wd):
+    """wd == 0: apex FusedLAMB (use_nvlamb=False) skips the trust ratio.  The gradient arena is only read (header contract)."""
     from oracle.optim import OracleOptimizer
     sizes = [1000, 7, 4096, 33, 10001]   # one tensor of exactly one chunk, one of 2.4 chunks
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
@@ -813,7 +839,7 @@ def test_lamb_matches_oracle():
     p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=3.0)
     p0[offs[1]:offs[2]] = 0.0        # a zero-norm tensor -> trust ratio 1
     cpu_p = [p0[offs[i]:offs[i + 1]].clone() for i in range(len(sizes))]
-    ref = OracleOptimizer(cpu_p, "LAMB", lr=1e-2, eps=1e-6, weight_decay=1e-2)
+    ref = OracleOptimizer(cpu_p, "LAMB", lr=1e-2, eps=1e-6, weight_decay=wd)
     p = p0.clone().to(dev())
     m, v = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
     lr = torch.tensor([1e-2], device=dev())
@@ -825,10 +851,11 @@ def test_lamb_matches_oracle():
         ref.step([gs[offs[i]:offs[i + 1]] for i in range(len(sizes))])
         gd = gs.clone().to(dev())
         step.fill_(s)
-        L.call("dc_lamb_step", len(sizes), vptr(od), n, vptr(p), vptr(gd), vptr(m), vptr(v), vptr(lr), 0.9, 0.999, 1e-6, 1e-2, vptr(step),
+        L.call("dc_lamb_step", len(sizes), vptr(od), n, vptr(p), vptr(gd), vptr(m), vptr(v), vptr(lr), 0.9, 0.999, 1e-6, wd, vptr(step),
                1.0, 1.0, vptr(ws), S())
         torch.cuda.synchronize()
         np.testing.assert_allclose(p.cpu().numpy(), torch.cat(cpu_p).numpy(), rtol=2e-5, atol=2e-6)
+        assert torch.equal(gd.cpu(), gs), "dc_lamb_step must leave the gradient arena untouched"
 
 
 def test_lamb_is_bit_reproducible():

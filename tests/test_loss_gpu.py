@@ -77,3 +77,18 @@ def test_confusion_counts_entry_point():
     torch.cuda.synchronize()
     tp, fp, fn = olm.confusion_counts(pred.numpy(), gt.numpy())
     np.testing.assert_array_equal(counts.cpu().numpy(), np.concatenate([tp, fp, fn]))
+
+
+@pytest.mark.parametrize("bad,dtype", [(3, torch.int64), (-1, torch.int64), (2 ** 32, torch.int64), (255, torch.uint8), (7, torch.int32)])
+def test_out_of_range_label_poisons_the_loss(bad, dtype):
+    """The reference's nn.CrossEntropyLoss raises for a label outside [0,3) (utils/losses.py:36).  A kernel cannot raise and the
+    ABI never synchronises: the loss and that pixel's gradient come back NaN instead of the pixel being dropped silently."""
+    g = torch.Generator().manual_seed(3)
+    logit = torch.randn(2, 3, 16, 24, generator=g)
+    target = torch.randint(0, 3, (2, 16, 24), generator=g).to(dtype)
+    loss, grad, _, _ = _run(logit, target)
+    assert np.isfinite(loss) and torch.isfinite(grad).all()
+    target[1, 5, 7] = bad
+    loss, grad, _, _ = _run(logit, target)
+    assert np.isnan(loss)
+    assert torch.isnan(grad[1, :, 5, 7]).all() and int(torch.isnan(grad).sum()) == 3

@@ -227,5 +227,11 @@ def test_lamb_is_self_consistent():
     assert float(delta) == pytest.approx(1e-2 * float(before[0].norm()), rel=1e-4)
     # zero-norm weights fall back to ratio 1
     assert float((p[1] - before[1]).abs().max()) > 0
+    # apex use_nvlamb=False: without weight decay there is no trust ratio -- the step is lr * (bias-corrected Adam direction)
+    q = [torch.randn(64, 32)]
+    q0 = q[0].clone()
+    gq = [torch.randn(64, 32) * 0.01]           # below the clipping norm: the first step's direction is sign(g) up to eps
+    ooptim.OracleOptimizer(q, "LAMB", lr=1e-2, weight_decay=0.0).step(gq)
+    assert float((q[0] - q0).abs().max()) == pytest.approx(1e-2, rel=1e-3)
     with pytest.raises(NotImplementedError):
         ooptim.OracleOptimizer(p, "SGD", lr=1e-2)
