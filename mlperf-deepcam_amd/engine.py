@@ -44,6 +44,7 @@ class Act:
             self.ld = Cc if Cc < 64 else (Cc + 31) // 32 * 32
             self.buf = torch.empty((N, H, W, self.ld), dtype=dtype or eng.dtype, device=eng.device)
             eng.act_bytes += self.buf.numel() * self.buf.element_size()
+            eng.saved[name] = self.buf
         else:
             assert (parent.N, parent.H, parent.W) == (N, H, W) and off + Cc <= parent.C
             self.buf, self.ld = parent.buf, parent.ld
@@ -127,6 +128,9 @@ class Engine:
         self.layout = S.Layout(n_input, n_classes)
         lay = self.layout
         self.act_bytes = 0
+        # name -> tensor of everything forward leaves behind for backward (activations, BatchNorm coefficient vectors): lets a
+        # test put two engines on ONE linearisation point (tests/test_model_gpu.py::test_backward_parity_at_shared_activations)
+        self.saved: Dict[str, torch.Tensor] = {}
 
         # ---- flat arenas (shared between engines of different batch shape, e.g. train B=2 and validation B=1) ----
         if share_from is not None:
@@ -462,6 +466,8 @@ class Engine:
             o = out or Act(self, name or bname, y.N, y.H, y.W, Cc, dtype=y.buf.dtype)
             assert o.buf.dtype == y.buf.dtype
         scale, shift, mean, invstd = (self._f32(Cc) for _ in range(4))
+        for suffix, t in ((".scale", scale), (".shift", shift), (".save_mean", mean), (".save_invstd", invstd)):
+            self.saved[bname + suffix] = t
         gam, bet = self.pptr(bname + ".weight"), self.pptr(bname + ".bias")
         rm, rv = self.bptr(bname + ".running_mean"), self.bptr(bname + ".running_var")
         nbt = C.c_void_p(self.nbt.data_ptr() + 8 * self.layout.nbt[bname + ".num_batches_tracked"])

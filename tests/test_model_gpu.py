@@ -42,12 +42,19 @@ def oracle_small():
     return (x, y) + _oracle_step(x, y)
 
 
-# Gradient tolerances: with B=2 the 77 train-mode BatchNorms make the backward pass ill-conditioned -- against an fp64
-# evaluation of the oracle, PyTorch's own CPU fp32 gradients are off by 1-3 % (relative L2, per tensor) at this size, and
-# the fp32 HIP engine shows the same figures (scripts/debug_grads.py; DESIGN.md "numerics").  So fp32-vs-fp32 per-tensor
-# agreement is bounded by ~2x that noise; the loss itself is well conditioned and is held to north_star's 1e-3.
-@pytest.mark.parametrize("dtype,ltol,gtol", [(torch.float32, 2e-5, 8e-2), (torch.bfloat16, 5e-3, 10.0)], ids=["f32", "bf16"])
-def test_forward_backward_vs_oracle(oracle_small, dtype, ltol, gtol):
+# Gradient tolerances.  With B=2 the 77 train-mode BatchNorms make the backward pass ill-conditioned: against an fp64 evaluation
+# of the oracle, PyTorch's own CPU fp32 gradients are off by 1-3 % (relative L2, per tensor) at this size and the fp32 HIP engine
+# shows the same figures (scripts/debug_grads.py), so fp32-vs-fp32 per-tensor agreement is bounded by ~2x that noise.
+# bf16 gradients are NOT compared with the oracle's: the measurement behind that decision is scripts/grad_check.py
+# (profiles/r02_grad_check.txt) -- at 768x1152 the fp32 engine's gradient agrees with central differences of its own loss, while
+# the bf16 gradient's projection on the fp32 encoder gradient is 0.16 (cosine over the whole arena 0.56, decoder 0.995): the
+# randomly initialised network amplifies bf16's 4e-3 rounding of the activations beyond the radius in which the gradient is
+# constant.  What IS checked for bf16: the loss (north_star's quantity); backward kernel by kernel (test_kernels_gpu.py, incl. the
+# full layer shapes); the whole backward program against the fp32 engine at ONE shared linearisation point
+# (test_backward_parity_at_shared_activations); and directional derivatives where the problem is well conditioned
+# (test_directional_derivatives_full_size).
+@pytest.mark.parametrize("dtype,ltol", [(torch.float32, 2e-5), (torch.bfloat16, 5e-3)], ids=["f32", "bf16"])
+def test_forward_backward_vs_oracle(oracle_small, dtype, ltol):
     x, y, sd, keys, out_ref, loss_ref = oracle_small
     eng = Engine(2, 64, 96, dtype, seed=333)
     # identical initial weights, bit for bit
@@ -60,6 +67,9 @@ def test_forward_backward_vs_oracle(oracle_small, dtype, ltol, gtol):
     loss = float(s.item()) / y.numel()
     assert loss == pytest.approx(loss_ref, rel=ltol)                     # north_star: 1e-3 relative
     lg = logits.cpu()
+    allg = torch.cat([eng.grad_view(k).cpu().flatten() for k in keys])
+    allr = torch.cat([sd[k].grad.flatten() for k in keys])
+    assert torch.isfinite(allg).all()
     if dtype == torch.float32:
         np.testing.assert_allclose(lg.numpy(), out_ref.numpy(), rtol=2e-3, atol=2e-3)
         # label argmax: identical except where the top-2 logits are closer than fp32 re-association noise
@@ -67,24 +77,22 @@ def test_forward_backward_vs_oracle(oracle_small, dtype, ltol, gtol):
         top2 = out_ref.sort(1, descending=True)[0]
         margin = (top2[:, 0] - top2[:, 1]).numpy()
         assert np.all((a == b) | (margin < 5e-3))
-    # (bf16: single logits are NOT comparable.  The randomly initialised 77-BatchNorm network amplifies a relative input
-    #  perturbation of 1e-6 into a 3e-4 change of the logits and a 3 % change of the gradients even in fp32
-    #  (scripts/sensitivity.py, profiles/sensitivity_r01.txt), so bf16's 4e-3 rounding decorrelates them; the loss, which
-    #  north_star pins, is insensitive: 2e-7.)
-    # gradients of every one of the 301 parameter tensors
-    worst = ("", 0.0)
-    for k in keys:
-        g, r = eng.grad_view(k).cpu(), sd[k].grad
-        e = _rel_l2(g, r)
-        if e > worst[1]:
-            worst = (k, e)
-    assert worst[1] < gtol, f"worst gradient {worst}"
-    allg = torch.cat([eng.grad_view(k).cpu().flatten() for k in keys])
-    allr = torch.cat([sd[k].grad.flatten() for k in keys])
-    total = _rel_l2(allg, allr)
-    print(f"[{dtype}] loss {loss:.7f} vs {loss_ref:.7f}; worst per-tensor grad err {worst}; whole-arena grad err {total:.3e}")
-    assert total < (3e-2 if dtype == torch.float32 else 2.0)
-    assert torch.isfinite(allg).all()
+        # gradients of every one of the 301 parameter tensors
+        worst = ("", 0.0)
+        for k in keys:
+            e = _rel_l2(eng.grad_view(k).cpu(), sd[k].grad)
+            if e > worst[1]:
+                worst = (k, e)
+        total = _rel_l2(allg, allr)
+        print(f"[fp32] loss {loss:.7f} vs {loss_ref:.7f}; worst per-tensor grad err {worst}; whole-arena grad err {total:.3e}")
+        assert worst[1] < 8e-2, f"worst gradient {worst}"
+        assert total < 3e-2
+    else:
+        # a descent direction of the right magnitude, no more (measured at this size: cosine 0.18, norm ratio 0.85)
+        cos = float((allg.double() @ allr.double()) / (allg.double().norm() * allr.double().norm()))
+        ratio = float(allg.double().norm() / allr.double().norm())
+        print(f"[bf16] loss {loss:.7f} vs {loss_ref:.7f}; gradient cosine with the oracle {cos:.4f}, norm ratio {ratio:.4f}")
+        assert cos > 0.05 and 0.6 < ratio < 1.4
     # BatchNorm running statistics were updated exactly once
     for k in ("xception_features.bn1", "xception_features.block4.rep.2", "global_avg_pool.2", "upsample.deconv3.1"):
         np.testing.assert_allclose(eng.buffer_view(k + ".running_mean").cpu().numpy(), sd[k + ".running_mean"].numpy(),
@@ -207,7 +215,9 @@ def test_golden_full_size_step0(golden_dir, dtype, tol):
         np.testing.assert_allclose(logits.flatten()[idx].cpu().numpy(), np.array(ref["logit_samples"]), rtol=2e-3, atol=2e-3)
     for k, d in ref["grad_digest"].items():
         got = float(eng.grad_view(k).double().abs().sum())
-        assert got == pytest.approx(d["abs"], rel=5e-3 if dtype == torch.float32 else 0.5), k
+        # abs-sums: fp32 measured within 2.3e-3 of the reference, bf16 within 0.11 (profiles/r02_grad_check.txt); an all-zero or
+        # mis-scaled tensor fails either bound (a sign flip does not: see test_backward_parity_at_shared_activations for that)
+        assert got == pytest.approx(d["abs"], rel=5e-3 if dtype == torch.float32 else 0.2), k
     assert torch.isfinite(eng.grads).all()
 
 
@@ -261,3 +271,208 @@ def test_steps_enqueued_ahead_match_synchronised_steps():
 
     for a, b in zip(run(True), run(False)):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs beyond B=2 step 0, and well-conditioned backward checks
+# ------------------------------------------------------------------------------------------------------------------------------
+def _full_steps(B, dtype, nsteps, optname="Adam", wd=1e-6):
+    x, y = make_inputs(B, 768, 1152)
+    net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=dtype, seed=333)
+    net.materialize(B, 768, 1152)
+    opt = dnn.make_optimizer(optname, net, 1e-3, 1e-8, wd)
+    step = dnn.TrainStep(net, opt, CW, B, 768, 1152, with_metrics=True)
+    xd, yd = x.to(DEV), y.to(DEV)
+    out = []
+    for _ in range(nsteps):
+        step(xd, yd)
+        torch.cuda.synchronize()
+        out.append((step.loss(), step.iou(), [int((step.pred == j).sum()) for j in range(3)]))
+    return out, net
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("B,fixture", [(2, "model_full.json"), (4, "model_full_b4.json")], ids=["b2", "b4"])
+def test_golden_full_size_two_adam_steps(golden_dir, B, fixture, dtype):
+    """768x1152 at local batch 2 (configs[1]) and 4 (configs[2]): loss, IoU and argmax histogram of TWO Adam steps against the
+    reference's own run.  Step 0 is a pure function of identical weights.  Step 1 follows an Adam update of lr*sign(g) on every
+    weight: measured (scripts/grad_check.py, profiles/r02_grad_check.txt) fp32 1.6e-4 / 1.8e-4 off the reference at B=2 / 4 --
+    inside north_star's 1e-3 -- and bf16 3.4e-3 / 1.6e-3 (its gradient is noisier, see above), held to 1e-2."""
+    g = json.load(open(os.path.join(golden_dir, fixture)))
+    ref = g["adam_wd1e-6"]["steps"]
+    got, net = _full_steps(B, dtype, 2)
+    f32 = dtype == torch.float32
+    ltol = ((2e-5, 1e-3) if f32 else (1e-3, 1e-2))
+    itol = ((1e-3, 5e-3) if f32 else (5e-3, 1e-2))
+    for s in range(2):
+        loss, iou, hist = got[s]
+        print(f"[B={B} {dtype} step {s}] loss {loss:.7f} vs {ref[s]['loss']:.7f} (rel {abs(loss - ref[s]['loss']) / ref[s]['loss']:.2e}); "
+              f"iou {iou:.6f} vs {ref[s]['iou']:.6f}; argmax histogram {hist} vs {ref[s]['pred_hist']}")
+        assert loss == pytest.approx(ref[s]["loss"], rel=ltol[s]), f"step {s}"
+        assert iou == pytest.approx(ref[s]["iou"], rel=itol[s]), f"step {s}"
+        assert sum(hist) == B * 768 * 1152
+        # argmax histogram: every class count within 2 % (fp32: 0.2 %) of the image away from the reference's
+        tol_px = (0.002 if f32 else 0.02) * B * 768 * 1152
+        assert all(abs(a - b) <= tol_px for a, b in zip(hist, ref[s]["pred_hist"])), (hist, ref[s]["pred_hist"])
+    if f32:
+        dg = g["adam_wd1e-6"]["final_state_digest"]
+        sd = net.state_dict()
+        assert int(sd["xception_features.bn1.num_batches_tracked"]) == 2
+        for k in ("xception_features.bn1.running_mean", "xception_features.bn1.running_var", "global_avg_pool.2.running_var"):
+            assert float(sd[k].double().abs().sum()) == pytest.approx(dg[k]["abs"], rel=2e-3), k
+
+
+def test_bench_configuration_b8_lamb_full_size():
+    """BASELINE configs[4]'s per-GPU shape, the one bench.py times: local batch 8, bf16, LAMB, 768x1152.  Finite, bit-reproducible
+    across two independently built models, and the bf16 loss curve against the fp32 engine's: 1e-3 at step 0 (same weights);
+    after LAMB updates the two precisions part -- measured 7.2e-3 at step 1 and 1.5e-2 at step 2 -- and both keep descending."""
+    runs = [_full_steps(8, torch.bfloat16, 3, "LAMB", 1e-2) for _ in range(2)]
+    (a, neta), (b, netb) = runs
+    assert torch.equal(neta.engine.params, netb.engine.params) and torch.equal(neta.engine.buffers, netb.engine.buffers)
+    assert [v[1:] for v in a] == [v[1:] for v in b]                      # IoU and histograms bit-equal (the loss is a fp64 atomic sum)
+    assert torch.isfinite(neta.engine.params).all() and torch.isfinite(neta.engine.grads).all()
+    del netb, runs
+    torch.cuda.empty_cache()
+    f, _ = _full_steps(8, torch.float32, 3, "LAMB", 1e-2)
+    for s, tol in enumerate((1e-3, 2e-2, 4e-2)):
+        print(f"[B=8 LAMB step {s}] bf16 {a[s][0]:.7f} fp32 {f[s][0]:.7f} rel {abs(a[s][0] - f[s][0]) / f[s][0]:.2e}")
+        assert a[s][0] == pytest.approx(f[s][0], rel=tol), f"step {s}"
+    assert a[0][0] > a[1][0] > a[2][0] and f[0][0] > f[1][0] > f[2][0]  # the curve descends in both precisions
+
+
+def test_lamb_step_fp32_engine_vs_oracle_b8():
+    """The bench configuration's optimizer against the oracle at a size the oracle affords (B=8, 64x96): loss of step 0 to 2e-5,
+    and the loss AFTER one LAMB update (which depends on every gradient through the global norm and the trust ratios)."""
+    B, H, W = 8, 64, 96
+    x, y = make_inputs(B, H, W)
+    sd = omodel.init_state(333)
+    keys = omodel.param_keys(sd)
+    params = [sd[k].requires_grad_(True) for k in keys]
+    opt = ooptim.OracleOptimizer([p.detach() for p in params], "LAMB", lr=1e-3, eps=1e-8, weight_decay=1e-2)
+    ref = []
+    for _ in range(2):
+        for p in params:
+            p.grad = None
+        loss = olm.fp_loss(omodel.forward(sd, x, training=True), y, CW)
+        loss.backward()
+        opt.step([p.grad for p in params])
+        ref.append(float(loss.detach()))
+    net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=torch.float32, seed=333)
+    net.materialize(B, H, W)
+    step = dnn.TrainStep(net, dnn.make_optimizer("LAMB", net, 1e-3, 1e-8, 1e-2), CW, B, H, W)
+    got = []
+    for _ in range(2):
+        step(x.to(DEV), y.to(DEV))
+        torch.cuda.synchronize()
+        got.append(step.loss())
+    print(f"[LAMB B=8 64x96] engine {got} oracle {ref}")
+    assert got[0] == pytest.approx(ref[0], rel=2e-5)
+    assert got[1] == pytest.approx(ref[1], rel=3e-4)                      # measured 3.3e-5
+
+
+def _shared_point_engines(B, H, W):
+    """A bf16 and an fp32 engine on ONE linearisation point: identical effective weights (masters rounded to bf16), the bf16
+    engine's forward state (every stored activation, every BatchNorm coefficient vector) copied into the fp32 engine, and the same
+    d(loss)/d(logits).  Backward is then the same LINEAR map in both, evaluated in bf16 and in fp32 arithmetic."""
+    x, y = make_inputs(B, H, W)
+    e16 = Engine(B, H, W, torch.bfloat16, seed=333)
+    e32 = Engine(B, H, W, torch.float32, seed=333)
+    for e in (e16, e32):
+        e.params.copy_(e.params.to(torch.bfloat16).float())
+        e.mark_weights_changed()
+    for e in (e16, e32):
+        lg = e.forward(x.to(DEV), train=True)
+        dnn.wce_fused(lg, y.to(DEV), CW, dlogits=e.dlogits)
+    torch.cuda.synchronize()
+    assert set(e16.saved) == set(e32.saved)
+    for k, t in e16.saved.items():
+        assert e32.saved[k].shape == t.shape, k
+        e32.saved[k].copy_(t)
+    e32.dlogits.copy_(e16.dlogits)
+    e16.backward()
+    e32.backward()
+    torch.cuda.synchronize()
+    return e16, e32
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (2, 768, 1152)], ids=["small", "full"])
+def test_backward_parity_at_shared_activations(B, H, W):
+    """Model-level check of the bf16 BACKWARD kernels (data gradients, weight gradients, depthwise, BatchNorm backward, head) that
+    does not suffer from the network's ill-conditioning: both engines differentiate at the same stored activations, so the only
+    difference is bf16 rounding of the gradient activations along the way.  Per tensor and over the whole arena."""
+    e16, e32 = _shared_point_engines(B, H, W)
+    errs = []
+    for k in e32.layout.params:
+        errs.append((_rel_l2(e16.grad_view(k), e32.grad_view(k)), k))
+    errs.sort(reverse=True)
+    total = _rel_l2(e16.grads, e32.grads)
+    cos = float((e16.grads.double() @ e32.grads.double()) / (e16.grads.double().norm() * e32.grads.double().norm()))
+    med = errs[len(errs) // 2][0]
+    print(f"[shared point {B}x{H}x{W}] whole-arena rel L2 {total:.3e}, cosine {cos:.6f}, median per-tensor {med:.3e}, worst {errs[:4]}")
+    # measured: whole arena 1.3e-2 / 1.6e-2 (full / small), cosine 0.99992 / 0.99987, worst tensor 2.6e-2 / 2.0e-2
+    assert total < 3e-2 and cos > 0.9995
+    assert med < 2.5e-2
+    assert errs[0][0] < 6e-2, errs[:4]
+
+
+def test_directional_derivatives_full_size():
+    """<grad, d> against central differences of the fp32 engine's loss, 768x1152, B=2 (the check VERDICT r01 asks for, where it is
+    well conditioned).  Directions are the fp32 gradient restricted to a parameter group, normalised.  Measured
+    (profiles/r02_grad_check.txt): decoder group -- fp32 5e-6, bf16 0.5 % off the finite difference; all parameters -- fp32
+    converges to its finite difference as eps -> 0 (1.8 % at 1e-3: the loss is that non-linear along its own gradient), bf16's
+    projection is 0.56 of it (no assertion: see the comment at the top of this file)."""
+    B, H, W = 2, 768, 1152
+    x, y = make_inputs(B, H, W)
+    xd, yd = x.to(DEV), y.to(DEV)
+
+    def loss_of(eng, backward):
+        s = torch.zeros(1, dtype=torch.float64, device=DEV)
+        lg = eng.forward(xd, train=True)
+        dnn.wce_fused(lg, yd, CW, dlogits=eng.dlogits if backward else None, loss_sum=s)
+        if backward:
+            eng.backward()
+        torch.cuda.synchronize()
+        return float(s.item()) / yd.numel()
+
+    e32 = Engine(B, H, W, torch.float32, seed=333)
+    loss_of(e32, True)
+    g32 = e32.grads.clone()
+    e16 = Engine(B, H, W, torch.bfloat16, seed=333)
+    loss_of(e16, True)
+    g16 = e16.grads.clone()
+    del e16
+    lay = e32.layout
+    import math
+
+    def direction(sel):
+        d = torch.zeros_like(g32)
+        for n, p in lay.params.items():
+            if sel(n):
+                k = math.prod(p.shape)
+                d[p.offset:p.offset + k] = g32[p.offset:p.offset + k]
+        return d / float(d.double().norm())
+
+    p0 = e32.params.clone()
+
+    def fd(d, eps):
+        vals = []
+        for sgn in (1.0, -1.0):
+            e32.params.copy_(p0 + sgn * eps * d)
+            e32.mark_weights_changed()
+            vals.append(loss_of(e32, False))
+        e32.params.copy_(p0)
+        e32.mark_weights_changed()
+        return (vals[0] - vals[1]) / (2 * eps)
+
+    d_dec = direction(lambda n: n.startswith("upsample.") or n.startswith("conv2") or n.startswith("bn2"))
+    f = fd(d_dec, 3e-3)
+    a32, a16 = float(g32.double() @ d_dec.double()), float(g16.double() @ d_dec.double())
+    print(f"[decoder direction] FD {f:.6e}  <g32,d> {a32:.6e}  <g16,d> {a16:.6e}")
+    assert a32 == pytest.approx(f, rel=1e-3)
+    assert a16 == pytest.approx(f, rel=1.5e-2)                             # measured 5.3e-3
+    d_all = direction(lambda n: True)
+    f = fd(d_all, 2e-4)
+    a32, a16 = float(g32.double() @ d_all.double()), float(g16.double() @ d_all.double())
+    print(f"[whole-gradient direction] FD {f:.6e}  <g32,d> {a32:.6e}  <g16,d> {a16:.6e} (ratio {a16 / a32:.3f})")
+    assert a32 == pytest.approx(f, rel=1.2e-2)                             # measured 3.9e-3 at eps 2e-4
+    assert a16 > 0.25 * a32                      # a descent direction; measured 0.56
