@@ -92,6 +92,14 @@ int dc_conv_fwd(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int
 int dc_conv_fwd_f32out(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,
                        float* y, int ldy, void* stream);
 
+/* The ASPP head (deeplab_xception.py:282-302; aspp2..aspp4 called at :445-447) runs three 3x3 convolutions of dilation 6 / 12 / 18
+ * (padding == dilation, stride 1) over ONE input.  This entry point computes `count` (<= 4) such convolutions in one launch:
+ * member b uses dilation dils[b] (host array), packed weights wfs[b], output view ys[b] (all with ldy) and statistics slab
+ * stat_slabs[b] (NULL array: no statistics).  d->dil / d->pad are ignored, d->k must be 3 and d->stride 1.  Results are
+ * bit-identical to `count` dc_conv_fwd calls (which is what runs when the fused kernel does not serve the dtype). */
+int dc_conv_fwd_dilated_group(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const int* dils, const void* x, int ldx,
+                              const void* const* wfs, void* const* ys, int ldy, float* const* stat_slabs, void* stream);
+
 /* dx = conv_backward_data(dy, w).  Hi, Wi are the FORWARD input extents (= extents of dx). */
 int dc_conv_dgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb,
                   void* dx, int lddx, int accumulate, void* stream);

@@ -21,6 +21,15 @@ struct IgemmParams {
   const void* zero_page;   // 256 zero bytes in device memory (set by the 256-tile launcher)
   int reg_epilogue;        // 256-tile kernel: epilogue from the accumulator registers (set by its launcher)
   int phase_fast;          // 256-tile kernel: consecutive tiles walk the sub-pixel phases of one pixel tile (set by its launcher)
+  // 256-tile kernel, grouped launch (dc_conv_fwd_dilated_group): `ngroup` "same" dilated 3x3 convolutions of ONE input share the
+  // launch.  g holds the unit-dilation tap table (dy, dx in {-1,0,1}); member b gathers at dy*gdil[b], dx*gdil[b], multiplies
+  // by gw[b] and writes gy[b] / gslab[b].  Member 0 is (w, y, slab) above with gdil[0].  ngroup <= 1: plain launch.
+  static constexpr int MAXGROUP = 4;
+  int ngroup;
+  int gdil[MAXGROUP];
+  const void* gw[MAXGROUP - 1];
+  void* gy[MAXGROUP - 1];
+  float* gslab[MAXGROUP - 1];
 };
 // OUT32: the epilogue stores fp32 regardless of T (used by the classifier head, whose logits must not be rounded to bf16)
 
@@ -30,7 +39,7 @@ void igemm256_set_epilogue(int v);
 void igemm256_set_phase_fast(int v);
 // workgroups the 256-tile kernel would launch for this problem
 inline long igemm256_tiles(const IgemmParams& p) {
-  return (long)((p.g.Cout + 255) / 256) * ((p.M - p.m_beg + 255) / 256) * p.g.os * p.g.os;
+  return (long)((p.g.Cout + 255) / 256) * ((p.M - p.m_beg + 255) / 256) * p.g.os * p.g.os * (p.ngroup > 1 ? p.ngroup : 1);
 }
 
 // thinconv.hip: the thin 3x3 stem convolutions (forward and data gradient) without LDS staging of the pixel operand

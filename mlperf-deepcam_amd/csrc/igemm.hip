@@ -534,6 +534,7 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   p.reg_epilogue = 0;
   p.phase_fast = 0;
   p.zero_page = nullptr;
+  p.ngroup = 0;
   p.mtiles = cdiv(M, BM);
   p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
@@ -796,6 +797,55 @@ extern "C" int dc_conv_stat_rows(const dc_conv_desc* d, int N, int Hi, int Wi) {
 extern "C" int dc_conv_fwd(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,
                            const float* bias, void* y, int ldy, float* stat_slab, int accumulate, void* stream) {
   return run_gather(d, kFwd, N, Hi, Wi, x, ldx, wf, bias, y, ldy, stat_slab, accumulate, stream);
+}
+
+// `count` "same" dilated 3x3 convolutions (stride 1, pad == dil) of ONE input in ONE launch of the 256-tile kernel: the three
+// atrous branches of the ASPP head read the same encoder output and are 108 tiles each at local batch 8 (27 at batch 2) on 256
+// CUs; together they fill the chip.  Per output element the arithmetic is that of dc_conv_fwd (same tile, same K order): the
+// results are bit-identical to `count` separate calls, which is also the fallback when the kernel does not serve the layer.
+extern "C" int dc_conv_fwd_dilated_group(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const int* dils, const void* x,
+                                         int ldx, const void* const* wfs, void* const* ys, int ldy, float* const* stat_slabs,
+                                         void* stream) {
+  DC_REQUIRE(d != nullptr && dils != nullptr && wfs != nullptr && ys != nullptr, "dc_conv_fwd_dilated_group: null argument");
+  DC_REQUIRE(count >= 1 && count <= IgemmParams::MAXGROUP, "dc_conv_fwd_dilated_group: count must be 1..4");
+  DC_REQUIRE(!d->transposed && d->k == 3 && d->stride == 1, "dc_conv_fwd_dilated_group: 3x3, stride 1 convolutions only");
+  for (int b = 0; b < count; ++b) DC_REQUIRE(dils[b] >= 1 && wfs[b] != nullptr && ys[b] != nullptr, "dc_conv_fwd_dilated_group: bad member");
+  const bool fused = count > 1 && d->dtype == DC_BF16 && g_igemm256 != 0;
+  if (!fused) {
+    for (int b = 0; b < count; ++b) {
+      dc_conv_desc db = *d;
+      db.dil = db.pad = dils[b];
+      if (int e = run_gather(&db, kFwd, N, Hi, Wi, x, ldx, wfs[b], nullptr, ys[b], ldy, stat_slabs ? stat_slabs[b] : nullptr, 0, stream)) return e;
+    }
+    return 0;
+  }
+  dc_conv_desc du = *d;
+  du.dil = du.pad = 1;                      // unit-dilation tap table; the kernel scales the offsets per member
+  IgemmParams p;
+  if (!build_geom(du, Hi, Wi, kFwd, &p.g)) return dc_fail("dc_conv_fwd_dilated_group: unsupported geometry", __FILE__, __LINE__);
+  if (int e = check_view(x, ldx, p.g.Cin, d->dtype, "dc_conv_fwd_dilated_group input")) return e;
+  for (int b = 0; b < count; ++b) {
+    if (int e = check_view(ys[b], ldy, p.g.Cout, d->dtype, "dc_conv_fwd_dilated_group output")) return e;
+    DC_REQUIRE(((uintptr_t)wfs[b] & 15) == 0, "dc_conv_fwd_dilated_group: weights unaligned");
+  }
+  const long M = (long)N * p.g.Qh * p.g.Qw;
+  DC_REQUIRE(N > 0 && M < (1L << 31) - BM, "dc_conv_fwd_dilated_group: bad pixel count");
+  p.x = x; p.w = wfs[0]; p.y = ys[0]; p.bias = nullptr; p.slab = stat_slabs ? stat_slabs[0] : nullptr;
+  p.N = N; p.ldx = ldx; p.ldy = ldy;
+  p.ldw = (p.g.Cin + 31) / 32 * 32;
+  p.M = (int)M; p.m_beg = 0; p.reg_epilogue = 0; p.phase_fast = 0; p.zero_page = nullptr;
+  p.mtiles = cdiv(M, BM);
+  p.accumulate = 0;
+  p.ngroup = count;
+  for (int b = 0; b < IgemmParams::MAXGROUP; ++b) p.gdil[b] = b < count ? dils[b] : 1;
+  for (int b = 1; b < IgemmParams::MAXGROUP; ++b) {
+    p.gw[b - 1] = b < count ? wfs[b] : nullptr;
+    p.gy[b - 1] = b < count ? ys[b] : nullptr;
+    p.gslab[b - 1] = (b < count && stat_slabs) ? stat_slabs[b] : nullptr;
+  }
+  if (stat_slabs)
+    for (int b = 0; b < count; ++b) DC_REQUIRE(stat_slabs[b] != nullptr, "dc_conv_fwd_dilated_group: statistics for all members or none");
+  return launch_igemm256(p, (hipStream_t)stream);
 }
 
 extern "C" int dc_conv_fwd_f32out(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,

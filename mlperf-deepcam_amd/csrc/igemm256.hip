@@ -84,7 +84,25 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + xslot;
   const int ntile_n = tile % ntn;
-  const int rest = tile / ntn;
+  int rest = tile / ntn;
+  // grouped launch: the members of one pixel tile are neighbours in the tile order (they read the same input rows through one
+  // XCD's L2).  `member` is wave-uniform; the member's pointers and dilation come out of scalar selects (indexing the by-value
+  // argument struct would move it to scratch memory).
+  const int ngroup = p.ngroup > 1 ? p.ngroup : 1;
+  const int member = rest % ngroup;
+  rest /= ngroup;
+  const void* wsel = p.w;
+  void* ysel = p.y;
+  float* slabsel = p.slab;
+  int dilmul = p.ngroup > 1 ? p.gdil[0] : 1;
+#pragma unroll
+  for (int b = 1; b < IgemmParams::MAXGROUP; ++b)
+    if (member == b) {
+      wsel = p.gw[b - 1];
+      ysel = p.gy[b - 1];
+      slabsel = p.gslab[b - 1];
+      dilmul = p.gdil[b];
+    }
   // phase fastest: the sub-pixel phases of a transposed conv have K loops of different length (1/2/2/4 taps), so neighbouring
   // workgroups finish at different times (their write bursts interleave with the others' K loops), and the four phases of one
   // pixel tile read the same input rows through one XCD's L2
@@ -97,8 +115,8 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
   const int tap_beg = g.phase_beg[phase], ntap = g.phase_beg[phase + 1] - tap_beg;
   if (tid < ntap) {
     const Tap tp = g.taps[tap_beg + tid];
-    s_tap[3 * tid] = tp.dy;
-    s_tap[3 * tid + 1] = tp.dx;
+    s_tap[3 * tid] = tp.dy * dilmul;
+    s_tap[3 * tid + 1] = tp.dx * dilmul;
     s_tap[3 * tid + 2] = tp.widx;
   }
   __syncthreads();
@@ -110,7 +128,7 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
   const int lrow = lane >> 2, pslot = lane & 3;
   const int lslot = pslot ^ ((lrow >> 1) & 3);          // logical 16-byte slot this lane fetches (swizzle on the source side)
   const bf16* __restrict__ xg = reinterpret_cast<const bf16*>(p.x);
-  const bf16* __restrict__ wg = reinterpret_cast<const bf16*>(p.w);
+  const bf16* __restrict__ wg = reinterpret_cast<const bf16*>(wsel);
   int rown[2], riy[2], rix[2];
   bool rok[2];
 #pragma unroll
@@ -305,8 +323,8 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
     // BatchNorm sums of the STORED values: over the lane's 8 pixels in registers, over the 16 pixel lanes by DPP; the wave's
     // 128 pixels x 64 channels are exactly its segment of one slab row.
     const bool odd = fg & 1;
-    bf16* __restrict__ yg = reinterpret_cast<bf16*>(p.y);
-    const bool do_stats = p.slab != nullptr;
+    bf16* __restrict__ yg = reinterpret_cast<bf16*>(ysel);
+    const bool do_stats = slabsel != nullptr;
     size_t opix[8];
     bool pok[8];
 #pragma unroll
@@ -392,7 +410,7 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
         const int which = fr >> 3, e = fr & 7;
         const int c = n0 + wc * 64 + (2 * pr + (odd ? 1 : 0)) * 16 + (fg >> 1) * 8 + e;
         if (c < g.Cout && mt128 < p.mtiles)
-          p.slab[((size_t)which * rows + phase * p.mtiles + mt128) * g.Cout + c] = mine;
+          slabsel[((size_t)which * rows + phase * p.mtiles + mt128) * g.Cout + c] = mine;
       }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // LDS-DMA fills of the last slots must land before the LDS is released
@@ -434,8 +452,8 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int e = 0; e < 8; ++e) ssum[h][e] = ssq[h][e] = 0.f;
-  bf16* __restrict__ yg = reinterpret_cast<bf16*>(p.y);
-  const bool do_stats = p.slab != nullptr;
+  bf16* __restrict__ yg = reinterpret_cast<bf16*>(ysel);
+  const bool do_stats = slabsel != nullptr;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll 2
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
       }
     }
   }
-  if (p.slab != nullptr) {
+  if (slabsel != nullptr) {
     __syncthreads();   // everyone is done reading the C tile
     float* red = reinterpret_cast<float*>(smem);   // [half][which][RPP][TN]
 #pragma unroll
@@ -493,7 +511,7 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
         float a = 0.f;
 #pragma unroll
         for (int r = 0; r < RPP; ++r) a += red[(hw * RPP + r) * TN + c];
-        p.slab[((size_t)which * rows + phase * p.mtiles + mt128) * g.Cout + n0 + c] = a;
+        slabsel[((size_t)which * rows + phase * p.mtiles + mt128) * g.Cout + n0 + c] = a;
       }
     }
   }

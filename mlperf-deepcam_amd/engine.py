@@ -156,10 +156,15 @@ class Engine:
         self.fuse_bn_reduce = os.environ.get("DC_FUSE_BN_REDUCE", "1") != "0"   # BN backward sums taken in the consumer dw data-gradient kernel
         self.fuse_bn_into_dw = os.environ.get("DC_FUSE_BN_DW", "1") != "0"   # BN(+ReLU) applied in the consumer depthwise kernel's LDS tile
         self.mask_from_y = os.environ.get("DC_MASK_FROM_Y", "1") != "0"
-        self.wgrad_group = max(1, min(4, int(os.environ.get("DC_WGRAD_GROUP", "1"))))   # layers per grouped weight-gradient launch
+        # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
+        # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 41.23 -> 41.28 -- the fp32 split slabs
+        # (256 KiB per workgroup whatever the batch) are a third of a 728-channel weight gradient's time at batch 2.
+        wg = os.environ.get("DC_WGRAD_GROUP", "auto")
+        self.wgrad_group = (3 if batch < 8 else 1) if wg == "auto" else max(1, min(4, int(wg)))
         self._wg_recs: List[dict] = []
         self.shift_side = os.environ.get("DC_SIDE_SCHEDULE", "eager") == "shift"   # complementary pairing of the two streams
         self._side_deferred: List = []
+        self.aspp_group = os.environ.get("DC_ASPP_GROUP", "1") != "0"      # atrous ASPP branches in one forward launch
         self.par_branches = os.environ.get("DC_PAR_BRANCHES", "0") != "0"    # ASPP branches side by side on their own streams (measured +0.5 ms: off)
         self._branch_streams: List[torch.cuda.Stream] = []
         self._deferred_names: List[str] = []
@@ -315,8 +320,9 @@ class Engine:
     # ------------------------------------------------------------------------------------------------ op builders
     def _conv(self, x: Act, wname: str, cout: int, k: int = 1, stride: int = 1, pad: int = 0, dil: int = 1,
               transposed: bool = False, out: Act = None, stats: bool = True, bias: str = None, name: str = None,
-              need_dx: bool = True, f32: bool = False):
-        """Dense conv (implicit GEMM).  Returns (y, slab, rows)."""
+              need_dx: bool = True, f32: bool = False, fwd_group: list = None):
+        """Dense conv (implicit GEMM).  Returns (y, slab, rows).  fwd_group: a list that collects (dilation, wf, y, slab) instead
+        of this layer's own forward launch (the caller then launches the members together: _dilated_group_fwd)."""
         lib = L.load()
         dt, tdtype = (L.DC_F32, torch.float32) if f32 else (self.dt, self.dtype)
         d = L.ConvDesc(dt, 3 if transposed else k, stride, pad, dil, 1 if transposed else 0, x.C, cout)
@@ -347,8 +353,12 @@ class Engine:
             L.call("dc_conv_fwd", C.byref(d), N, H, W, x.ptr, x.ld, L.dptr(wf), pb, y.ptr, y.ld,
                    L.dptr(slab) if train else None, 0, self._st())
 
-        self.fwd_train.append(lambda: fwd(True))
-        self.fwd_eval.append(lambda: fwd(False))
+        if fwd_group is not None:
+            assert k == 3 and stride == 1 and pad == dil and not transposed and bias is None and not f32
+            fwd_group.append((dil, wf, y, slab, d, x))
+        else:
+            self.fwd_train.append(lambda: fwd(True))
+            self.fwd_eval.append(lambda: fwd(False))
 
         def make_bwd():
             dy = y.grad
@@ -392,6 +402,26 @@ class Engine:
 
         self.bwd.append(make_bwd)
         return y, slab, rows
+
+    def _dilated_group_fwd(self, members: list) -> None:
+        """One launch for the forward of several "same" dilated 3x3 convolutions of one input (the atrous ASPP branches,
+        deeplab_xception.py:445-447): dc_conv_fwd_dilated_group.  Bit-identical to the per-layer launches."""
+        cnt = len(members)
+        d0, x = members[0][4], members[0][5]
+        y0 = members[0][2]
+        assert all(m[5] is x and m[2].ld == y0.ld and (m[2].H, m[2].W, m[2].C) == (y0.H, y0.W, y0.C) for m in members)
+        dils = (C.c_int * cnt)(*[m[0] for m in members])
+        wfs = (C.c_void_p * cnt)(*[m[1].data_ptr() for m in members])
+        slabs = (C.c_void_p * cnt)(*[m[3].data_ptr() for m in members])
+        N, H, W = x.N, x.H, x.W
+
+        def fwd(train: bool):
+            ys = (C.c_void_p * cnt)(*[m[2].ptr.value for m in members])
+            L.call("dc_conv_fwd_dilated_group", C.byref(d0), N, H, W, cnt, dils, x.ptr, x.ld, wfs, ys, y0.ld, slabs if train else None,
+                   self._st())
+
+        self.fwd_train.append(lambda: fwd(True))
+        self.fwd_eval.append(lambda: fwd(False))
 
     def _dw(self, x, wname: str, stride: int, dil: int, name: str) -> Act:
         """Depthwise 3x3.  x is an Act, or a LazyAct (then the preceding BatchNorm+ReLU is applied on load)."""
@@ -658,11 +688,23 @@ class Engine:
             return bwd, []
 
         self.bwd.append(bc_bwd_make)
+        # The atrous branches share ONE forward launch (dc_conv_fwd_dilated_group): each is 108 tiles of the 256-tile kernel at local
+        # batch 8 and 27 at batch 2, on 256 CUs.  (DC_ASPP_GROUP=0 or DC_PAR_BRANCHES=1: one launch per branch.)
+        group = [] if (self.aspp_group and not self.par_branches) else None
+        pending = []
         for i, rate in enumerate(S.ASPP_RATES, start=1):
             self._par_branch()
             k, pad = (1, 0) if rate == 1 else (3, rate)
-            y, slab, rows = self._conv(e, f"aspp{i}.atrous_convolution.weight", 256, k=k, pad=pad, dil=rate, name=f"aspp{i}.conv")
-            self._bn(y, slab, rows, f"aspp{i}.bn", True, out=cat1.slice(f"aspp{i}", 256 * (i - 1), 256))
+            y, slab, rows = self._conv(e, f"aspp{i}.atrous_convolution.weight", 256, k=k, pad=pad, dil=rate, name=f"aspp{i}.conv",
+                                       fwd_group=group if rate != 1 else None)
+            if group is not None and rate != 1:
+                pending.append((y, slab, rows, i))
+            else:
+                self._bn(y, slab, rows, f"aspp{i}.bn", True, out=cat1.slice(f"aspp{i}", 256 * (i - 1), 256))
+        if group:
+            self._dilated_group_fwd(group)
+            for y, slab, rows, i in pending:
+                self._bn(y, slab, rows, f"aspp{i}.bn", True, out=cat1.slice(f"aspp{i}", 256 * (i - 1), 256))
         self._par_end()
         y, slab, rows = self._conv(cat1, "conv1.weight", 256, name="proj")
         p = self._bn(y, slab, rows, "bn1", True)

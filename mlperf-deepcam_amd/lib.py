@@ -46,6 +46,7 @@ _SIGS = {
     "dc_conv_stat_rows": (I, [CD, I, I, I]),
     "dc_conv_fwd": (I, [CD, I, I, I, P, I, P, P, P, I, P, I, P]),
     "dc_conv_fwd_f32out": (I, [CD, I, I, I, P, I, P, P, I, P]),
+    "dc_conv_fwd_dilated_group": (I, [CD, I, I, I, I, P, P, I, P, P, I, P, P]),
     "dc_conv_dgrad": (I, [CD, I, I, I, P, I, P, P, I, I, P]),
     "dc_conv_wgrad_workspace": (SZ, [CD, I, I, I]),
     "dc_conv_wgrad": (I, [CD, I, I, I, P, I, P, I, P, SZ, P, P]),

@@ -233,6 +233,55 @@ def test_conv_full_shape_pw728_fp32():
     test_conv_fwd_dgrad_wgrad(("full_pw728_b2_f32", 1, 1, 0, 1, 0, 728, 728, 2, 48, 72), torch.float32)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 20, 28, 64, 40), (2, 48, 72, 2048, 256)], ids=["small", "aspp_full"])
+def test_dilated_group_is_bit_identical_to_single_launches(shape, dtype):
+    """dc_conv_fwd_dilated_group (the three atrous ASPP branches in one launch) against one dc_conv_fwd per branch: outputs and
+    BatchNorm partial sums bit for bit (fp32 runs the per-branch fallback inside the entry point: same contract)."""
+    N, H, W, cin, cout = shape
+    dils = [6, 12, 18]
+    x = q(rnd(N, cin, H, W, seed=1), dtype)
+    _, xv = to_nhwc(x, dtype, ld=cin + 32, off=16)
+    d0 = desc(dtype, 3, 1, 1, 1, 0, cin, cout)
+    singles, wfs = [], []
+    cat = torch.full((N, H, W, 3 * cout + 8), float("nan"), dtype=dtype, device=dev())          # members write channel slices of one buffer
+    for b, dil in enumerate(dils):
+        d = desc(dtype, 3, 1, dil, dil, 0, cin, cout)
+        w = rnd(cout, cin, 3, 3, seed=10 + b, scale=(cin * 9) ** -0.5).to(dev())
+        nwf, nwb = C.c_size_t(), C.c_size_t()
+        L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
+        wf = torch.empty(nwf.value, dtype=dtype, device=dev())
+        L.call("dc_conv_pack_weights", C.byref(d), vptr(w), vptr(wf), None, S())
+        rows = L.load().dc_conv_stat_rows(C.byref(d), N, H, W)
+        ybuf, yv = empty_nhwc(N, H, W, cout, dtype, ld=3 * cout + 8, off=b * cout)
+        slab = torch.full((2, rows, cout), float("nan"), device=dev())
+        L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 32, vptr(wf), None, vptr(yv), 3 * cout + 8, vptr(slab), 0, S())
+        singles.append((yv.clone(), slab))
+        wfs.append(wf)
+        if b == 0:   # the first member against the CPU reference
+            torch.cuda.synchronize()
+            assert_close(from_nhwc(yv), F.conv2d(x, q(w.cpu(), dtype), None, 1, dil, dil), dtype)
+    rows = singles[0][1].shape[1]
+    gslabs = [torch.full((2, rows, cout), float("nan"), device=dev()) for _ in dils]
+    ys = [cat[..., b * cout:(b + 1) * cout] for b in range(3)]
+    L.call("dc_conv_fwd_dilated_group", C.byref(d0), N, H, W, 3, (C.c_int * 3)(*dils), vptr(xv), cin + 32,
+           (C.c_void_p * 3)(*[t.data_ptr() for t in wfs]), (C.c_void_p * 3)(*[t.data_ptr() for t in ys]), 3 * cout + 8,
+           (C.c_void_p * 3)(*[t.data_ptr() for t in gslabs]), S())
+    torch.cuda.synchronize()
+    for b in range(3):
+        assert torch.equal(ys[b], singles[b][0]), f"member {b}: outputs differ"
+        assert torch.equal(gslabs[b], singles[b][1]), f"member {b}: statistics differ"
+    assert torch.isnan(cat[..., 3 * cout:].float()).all()
+    # no statistics (eval mode): NULL slab array
+    cat.fill_(float("nan"))
+    L.call("dc_conv_fwd_dilated_group", C.byref(d0), N, H, W, 3, (C.c_int * 3)(*dils), vptr(xv), cin + 32,
+           (C.c_void_p * 3)(*[t.data_ptr() for t in wfs]), (C.c_void_p * 3)(*[t.data_ptr() for t in ys]), 3 * cout + 8, None, S())
+    torch.cuda.synchronize()
+    assert all(torch.equal(ys[b], singles[b][0]) for b in range(3))
+    with pytest.raises(L.DeepcamHipError):
+        L.call("dc_conv_fwd_dilated_group", C.byref(d0), N, H, W, 5, (C.c_int * 5)(1, 2, 3, 4, 5), vptr(xv), cin + 32, None, None, cout, None, S())
+
+
 MIX_CASES = [
     # name, k, stride, pad, dil, transposed, cin, cout, N, H, W, cus, tail_pct
     ("pw_3_tiles_on_2", 1, 1, 0, 1, 0, 64, 256, 2, 20, 16, 2, 60),          # 640 px: 512 on the 256-tile kernel, 128 on the small one
