@@ -122,7 +122,11 @@ class SyntheticHWC:
 
     def __init__(self, global_size: int, H: int, W: int, cfile: int = 16, channels: Sequence[int] = tuple(range(16)),
                  allow_uneven_distribution: bool = False, shuffle: bool = False, comm_size: int = 1, comm_rank: int = 0,
-                 seed: int = 12345):
+                 seed: int = 12345, learnable: bool = False):
+        # learnable: the labels are a function of the fields (block-constant structures in channels 0 and 1 decide the class), so
+        # a run has something to converge on: used for the time-to-target demonstration of the driver's stop rule
+        # (train_hdf5_ddp.py:505-507).  Otherwise labels are independent draws with the reference's class frequencies.
+        self.learnable = learnable
         names = [f"data-synthetic-{i:06d}.h5" for i in range(global_size)]
         self.files, self.global_size = shard_files(names, comm_size, comm_rank, allow_uneven_distribution, shuffle, seed)
         self.local_size = len(self.files)
@@ -142,6 +146,17 @@ class SyntheticHWC:
         idx = int(self.files[i].split("-")[-1].split(".")[0])
         rs = np.random.RandomState(1000003 + idx)
         u = rs.random_sample((self.H, self.W, self.cfile)).astype(np.float32)
+        if self.learnable:
+            bh, bw = (self.H + 7) // 8, (self.W + 7) // 8
+            blk = rs.random_sample((bh, bw, 2)).astype(np.float32)
+            field = np.repeat(np.repeat(blk, 8, axis=0), 8, axis=1)[:self.H, :self.W]
+            u[..., :2] = 0.9 * field + 0.1 * u[..., :2]
+            lab = np.zeros((self.H, self.W), np.int64)
+            lab[field[..., 0] > 0.75] = 2
+            lab[(field[..., 0] > 0.75) & (field[..., 1] > 0.8)] = 1
+            data_out[...] = self._lo + u * (self._hi - self._lo)
+            label_out[...] = lab
+            return self.files[i]
         data_out[...] = self._lo + u * (self._hi - self._lo)
         label_out[...] = rs.choice(3, size=(self.H, self.W), p=np.array(self.CLASS_FREQ) / sum(self.CLASS_FREQ))
         return self.files[i]

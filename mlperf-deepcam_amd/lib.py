@@ -99,9 +99,10 @@ class DeepcamHipError(RuntimeError):
     pass
 
 
-def build(verbose: bool = False) -> str:
-    """Compile csrc/ into libdeepcam_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+def build(verbose: bool = False, force: bool = False) -> str:
+    """Compile csrc/ into libdeepcam_hip.so for gfx950 (hipcc cross-compiles without a GPU).  force: rebuild every object
+    (`make -B`), so that a tree that already carries object files still proves that the sources compile."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"] + (["-B"] if force else []), capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout[-4000:])
         print(r.stderr[-4000:])

@@ -7,7 +7,8 @@ checkpoint dictionary (:515-527: step, epoch, model with 'module.'-prefixed keys
 Input: data.InputPipeline over the HDF5 files (decoded with h5py, or through the HDF5 C library when h5py is not installed:
 h5lite), or over synthetic HWC fields with ``--synthetic_samples N``.
 
-Extra flags (not in the reference): --wireup_method env|single, --dtype, --synthetic_samples, --height/--width, --max_steps.
+Extra flags (not in the reference): --wireup_method env|single, --dtype, --synthetic_samples, --synthetic_learnable,
+--height/--width, --max_steps.
 """
 from __future__ import annotations
 
@@ -112,6 +113,7 @@ def build_parser():
     # extensions
     AP.add_argument("--dtype", type=str, default=None, choices=["fp32", "bf16"], help="overrides --amp_opt_level")
     AP.add_argument("--synthetic_samples", type=int, default=0, help="train on this many synthetic samples instead of HDF5 files")
+    AP.add_argument("--synthetic_learnable", action="store_true", help="synthetic labels that are a function of the fields (convergence / time-to-target runs)")
     AP.add_argument("--height", type=int, default=768)
     AP.add_argument("--width", type=int, default=1152)
     AP.add_argument("--max_steps", type=int, default=None)
@@ -179,10 +181,11 @@ def main(pargs):
     root_dir = os.path.join(pargs.data_dir_prefix)
     if pargs.synthetic_samples > 0:
         train_set = ddata.SyntheticHWC(pargs.synthetic_samples, H, W, channels=pargs.channels, allow_uneven_distribution=False,
-                                       shuffle=True, comm_size=size, comm_rank=rank)
+                                       shuffle=True, comm_size=size, comm_rank=rank, learnable=pargs.synthetic_learnable)
         n_val = max(size, pargs.synthetic_samples // 8)
         validation_set = ddata.SyntheticHWC(n_val, H, W, channels=pargs.channels, allow_uneven_distribution=True,
-                                            shuffle=(pargs.max_validation_steps is not None), comm_size=size, comm_rank=rank, seed=54321)
+                                            shuffle=(pargs.max_validation_steps is not None), comm_size=size, comm_rank=rank, seed=54321,
+                                            learnable=pargs.synthetic_learnable)
     else:
         train_set = ddata.CamDataset(os.path.join(root_dir, "train"), os.path.join(root_dir, "stats.h5"), pargs.channels,
                                      allow_uneven_distribution=False, shuffle=True, preprocess=True, comm_size=size, comm_rank=rank)
