@@ -71,9 +71,21 @@ def _worker(rank, world, port, q):
                 eng.grads[p.offset:p.offset + k] = local[p.offset:p.offset + k]
             eng.on_grad_ready(chunk)
         assert red.launched == len(red.buckets)
-        red.finish()
+        # step 0: the fused-step contract (the arena holds the SUM, the optimizer applies 1/world); step 1: the DDP wrapper's
+        # contract (finish(average=True) leaves the averaged gradient).  Either way the buckets are re-armed for the next backward.
+        red.finish(average=(step == 1))
         expect = sum(torch.randn(lay.n_params, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world))
+        if step == 1:
+            expect = expect / world
         assert torch.allclose(eng.grads, expect, atol=1e-6)
+        assert red.launched == 0 and all(b.remaining == len(b.names) and b.work is None for b in red.buckets)
+    # a backward that never reported some gradient must not pass silently
+    eng.on_grad_ready(names[:5])
+    try:
+        red.finish()
+        raise AssertionError("finish() accepted an incomplete backward")
+    except RuntimeError as e:
+        assert "never completed" in str(e)
     q.put((rank, "ok"))
     dist.destroy_process_group()
 
