@@ -115,7 +115,10 @@ class LazyAct:
 
 class Engine:
     def __init__(self, batch: int, height: int, width: int, dtype=torch.bfloat16, device=None, n_input: int = 16,
-                 n_classes: int = 3, seed: Optional[int] = 333, share_from: "Engine" = None):
+                 n_classes: int = 3, seed: Optional[int] = 333, share_from: "Engine" = None, layout: "S.Layout" = None,
+                 builder: Callable[["Engine"], None] = None):
+        """layout + builder: a sub-network as an engine of its own (tests build ONE Xception Block from the op builders below
+        and run it against the reference's Block vectors); the default is the whole DeepLabV3+ network."""
         if not torch.cuda.is_available():
             raise L.DeepcamHipError("mlperf_deepcam_amd.Engine needs a HIP device: there is no CPU path")
         L.load()
@@ -125,7 +128,8 @@ class Engine:
         self.dtype, self.dt = dtype, L.dtype_code(dtype)
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.n_input, self.n_classes = n_input, n_classes
-        self.layout = S.Layout(n_input, n_classes)
+        self.layout = layout if layout is not None else S.Layout(n_input, n_classes)
+        self._builder = builder
         lay = self.layout
         self.act_bytes = 0
         # name -> tensor of everything forward leaves behind for backward (activations, BatchNorm coefficient vectors): lets a
@@ -139,7 +143,10 @@ class Engine:
             self.version = share_from.version
         else:
             host = torch.empty(lay.n_params, dtype=torch.float32)
-            S.init_arena(lay, host, seed)
+            if layout is None:
+                S.init_arena(lay, host, seed)
+            else:
+                host.zero_()                  # a custom layout's owner fills the arena (engine.params) itself
             self.params = host.to(self.device)
             self.grads = torch.zeros(lay.n_params, dtype=torch.float32, device=self.device)
             hb = torch.zeros(lay.n_buffers, dtype=torch.float32)
@@ -567,8 +574,38 @@ class Engine:
         relu = s.relu_after if relu_override is None else relu_override
         return self._bn(y, slab, rows, s.bn, relu, residual=residual, name=s.bn + ".out", lazy=lazy and self.fuse_bn_into_dw)
 
+    def _xblock(self, blk: S.BlockSpec, z: Act, relu_out: Optional[bool] = None) -> Act:
+        """One Xception Block (deeplab_xception.py:69-122) on an input that is already ReLU'd (the reference's in-place leading
+        ReLU also reaches the shortcut): rep(z) + skip(z), materialised through the NEXT block's in-place ReLU when relu_out
+        (blocks 1-19; block20's output is consumed as it is by conv3, :229-230)."""
+        X = "xception_features."
+        ro = blk.relu_out if relu_out is None else relu_out
+        t = z
+        nsep = len(blk.seps)
+        for i, s in enumerate(blk.seps):
+            last = i == nsep - 1
+            if last and not blk.skip:
+                # identity shortcut: out = relu(bn(pw(dw(t))) + z)   (x += skip, then the next block's in-place ReLU)
+                t = self._sep(t, s, residual=z, relu_override=ro)
+            else:
+                # a BatchNorm between two separable convs is consumed by the next depthwise conv only
+                t = self._sep(t, s, lazy=bool(s.bn) and not last)
+        if blk.skip:
+            ys, slab, rows = self._conv(z, f"{X}{blk.name}.skip.weight", blk.cout, stride=blk.stride, name=blk.name + ".skip")
+            t = self._bn(ys, slab, rows, f"{X}{blk.name}.skipbn", ro, residual=t, name=blk.name + ".out")
+        return t
+
     # ------------------------------------------------------------------------------------------------ network
     def _build(self) -> None:
+        if self._builder is not None:
+            self._enc_fwd_end = self._enc_bwd_makers = 0
+            self._builder(self)
+            self._resolve_backward()
+            return
+        self._build_network()
+        self._resolve_backward()
+
+    def _build_network(self) -> None:
         lib = L.load()
         B, H, W = self.B, self.H, self.W
         X = "xception_features."
@@ -618,21 +655,7 @@ class Engine:
         # ---- Xception blocks.  Every block input `z` is already ReLU'd (the reference's in-place leading ReLU).
         low = None
         for blk in S.blocks():
-            z = x
-            t = z
-            nsep = len(blk.seps)
-            for i, s in enumerate(blk.seps):
-                last = i == nsep - 1
-                if last and not blk.skip:
-                    # identity shortcut: out = relu(bn(pw(dw(t))) + z)   (x += skip, then the next block's in-place ReLU)
-                    t = self._sep(t, s, residual=z, relu_override=True)
-                else:
-                    # a BatchNorm between two separable convs is consumed by the next depthwise conv only
-                    t = self._sep(t, s, lazy=bool(s.bn) and not last)
-            if blk.skip:
-                ys, slab, rows = self._conv(z, f"{X}{blk.name}.skip.weight", blk.cout, stride=blk.stride, name=blk.name + ".skip")
-                t = self._bn(ys, slab, rows, f"{X}{blk.name}.skipbn", blk.relu_out, residual=t, name=blk.name + ".out")
-            x = t
+            x = self._xblock(blk, x)
             if blk.name == "block1":
                 low = x            # low_level_feat, after block2's in-place ReLU has hit it
         for i, s in enumerate(S.EXIT_SEPS):
@@ -750,7 +773,8 @@ class Engine:
 
         self.bwd.append(head_bwd_make)
 
-        # ---- resolve the backward program in reverse order (fixes write/accumulate modes of every gradient)
+    def _resolve_backward(self) -> None:
+        """Resolve the backward program in reverse order (fixes write/accumulate modes of every gradient)."""
         makers = self.bwd
         self.bwd = []
         self.grad_ready = []

@@ -132,12 +132,28 @@ def _param_table(n_input: int, n_classes: int) -> List[Tuple[str, Tuple[int, ...
     return t
 
 
+def block_param_table(b: BlockSpec) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """The rows of _param_table that belong to one Block (same order): lets a single Block be built as an engine of its own
+    (tests/test_block_gpu.py checks the HIP block program against the reference's Block known-answer vectors)."""
+    X = "xception_features."
+    t: List[Tuple[str, Tuple[int, ...], str]] = []
+    if b.skip:
+        t.append((X + b.name + ".skip.weight", (b.cout, b.cin, 1, 1), "convk"))
+        t.append((X + b.name + ".skipbn", (b.cout,), "bn"))
+    for s in b.seps:
+        t.append((s.prefix + ".conv1.weight", (s.cin, 1, 3, 3), "convk"))
+        t.append((s.prefix + ".pointwise.weight", (s.cout, s.cin, 1, 1), "convk"))
+        if s.bn:
+            t.append((s.bn, (s.cout,), "bn"))
+    return t
+
+
 class Layout:
     """Offsets of every parameter / buffer inside the flat arenas."""
 
-    def __init__(self, n_input: int = 16, n_classes: int = 3):
+    def __init__(self, n_input: int = 16, n_classes: int = 3, table=None):
         self.n_input, self.n_classes = n_input, n_classes
-        self.table = _param_table(n_input, n_classes)
+        self.table = table if table is not None else _param_table(n_input, n_classes)
         self.params: "OrderedDict[str, ParamInfo]" = OrderedDict()
         self.buffers: "OrderedDict[str, Tuple[int, int]]" = OrderedDict()   # running_mean / running_var: name -> (offset, C)
         self.nbt: "OrderedDict[str, int]" = OrderedDict()                   # num_batches_tracked: name -> index
