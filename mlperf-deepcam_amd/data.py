@@ -245,6 +245,9 @@ class InputPipeline:
         # reader possibly still writing a slot's pinned buffer: it has been told to stop (finally: below); wait for it before
         # any slot is handed out again, and forget the slot the abandoned iteration had out.
         if self._reader_thread is not None:
+            # (the abandoned generator's `finally` normally did this already; repeat it in case the generator object is still alive)
+            self._reader_stop.set()
+            self._reader_free_q.put(None)
             self._reader_thread.join()
             self._reader_thread = None
         self._prev = None
@@ -258,7 +261,7 @@ class InputPipeline:
             s.consumed.record(torch.cuda.current_stream())
             free_q.put(s)
         t = threading.Thread(target=self._reader, args=(free_q, full_q, stop), daemon=True)
-        self._reader_thread = t
+        self._reader_thread, self._reader_stop, self._reader_free_q = t, stop, free_q
         t.start()
         staged: List[_Slot] = []
 
@@ -301,7 +304,8 @@ class InputPipeline:
                 self._release(self._prev, free_q)
                 self._prev = None
         finally:
-            self._prev = None
+            if self._reader_thread is t:          # (a stale generator finalised late must not disturb its successor)
+                self._prev = None
             stop.set()
             free_q.put(None)
 
