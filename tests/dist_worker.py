@@ -15,7 +15,7 @@ def grads_for(eng, seed, dev, cw):
     eng.backward()
 
 def main():
-    ddist.init("env", backend="gloo")
+    ddist.init("env", backend=os.environ.get("DC_TEST_BACKEND", "gloo"))
     rank, world = ddist.get_rank(), ddist.get_size()
     torch.cuda.set_device(0); dev = torch.device("cuda", 0); cw = dnn.class_weights()
     eng = Engine(2, 64, 96, torch.float32, seed=333 + rank)          # different init per rank: broadcast must fix it

@@ -66,3 +66,26 @@ def test_train_driver_two_ranks_end_to_end(tmp_path):
     c = torch.load(ck, map_location="cpu", weights_only=False)
     assert c["step"] == 2 and len(c["model"]) == 532 and all(k.startswith("module.") for k in c["model"])
     assert sorted(os.listdir(os.path.join(out, "logs"))) == ["w2.log"]
+
+
+def test_rccl_backend_single_rank():
+    """The reducer's call pattern on the REAL backend (RCCL: in-place all_reduce of arena slices launched from the side stream,
+    async work objects waited on the compute stream, broadcast of the arenas), with the one rank a one-GPU box allows: the
+    collectives are identities, the stream hand-off and the API usage are what is exercised."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29625", os.path.join(ROOT, "tests", "dist_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, DC_TEST_BACKEND="nccl"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "DIST_WORKER rel_err" in r.stdout
+
+
+def test_bench_single_rank_through_torchrun_rccl():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, RCCL), at N = 1."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29626", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--local_batch_size", "2", "--height", "128", "--width", "192", "--no_cpu_baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0
