@@ -818,8 +818,9 @@ def test_nchw_to_nhwc(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-def test_pool_branch_helpers(dtype):
-    N, Cc, H, W = 2, 2048, 6, 5
+@pytest.mark.parametrize("H,W", [(6, 5), (13, 11), (48, 72)], ids=["hw30", "hw143_ragged", "hw3456_real"])
+def test_pool_branch_helpers(dtype, H, W):
+    N, Cc = 2, 2048
     dt = L.dtype_code(dtype)
     HW = H * W
     x = q(rnd(N, Cc, H, W, seed=1), dtype)
