@@ -354,23 +354,41 @@ __global__ void head_wfinish_kernel(const float* __restrict__ tmp, float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------- input layout
-// NCHW fp32 (the reference's batch layout) -> NHWC T.  One thread per (pixel, 16-byte channel group): the per-channel
-// reads are coalesced along W, the write is one vector.
+// NCHW fp32 (the reference's batch layout) -> NHWC T.  One thread per PIXEL: its Cc per-channel reads are coalesced along W
+// (and all in flight together), its 16-byte vectors are adjacent, so a wave writes one contiguous run of 64 pixels.  (One
+// thread per (pixel, channel group) left every other 16 bytes of a 32-byte pixel to another pass: 2.65 TB/s on the 16-channel
+// input.)
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ out, int ldo, int N, int Cc, long HW) {
   constexpr int KPV = Elem<T>::kPerVec;
   const int ngroups = Cc / KPV;
-  const long total = (long)N * HW * ngroups;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long pix = i % (N * HW);          // pixel fastest: neighbouring lanes read neighbouring W positions
-    const int cg = (int)(i / (N * HW));
+  const long total = (long)N * HW;
+  for (long pix = blockIdx.x * (long)blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
     const long n = pix / HW, p = pix % HW;
-    float f[KPV];
+    const float* src = x + (size_t)n * Cc * HW + p;
+    T* dst = out + (size_t)pix * ldo;
+    if (ngroups == 2) {          // the 16-channel bf16 stem input: everything unrolled, 16 loads in flight
+      float f[2][KPV];
 #pragma unroll
-    for (int e = 0; e < KPV; ++e) f[e] = x[((size_t)n * Cc + cg * KPV + e) * HW + p];
-    vec16 v;
-    pack(v, f, T());
-    stg16(out + (size_t)pix * ldo + cg * KPV, v);
+      for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+        for (int e = 0; e < KPV; ++e) f[cg][e] = src[(size_t)(cg * KPV + e) * HW];
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) {
+        vec16 v;
+        pack(v, f[cg], T());
+        stg16(dst + cg * KPV, v);
+      }
+      continue;
+    }
+    for (int cg = 0; cg < ngroups; ++cg) {
+      float f[KPV];
+#pragma unroll
+      for (int e = 0; e < KPV; ++e) f[e] = src[(size_t)(cg * KPV + e) * HW];
+      vec16 v;
+      pack(v, f, T());
+      stg16(dst + cg * KPV, v);
+    }
   }
 }
 
@@ -560,8 +578,7 @@ extern "C" int dc_head_bwd(int dtype, int N, int Cin, int Hi, int Wi, const void
 extern "C" int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, void* out, int ldo, void* stream) {
   if (int e = dc_check_view(out, ldo, C, dtype, "dc_nchw_to_nhwc out")) return e;
   DC_REQUIRE(x_nchw && N > 0 && H > 0 && W > 0, "dc_nchw_to_nhwc: bad argument");
-  const int kpv = dtype == DC_BF16 ? 8 : 4;
-  const long total = (long)N * H * W * (C / kpv);
+  const long total = (long)N * H * W;
   long blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipStream_t st = (hipStream_t)stream;
