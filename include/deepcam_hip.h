@@ -263,7 +263,7 @@ int dc_adam_step(int kind, long n, float* p, const float* g, float* m, float* v,
                  void* stream);
 /* LAMB: tensor t occupies [offsets[t], offsets[t+1]) of the arena (device int64[ntensors+1]).
  * workspace: dc_lamb_workspace_words(ntensors, n) 4-byte words (partial sums of the global norm, chunk plan, per-chunk
- * norms and the n-element update direction; 16-byte aligned).  `g` is only read (as apex FusedLAMB leaves .grad intact).
+ * norms and the n-element update direction).  p, g, m, v and workspace must be 16-byte aligned.  `g` is only read (as apex FusedLAMB leaves .grad intact).
  * As apex with use_nvlamb=False, the per-tensor trust ratio is applied only when weight_decay != 0.
  * No atomics: the update is bit-identical from run to run. */
 size_t dc_lamb_workspace_words(int ntensors, long n);
