@@ -670,6 +670,58 @@ __device__ inline void pack_dense_tile(const PackEntry& e, int tile, float* lds)
   }
 }
 
+// The pointwise layers (two thirds of the dense weights) in bf16: the same 64 x 64 tile, moved with 16-byte accesses -- four float4
+// loads per thread instead of sixteen scalar ones, and one 16-byte store per 8 packed values instead of four 4-byte stores (the
+// generic pass ran at 1.7 TB/s).  Same conversions (pack2_bf16), same bits.  Needs A and B to be multiples of 8.
+__device__ inline void pack_pointwise_tile_bf16(const PackEntry& e, int tile, float* lds) {
+  const int A = e.kind == 1 ? e.cin : e.cout, B = e.kind == 1 ? e.cout : e.cin;
+  bf16* P = reinterpret_cast<bf16*>(e.kind == 1 ? e.wb : e.wf);   // [a][b], row stride r32(B)
+  bf16* Q = reinterpret_cast<bf16*>(e.kind == 1 ? e.wf : e.wb);   // [b][a], row stride r32(A)
+  const int ldp = (B + 31) / 32 * 32, ldq = (A + 31) / 32 * 32;
+  constexpr int TS = 64, ROWF = TS + 1;
+  const int ntb = (B + TS - 1) / TS;
+  const int a0 = (tile / ntb) * TS, b0 = (tile % ntb) * TS;
+  const int run = min(TS, B - b0);              // a multiple of 8
+  __syncthreads();                              // previous tile fully written out
+#pragma unroll
+  for (int idx = threadIdx.x; idx < TS * (TS / 4); idx += 256) {
+    const int al = idx / (TS / 4), j = (idx % (TS / 4)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a0 + al < A && j < run) v = *reinterpret_cast<const float4*>(e.master + (size_t)(a0 + al) * B + b0 + j);
+    float* d = lds + al * ROWF + j;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  if (P != nullptr) {
+#pragma unroll
+    for (int idx = threadIdx.x; idx < TS * (TS / 8); idx += 256) {
+      const int u = idx % (TS / 8), al = idx / (TS / 8);
+      if (a0 + al < A && b0 + u * 8 < B) {
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = lds[al * ROWF + u * 8 + k];
+        vec16 v;
+        pack(v, f, bf16());
+        stg16(P + (size_t)(a0 + al) * ldp + b0 + u * 8, v);
+      }
+    }
+  }
+  if (Q != nullptr) {
+#pragma unroll
+    for (int idx = threadIdx.x; idx < TS * (TS / 8); idx += 256) {
+      const int u = idx % (TS / 8), bl = idx / (TS / 8);
+      if (b0 + bl < B && a0 + u * 8 < A) {
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = lds[(u * 8 + k) * ROWF + bl];
+        vec16 v;
+        pack(v, f, bf16());
+        stg16(Q + (size_t)(b0 + bl) * ldq + a0 + u * 8, v);
+      }
+    }
+  }
+}
+
 // tiles of one table entry (dense: TS x TS x taps tiles of the master tensor; depthwise: runs of 256 channels)
 __device__ inline int pack_entry_tiles(const PackEntry& e) {
   if (e.kind == 2) return (e.cout + 255) / 256;
@@ -712,8 +764,16 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackEntry* __restri
       }
       continue;
     }
-    if (e.taps == 1) pack_dense_tile<T, 1>(e, tile, lds);
-    else pack_dense_tile<T, 9>(e, tile, lds);
+    if (e.taps == 1) {
+      if constexpr (sizeof(T) == 2) {
+        if (((e.cin | e.cout) & 7) == 0) pack_pointwise_tile_bf16(e, tile, lds);
+        else pack_dense_tile<T, 1>(e, tile, lds);
+      } else {
+        pack_dense_tile<T, 1>(e, tile, lds);
+      }
+    } else {
+      pack_dense_tile<T, 9>(e, tile, lds);
+    }
   }
 }
 

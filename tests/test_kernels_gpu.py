@@ -407,7 +407,8 @@ def test_conv_rejects_bad_arguments():
         L.call("dc_conv_dgrad", C.byref(d), 1, 5, 5, vptr(x), 64, vptr(x), vptr(x), 64, 0, S())
 
 
-PACK_CASES = [(1, 0, 728, 728), (3, 0, 304, 256), (3, 0, 16, 32), (3, 1, 256, 256), (1, 0, 2048, 256), (3, 0, 2048, 64), (1, 0, 48, 130)]
+PACK_CASES = [(1, 0, 728, 728), (3, 0, 304, 256), (3, 0, 16, 32), (3, 1, 256, 256), (1, 0, 2048, 256), (3, 0, 2048, 64), (1, 0, 48, 130),
+              (1, 0, 128, 48), (1, 0, 1024, 1536), (1, 0, 72, 8)]   # the last three: 16-byte pointwise path with partial tiles
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
