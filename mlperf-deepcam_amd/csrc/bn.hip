@@ -138,22 +138,38 @@ constexpr int FIN_CH = 4, FIN_RL = 64;
 __device__ inline void slab_colsum2(const float* __restrict__ s0, const float* __restrict__ s1, int rows, int C, int c,
                                     bool ok, double (&red)[2][FIN_RL][FIN_CH], double& a, double& b) {
   const int cl = threadIdx.x & (FIN_CH - 1), rl = threadIdx.x / FIN_CH;
-  double x0 = 0.0, x1 = 0.0, y0 = 0.0, y1 = 0.0;
+  // FIN_UR independent partial sums per thread and slab: the 13 824-row slabs of the 384 x 576 layers are 216 rows per thread, and
+  // with two loads in flight the kernel was a chain of ~100 memory latencies (63-83 us); the partials are combined in a fixed order
+  constexpr int FIN_UR = 8;
+  double xs[FIN_UR], ys[FIN_UR];
+#pragma unroll
+  for (int u = 0; u < FIN_UR; ++u) xs[u] = ys[u] = 0.0;
   if (ok) {
     int r = rl;
-    for (; r + FIN_RL < rows; r += 2 * FIN_RL) {
-      x0 += (double)s0[(size_t)r * C + c];
-      x1 += (double)s0[(size_t)(r + FIN_RL) * C + c];
-      y0 += (double)s1[(size_t)r * C + c];
-      y1 += (double)s1[(size_t)(r + FIN_RL) * C + c];
+    for (; r + (FIN_UR - 1) * FIN_RL < rows; r += FIN_UR * FIN_RL) {
+      float fx[FIN_UR], fy[FIN_UR];
+#pragma unroll
+      for (int u = 0; u < FIN_UR; ++u) {
+        fx[u] = s0[(size_t)(r + u * FIN_RL) * C + c];
+        fy[u] = s1[(size_t)(r + u * FIN_RL) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < FIN_UR; ++u) {
+        xs[u] += (double)fx[u];
+        ys[u] += (double)fy[u];
+      }
     }
-    if (r < rows) {
-      x0 += (double)s0[(size_t)r * C + c];
-      y0 += (double)s1[(size_t)r * C + c];
+#pragma unroll
+    for (int u = 0; u < FIN_UR - 1; ++u) {          // at most FIN_UR - 1 rows left (static indices: the partials stay in registers)
+      const int rr = r + u * FIN_RL;
+      if (rr < rows) {
+        xs[u] += (double)s0[(size_t)rr * C + c];
+        ys[u] += (double)s1[(size_t)rr * C + c];
+      }
     }
   }
-  red[0][rl][cl] = x0 + x1;
-  red[1][rl][cl] = y0 + y1;
+  red[0][rl][cl] = ((xs[0] + xs[1]) + (xs[2] + xs[3])) + ((xs[4] + xs[5]) + (xs[6] + xs[7]));
+  red[1][rl][cl] = ((ys[0] + ys[1]) + (ys[2] + ys[3])) + ((ys[4] + ys[5]) + (ys[6] + ys[7]));
   __syncthreads();
   a = b = 0.0;
   if (threadIdx.x < FIN_CH) {
