@@ -83,7 +83,7 @@ text = "\n".join(out)
 print(text)
 if len(sys.argv) > 2:
     with open(sys.argv[2], "w") as fh:
-        fh.write("# Per-kernel roofline table (round 1)\n\n" + __doc__.split("Per kernel")[0].strip().split("\n\n")[0] + "\n\n"
+        fh.write("# Per-kernel roofline table\n\n" + __doc__.split("Per kernel")[0].strip().split("\n\n")[0] + "\n\n"
                  "Columns: bytes = 2 x FETCH_SIZE + WRITE_SIZE (fabric side of the L2s: HBM + Infinity Cache); flop = 512 x MFMA MOPS counters "
                  "(executed, padding included); roof = MFMA when flop/byte x 8 TB/s exceeds 2.5 PFLOP/s, else HBM; kernels run one at a time under "
                  "counter collection.  Produced by `scripts/roofline_report.py` (commands in its header).\n\n" + text + "\n")
