@@ -1,0 +1,54 @@
+"""The driver's command line and log format without a GPU: flag names / defaults of train_hdf5_ddp.py:549-577,
+the `--lr_schedule` key=value parser (:81-90) and the `:::MLLOG` line shape of utils/mlperf_log_utils.py."""
+import json
+import os
+
+from mlperf_deepcam_amd import train
+
+
+REFERENCE_DEFAULTS = {            # flag -> default, train_hdf5_ddp.py:549-577
+    "wireup_method": "nccl-openmpi", "wandb_certdir": "/opt/certs", "checkpoint": None, "data_dir_prefix": "/",
+    "max_inter_threads": 1, "max_epochs": 30, "save_frequency": 100, "validation_frequency": 100, "max_validation_steps": None,
+    "logging_frequency": 100, "training_visualization_frequency": 50, "validation_visualization_frequency": 50,
+    "local_batch_size": 1, "channels": list(range(16)), "optimizer": "Adam", "start_lr": 1e-3, "adam_eps": 1e-8,
+    "weight_decay": 1e-6, "loss_weight_pow": -0.125, "lr_warmup_steps": 0, "lr_warmup_factor": 1.0, "target_iou": 0.82,
+    "model_prefix": "model", "amp_opt_level": "O0", "enable_wandb": False, "resume_logging": False,
+}
+
+
+def test_flags_and_defaults_are_the_references():
+    a = train.build_parser().parse_args([])
+    for k, v in REFERENCE_DEFAULTS.items():
+        assert getattr(a, k) == v, k
+    assert a.run_tag is None and a.output_dir is None and a.lr_schedule is None
+
+
+def test_canonical_dgx2_command_line_parses():
+    """run_scripts/run_training_dgx2.sh:51-70, as the shell hands it over."""
+    argv = ["--wireup_method", "nccl-openmpi", "--run_tag", "deepcam_prediction_run1", "--data_dir_prefix", "/data", "--output_dir", "/data/runs/x",
+            "--max_inter_threads", "2", "--model_prefix", "classifier", "--optimizer", "LAMB", "--start_lr", "1e-3",
+            "--lr_schedule", 'type="multistep",milestones="15000 25000",decay_rate="0.1"', "--lr_warmup_steps", "0", "--lr_warmup_factor", "1.",
+            "--weight_decay", "1e-2", "--validation_frequency", "200", "--training_visualization_frequency", "200",
+            "--validation_visualization_frequency", "40", "--max_validation_steps", "50", "--logging_frequency", "0", "--save_frequency", "400",
+            "--max_epochs", "200", "--amp_opt_level", "O1", "--local_batch_size", "2"]
+    a = train.build_parser().parse_args(argv)
+    assert a.lr_schedule == {"type": "multistep", "milestones": "15000 25000", "decay_rate": "0.1"}
+    assert (a.optimizer, a.weight_decay, a.local_batch_size, a.amp_opt_level, a.logging_frequency) == ("LAMB", 1e-2, 2, "O1", 0)
+
+
+def test_mllog_line_format(tmp_path, capsys):
+    log = train.MLLogger(os.path.join(str(tmp_path), "logs", "t.log"))
+    log.log_start(key="run_start", sync=True)
+    log.log_event(key="train_loss", value=1.25, metadata={"epoch_num": 1, "step_num": 7})
+    log.log_end(key="run_stop", metadata={"status": "success"})
+    out = [l for l in capsys.readouterr().out.splitlines() if l.startswith(":::MLLOG ")]
+    recs = [json.loads(l[len(":::MLLOG "):]) for l in out]
+    assert [r["key"] for r in recs[:5]] == ["submission_benchmark", "submission_org", "submission_division", "submission_status", "submission_platform"]
+    assert recs[0]["value"] == "deepcam"
+    tail = recs[5:]
+    assert [(r["event_type"], r["key"]) for r in tail] == [("INTERVAL_START", "run_start"), ("POINT_IN_TIME", "train_loss"), ("INTERVAL_END", "run_stop")]
+    assert tail[1]["value"] == 1.25 and tail[1]["metadata"] == {"epoch_num": 1, "step_num": 7} and isinstance(tail[1]["time_ms"], int)
+    assert set(tail[0]) == {"namespace", "time_ms", "event_type", "key", "value", "metadata"}
+    # the file holds the same lines
+    with open(os.path.join(str(tmp_path), "logs", "t.log")) as f:
+        assert [l.rstrip("\n") for l in f if l.startswith(":::MLLOG ")] == out
