@@ -382,6 +382,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const size_t stride4 = ((size_t)taps * per) >> 2;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
     int s = 0;
+    // eight slabs in flight first (the 728-channel layers have 21 splits: 6 dependent rounds of four became 2 of eight + 1 of
+    // four + 1); fixed combination order, so the result does not depend on anything but the split count
+    float4 b0 = a0, b1 = a0, b2 = a0, b3 = a0;
+    for (; s + 8 <= splits; s += 8) {
+      const float4 v0 = src[(size_t)s * stride4], v1 = src[(size_t)(s + 1) * stride4];
+      const float4 v2 = src[(size_t)(s + 2) * stride4], v3 = src[(size_t)(s + 3) * stride4];
+      const float4 v4 = src[(size_t)(s + 4) * stride4], v5 = src[(size_t)(s + 5) * stride4];
+      const float4 v6 = src[(size_t)(s + 6) * stride4], v7 = src[(size_t)(s + 7) * stride4];
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+      b0.x += v4.x; b0.y += v4.y; b0.z += v4.z; b0.w += v4.w;
+      b1.x += v5.x; b1.y += v5.y; b1.z += v5.z; b1.w += v5.w;
+      b2.x += v6.x; b2.y += v6.y; b2.z += v6.z; b2.w += v6.w;
+      b3.x += v7.x; b3.y += v7.y; b3.z += v7.z; b3.w += v7.w;
+    }
+    a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+    a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+    a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
     for (; s + 4 <= splits; s += 4) {
       const float4 v0 = src[(size_t)s * stride4], v1 = src[(size_t)(s + 1) * stride4];
       const float4 v2 = src[(size_t)(s + 2) * stride4], v3 = src[(size_t)(s + 3) * stride4];
