@@ -803,6 +803,7 @@ extern "C" int dc_pack_all(int dtype, const void* table_dev, int nentries, void*
 // Tuning switches for A/B measurements in one process: "igemm_mode" (0/1/2, see StageCfg), "wgrad_target_blocks".
 extern "C" int dc_wgrad_set_target_blocks(int n);
 extern "C" int dc_wgrad_set_mode(int m);
+extern "C" int dc_wgrad_set_min_steps(int n);
 extern "C" int dc_wgrad_set_256(int m);
 extern "C" int dc_wgrad_set_thin(int m);
 extern "C" int dc_wgrad_set_slots(int n);
@@ -830,6 +831,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm_mix_tail") == 0) { g_mix_tail_pct = value; return 0; }
   if (name != nullptr && strcmp(name, "wgrad_target_blocks") == 0) return dc_wgrad_set_target_blocks(value);
   if (name != nullptr && strcmp(name, "wgrad_mode") == 0) return dc_wgrad_set_mode(value);
+  if (name != nullptr && strcmp(name, "wgrad_min_steps") == 0) return dc_wgrad_set_min_steps(value);
   if (name != nullptr && strcmp(name, "wgrad256") == 0) return dc_wgrad_set_256(value);
   if (name != nullptr && strcmp(name, "thin_wgrad") == 0) return dc_wgrad_set_thin(value);
   if (name != nullptr && strcmp(name, "wgrad256_slots") == 0) return dc_wgrad_set_slots(value);

@@ -430,10 +430,15 @@ static int g_thin_wgrad = 1;               // one-pass kernel for the two thin s
 static int g_wgrad256 = 1;                 // 0: 128-tile kernel only, 1: planner, 2: 256-tile kernel wherever eligible (bf16)
 static int g_wgrad_target_blocks = 768;    // resident capacity: 256 CUs x 3 workgroups (48 KiB LDS, 146 registers)
 
+// Fewest K steps (of BP pixels) a pixel split may have (tuning switch "wgrad_min_steps").  Every split costs a 64 KiB fp32 slab
+// tile written and read back: with two steps as the floor, the 128 -> 128 layer at 384 x 576 and local batch 2 was cut into 768
+// splits of 9 steps (50 MB of slabs for a 64 KiB result).  Whole-step A/B at 2 / 8 / 16 / 32 / 64 steps: local batch 2 14.71 /
+// 14.54 / 14.43 / 14.45 / 14.86 ms, batch 4 23.26 / 23.20 / 23.08 / 23.18 / 23.32, batch 8 unchanged (40.9-41.0).
+static int g_wgrad_min_steps = 16;
 static void plan_splits(const GatherGeom& g, long M, int BP, int* splits, int* chunk) {
   const long tiles = (long)cdiv(g.Cin, 128) * cdiv(g.Cout, 128) * g.ntaps;
   long want = g_wgrad_target_blocks / tiles;   // FLOOR: all workgroups must be co-resident (3 per CU), a second partial wave costs more than it buys
-  const long maxs = (M + 2 * BP - 1) / (2 * BP);   // at least two steps per split
+  const long maxs = (M + (long)g_wgrad_min_steps * BP - 1) / ((long)g_wgrad_min_steps * BP);   // at least that many steps per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   if (want > 1024) want = 1024;
@@ -446,6 +451,12 @@ static void plan_splits(const GatherGeom& g, long M, int BP, int* splits, int* c
 }  // namespace dc
 
 using namespace dc;
+
+extern "C" int dc_wgrad_set_min_steps(int n) {
+  if (n < 1) return dc_fail("dc_set_option: wgrad_min_steps must be positive", __FILE__, __LINE__);
+  g_wgrad_min_steps = n;
+  return 0;
+}
 
 extern "C" int dc_wgrad_set_mode(int m) {
   g_wgrad_mode = m ? 1 : 0;
