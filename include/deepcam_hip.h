@@ -271,6 +271,15 @@ int dc_lamb_step(int ntensors, const int64_t* offsets_dev, long n, float* p, con
                  const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                  const int* step_dev, float max_grad_norm, float grad_scale, float* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Gradient payload of the data-parallel all-reduce (train_hdf5_ddp.py:227,363: apex / torch DDP reduce the gradients the
+ * optimizer reads; SURVEY 5.8: 225.8 MB fp32 or 112.9 MB bf16 per step).  The fp32 arena stays the master copy:
+ * dc_grad_pack_bf16 rounds a bucket (round-to-nearest-even) into the send buffer the collective sums in bf16,
+ * dc_grad_unpack_bf16 widens the reduced buffer back into the arena.  n elements; both pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------ */
+int dc_grad_pack_bf16(long n, const float* g, void* out_bf16, void* stream);
+int dc_grad_unpack_bf16(long n, const void* in_bf16, float* g, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/deepcam_hip.h"
 
 namespace dc {
@@ -88,6 +90,15 @@ __device__ inline double wave_sum(double v) {
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace dc
+
+// One-time, thread-safe set-up at a call site (the dynamic-LDS attribute of a kernel, a symbol address): the C ABI may be called from
+// any host thread (autograd's worker thread beside the main thread), and a plain `static bool` could read true before the other
+// thread's hipFuncSetAttribute had returned.
+#define DC_ONCE(...)                               \
+  do {                                             \
+    static std::once_flag once_flag__;             \
+    std::call_once(once_flag__, [&] { __VA_ARGS__; }); \
+  } while (0)
 
 #define DC_CHECK_LAUNCH()                                  \
   do {                                                     \

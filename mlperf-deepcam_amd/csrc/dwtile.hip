@@ -364,11 +364,7 @@ template <typename T, int DIL, bool FLIP, int CG>
 static void launch_fwd1(const TileGrid& t, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out,
                         int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats& bs) {
   constexpr int LDS = TileCfg<DIL, CG>::LDS_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, FLIP, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, FLIP, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   hipLaunchKernelGGL((dwt_kernel<T, DIL, FLIP, CG>), dim3(t.ntiles * t.ncgb), dim3(256), LDS, st, (const T*)in, ldin, wp,
                      (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs);
 }
@@ -408,11 +404,7 @@ static void launch_wg1(const TileGrid& t, int tpb, int rows, const void* x, int 
                        int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu) {
   constexpr int FOLD = TileCfg<DIL, CG>::NSL * 9 * CG * Elem<T>::kPerVec * (int)sizeof(float);   // red[strip lane][9][channels]
   constexpr int LDS = TileCfg<DIL, CG>::LDS_BYTES > FOLD ? TileCfg<DIL, CG>::LDS_BYTES : FOLD;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_wgrad_kernel<T, DIL, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_wgrad_kernel<T, DIL, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   hipLaunchKernelGGL((dwt_wgrad_kernel<T, DIL, CG>), dim3(rows * t.ncgb), dim3(256), LDS, st, (const T*)x, ldx, (const T*)dy, lddy,
                      slab, H, W, C, t.ncgb, t.ntx, t.nty, t.ntiles, tpb, pscale, pshift, prelu);
 }

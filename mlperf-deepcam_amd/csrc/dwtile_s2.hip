@@ -346,18 +346,17 @@ static void launch3(int mode, S2Args a, int N, const void* p0, int ld0, const fl
   a.nty = cdiv(mode == 1 ? a.Hi : a.Ho, mode == 1 ? 8 : 4);
   a.ncgb = cdiv(a.C / Elem<T>::kPerVec, CG);
   const int ntiles = N * a.ntx * a.nty;
-  static bool attr[3] = {false, false, false};
   if (mode == 0) {
-    if (!attr[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_fwd_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_F); attr[0] = true; }
+    DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_fwd_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_F));
     hipLaunchKernelGGL((dws2_fwd_kernel<T, CG>), dim3(ntiles * a.ncgb), dim3(256), LDS_F, st, (const T*)p0, ld0, wp, (T*)out, ldout, a);
   } else if (mode == 1) {
-    if (!attr[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_dgrad_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D); attr[1] = true; }
+    DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_dgrad_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
     if (bs.slab != nullptr) bs.rows = ntiles;
     if (rows_out) *rows_out = ntiles;
     hipLaunchKernelGGL((dws2_dgrad_kernel<T, CG>), dim3(ntiles * a.ncgb), dim3(256), LDS_D, st, (const T*)p0, ld0, wp, (const T*)p1, ld1, (T*)out, ldout, a, bs);
   } else {
     constexpr int LDS_W = LDS_F > FOLD ? LDS_F : FOLD;
-    if (!attr[2]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_wgrad_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_W); attr[2] = true; }
+    DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_wgrad_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_W));
     long tpb = ((long)ntiles * a.ncgb + 256) / 512;      // ~512 workgroups, as the stride-1 planner
     if (tpb < 1) tpb = 1;
     while (cdiv(ntiles, tpb) > DWT_MAX_ROWS) ++tpb;

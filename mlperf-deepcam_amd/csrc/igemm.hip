@@ -468,11 +468,7 @@ static int launch_igemm2(const IgemmParams& p, hipStream_t st) {
   constexpr int CROW = BN * (int)(OUT32 ? 4 : sizeof(T)) + 16;
   constexpr size_t RING = (size_t)2 * StageCfg<MODE>::NSTAGE * BM * StageCfg<MODE>::ROWB;
   const size_t lds = (RING > (size_t)BM * CROW ? RING : (size_t)BM * CROW) + 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, OUT32, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, OUT32, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid(cdiv(p.g.Cout, BN) * cdiv(p.M - p.m_beg, BM) * p.g.os * p.g.os);
   hipLaunchKernelGGL((igemm_kernel<T, OUT32, MODE>), grid, dim3(256), lds, st, p);
   DC_CHECK_LAUNCH();

@@ -543,16 +543,15 @@ void igemm256_set_phase_fast(int v) { g_phase_fast = v ? 1 : 0; }
 
 int launch_igemm256(const IgemmParams& p_in, hipStream_t st) {
   const size_t lds = (size_t)MAIN_BYTES + 128;
-  static bool attr_set = false;
   static const void* zero_dev = nullptr;
-  if (!attr_set) {
+  static hipError_t init_err = hipSuccess;
+  DC_ONCE({
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void* zp = nullptr;
-    hipError_t e = hipGetSymbolAddress(&zp, HIP_SYMBOL(zero_page256));
-    if (e != hipSuccess) return dc_set_error(e, __FILE__, __LINE__);
+    init_err = hipGetSymbolAddress(&zp, HIP_SYMBOL(zero_page256));
     zero_dev = zp;
-    attr_set = true;
-  }
+  });
+  if (init_err != hipSuccess) return dc_set_error(init_err, __FILE__, __LINE__);
   IgemmParams p = p_in;
   p.zero_page = zero_dev;
   p.reg_epilogue = g_reg_epilogue;

@@ -310,6 +310,46 @@ static int ew_blocks2(long total) {
   return (int)b;
 }
 
+// ---- gradient payload for the all-reduce (dist.GradReducer, payload="bf16": SURVEY 5.8, 112.9 MB per step instead of 225.8) ----
+// The fp32 gradient arena is the master copy.  A bucket is rounded to bf16 (round-to-nearest-even) into a send buffer, summed
+// across ranks in bf16 by the collective, and widened back into the arena, which then holds the (bf16-rounded) SUM.
+__global__ __launch_bounds__(256) void grad_pack_bf16_kernel(long n, const float* __restrict__ g, bf16* __restrict__ out) {
+  const long nv = n >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    const vec16 a = ldg16(g + i * 8), b = ldg16(g + i * 8 + 4);
+    vec16 o;
+    o.w[0] = pack2_bf16(__uint_as_float(a.w[0]), __uint_as_float(a.w[1]));
+    o.w[1] = pack2_bf16(__uint_as_float(a.w[2]), __uint_as_float(a.w[3]));
+    o.w[2] = pack2_bf16(__uint_as_float(b.w[0]), __uint_as_float(b.w[1]));
+    o.w[3] = pack2_bf16(__uint_as_float(b.w[2]), __uint_as_float(b.w[3]));
+    stg16(out + i * 8, o);
+  }
+  if (blockIdx.x == 0) {
+    const long t = nv * 8 + threadIdx.x;
+    if (t < n) out[t] = (bf16)g[t];
+  }
+}
+
+__global__ __launch_bounds__(256) void grad_unpack_bf16_kernel(long n, const bf16* __restrict__ in, float* __restrict__ g) {
+  const long nv = n >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    float f[8];
+    unpack(ldg16(in + i * 8), f, bf16());
+    vec16 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a.w[e] = __float_as_uint(f[e]);
+      b.w[e] = __float_as_uint(f[4 + e]);
+    }
+    stg16(g + i * 8, a);
+    stg16(g + i * 8 + 4, b);
+  }
+  if (blockIdx.x == 0) {
+    const long t = nv * 8 + threadIdx.x;
+    if (t < n) g[t] = (float)in[t];
+  }
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -373,6 +413,22 @@ extern "C" int dc_copy_view(int dtype, long M, int C, const void* src, int lds, 
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const int blocks = ew_blocks2(M * (C / kpv));
   DISPATCH_T(dtype, hipLaunchKernelGGL((hw_ew_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, M, 1, C, src, lds, 1.f, (T*)dst, ldd));
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dc_grad_pack_bf16(long n, const float* g, void* out_bf16, void* stream) {
+  DC_REQUIRE(g && out_bf16 && n > 0, "dc_grad_pack_bf16: bad argument");
+  DC_REQUIRE((((uintptr_t)g | (uintptr_t)out_bf16) & 15) == 0, "dc_grad_pack_bf16: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(grad_pack_bf16_kernel, dim3(ew_blocks2(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, n, g, (bf16*)out_bf16);
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int dc_grad_unpack_bf16(long n, const void* in_bf16, float* g, void* stream) {
+  DC_REQUIRE(g && in_bf16 && n > 0, "dc_grad_unpack_bf16: bad argument");
+  DC_REQUIRE((((uintptr_t)g | (uintptr_t)in_bf16) & 15) == 0, "dc_grad_unpack_bf16: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(grad_unpack_bf16_kernel, dim3(ew_blocks2(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, n, (const bf16*)in_bf16, g);
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -534,8 +534,7 @@ extern "C" int dc_head_fwd(int dtype, int N, int Cin, int Hi, int Wi, const void
   if (dtype == DC_BF16 && g_head_fused && Cin == 256) {
     const int ntx = cdiv(Wi, HF_TX), nty = cdiv(Hi, HF_TY), strips = cdiv(ntx, HF_TILES);
     const size_t lds = (size_t)HF_MB * 16 * HEAD_NP * 4 + (size_t)HEAD_NP * Cin * 2;
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(head_fused_fwd_kernel, dim3(strips * nty * N), dim3(256), lds, st, (const bf16*)x, ldx, (const bf16*)ws.wf, logits_nchw,
                        N, Hi, Wi, Cin, ntx);
     DC_CHECK_LAUNCH();

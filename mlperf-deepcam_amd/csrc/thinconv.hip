@@ -365,13 +365,11 @@ int launch_thin_wgrad(const dc_conv_desc& d, int N, int Hi, int Wi, const void* 
   DC_REQUIRE((long)N * Hi * Wi < (1L << 31), "dc_conv_wgrad: tensor too large for the thin path");
   if (d.cin == 16) {
     typedef ThinCfg<16, 32, 2> K;
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_kernel<16, 32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS); once = true; }
+    DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_kernel<16, 32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS));
     hipLaunchKernelGGL((thin_wgrad_kernel<16, 32, 2>), dim3(p.blocks), dim3(256), K::LDS, st, a);
   } else {
     typedef ThinCfg<32, 64, 1> K;
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_kernel<32, 64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS); once = true; }
+    DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_kernel<32, 64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS));
     hipLaunchKernelGGL((thin_wgrad_kernel<32, 64, 1>), dim3(p.blocks), dim3(256), K::LDS, st, a);
   }
   DC_CHECK_LAUNCH();
@@ -407,8 +405,7 @@ int launch_thin_fwd(const GatherGeom& g, int N, const void* in, int ldin, const 
 #define THIN_FWD(CI, CO)                                                                                                        \
   do {                                                                                                                          \
     constexpr int LDS = ((9 * CI + 31) / 32) * CO * 64;                                                                         \
-    static bool once = false;                                                                                                   \
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel<CI, CO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; } \
+    DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel<CI, CO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
     hipLaunchKernelGGL((thin_fwd_kernel<CI, CO>), dim3(grid), dim3(256), LDS, st, a);                                           \
   } while (0)
   if (g.Cin == 16) THIN_FWD(16, 32);

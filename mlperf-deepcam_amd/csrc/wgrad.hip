@@ -546,23 +546,20 @@ extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const
     if (int e = launch_wgrad256(p, st)) return e;
   } else if (g_wgrad_mode == 1) {
     const size_t lds = 3 * 2 * 8192;
-    static bool once_b = false, once_f = false;
     if (d->dtype == DC_BF16) {
-      if (!once_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once_b = true; }
+      DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(wgrad_dma_kernel<bf16>, grid, dim3(256), lds, st, p);
     } else {
-      if (!once_f) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once_f = true; }
+      DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(wgrad_dma_kernel<float>, grid, dim3(256), lds, st, p);
     }
   } else if (d->dtype == DC_BF16) {
     const size_t lds = 4 * (size_t)WgTraits<bf16>::BP * WgTraits<bf16>::ROW;
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(wgrad_kernel<bf16>, grid, dim3(256), lds, st, p);
   } else {
     const size_t lds = 4 * (size_t)WgTraits<float>::BP * WgTraits<float>::ROW;
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), lds, st, p);
   }
   DC_CHECK_LAUNCH();

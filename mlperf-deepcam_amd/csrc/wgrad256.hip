@@ -284,16 +284,15 @@ void wgrad256_plan(const GatherGeom& g, long M, int* splits, int* chunk, int gro
 
 int launch_wgrad256(const WgradParams& p, hipStream_t st, int group, const void* const* xs, const void* const* dys, float* const* slabs) {
   const size_t lds = (size_t)WNST * WSTAGE;
-  static bool attr_set = false;
   static const void* zero_dev = nullptr;
-  if (!attr_set) {
+  static hipError_t init_err = hipSuccess;
+  DC_ONCE({
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void* zp = nullptr;
-    hipError_t e = hipGetSymbolAddress(&zp, HIP_SYMBOL(wg256_zero_page));
-    if (e != hipSuccess) return dc_set_error(e, __FILE__, __LINE__);
+    init_err = hipGetSymbolAddress(&zp, HIP_SYMBOL(wg256_zero_page));
     zero_dev = zp;
-    attr_set = true;
-  }
+  });
+  if (init_err != hipSuccess) return dc_set_error(init_err, __FILE__, __LINE__);
   Wgrad256Params pp;
   pp.w = p;
   pp.zero_page = zero_dev;

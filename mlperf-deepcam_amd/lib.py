@@ -89,6 +89,8 @@ _SIGS = {
     "dc_adam_step": (I, [I, L, P, P, P, P, P, F, F, F, F, P, F, P]),
     "dc_lamb_workspace_words": (SZ, [I, C.c_long]),
     "dc_lamb_step": (I, [I, P, L, P, P, P, P, P, F, F, F, F, P, F, F, P, P]),
+    "dc_grad_pack_bf16": (I, [L, P, P, P]),
+    "dc_grad_unpack_bf16": (I, [L, P, P, P]),
 }
 EXPORTS = sorted(_SIGS)
 

@@ -127,6 +127,8 @@ class _NetFn(torch.autograd.Function):
         ctx.eng, ctx.module = eng, module
         out = eng.forward(x, train=module.training)
         if module.training:
+            if len(_dlogits_for) > 64:           # engines come and go with input shapes: drop entries of freed buffers
+                _dlogits_for.clear()
             _dlogits_for[out.data_ptr()] = eng.dlogits
         return out
 
@@ -191,6 +193,8 @@ class DeepLabv3_plus(torch.nn.Module):
             else:
                 eng = Engine(B, H, W, self.act_dtype, n_input=self.n_input, n_classes=self.n_classes, share_from=self._primary)
             self._engines[key] = eng
+            if self._ddp_reducer is not None:
+                self._ddp_reducer.hook(eng)       # every engine that shares the arena reports its gradients to the reducer
         return eng
 
     def materialize(self, batch: int, height: int, width: int) -> Engine:
@@ -288,7 +292,9 @@ class ArenaOptimizer:
         self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self._offsets = torch.tensor(lay.offsets(), dtype=torch.int64, device=dev)
-        self._lamb_ws = torch.zeros(L.load().dc_lamb_workspace_words(len(lay.params), lay.n_params), dtype=torch.float32, device=dev)
+        # the LAMB workspace holds an n-element update direction (226 MB): only LAMB allocates it
+        self._lamb_ws = (torch.zeros(L.load().dc_lamb_workspace_words(len(lay.params), lay.n_params), dtype=torch.float32, device=dev)
+                         if self.kind == L.DC_LAMB else None)
         self.state = {}
 
     def zero_grad(self, set_to_none: bool = True):
@@ -482,6 +488,11 @@ class TrainStep:
         waits for them before the optimizer and the 1/world averaging rides in the optimizer kernel (no extra pass)."""
         self.after_backward = reducer.finish
         self.opt.grad_scale = 1.0 / reducer.world
+        # one averaging mechanism per module: the autograd path (DistributedDataParallel -> finish(average=True)) is switched off
+        reducer.averaging_in_optimizer = True
+        reducer.hook(self.eng)
+        if getattr(self.net, "_ddp_reducer", None) is reducer:
+            self.net._ddp_reducer = None
 
     def launch(self, x: torch.Tensor, labels: torch.Tensor) -> None:
         eng = self.eng

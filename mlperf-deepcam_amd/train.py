@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import argparse as ap
 import json
+import math
 import os
 import sys
 import time
@@ -76,6 +77,27 @@ class MLLogger:
 
     def log_event(self, key, value=None, metadata=None, sync=False):
         self._emit("POINT_IN_TIME", key, value, metadata, sync)
+
+
+def amp_state_dict(opt_level: str = "O0"):
+    """The 'amp' entry of the reference's checkpoint (train_hdf5_ddp.py:524-525 writes apex's amp.state_dict(), :238-239 feeds it
+    back through amp.load_state_dict, which raises KeyError without it).  apex's format as published (apex/amp/frontend.py,
+    state_dict / load_state_dict): one entry per loss scaler, 'loss_scaler%d' -> {'loss_scale': float, 'unskipped': int}.
+    bf16 here needs no loss scaling, so the entry carries what a fresh apex run starts from: the dynamic scaler's initial 2**16
+    for O1/O2/O3 and the static 1.0 of O0 -- a reference + apex run resuming from this file then behaves like a fresh scaler."""
+    from collections import OrderedDict
+    scale = 1.0 if opt_level == "O0" else 2.0 ** 16
+    return OrderedDict(loss_scaler0={"loss_scale": scale, "unskipped": 0})
+
+
+def check_amp_state(state) -> None:
+    """Accept (and ignore) the 'amp' entry of a checkpoint: loss-scaler state has no counterpart in the bf16 / fp32 engine.
+    A malformed entry is an error, a missing one is fine (reference runs without apex do not write it)."""
+    if state is None:
+        return
+    for k, v in state.items():
+        if not (k.startswith("loss_scaler") and "loss_scale" in v and "unskipped" in v):
+            raise ValueError(f"checkpoint['amp'][{k!r}] is not an apex loss-scaler entry")
 
 
 def build_parser():
@@ -161,6 +183,7 @@ def main(pargs):
         start_step, start_epoch = checkpoint["step"], checkpoint["epoch"]
         optimizer.load_state_dict(checkpoint["optimizer"])
         ddp.load_state_dict(checkpoint["model"])
+        check_amp_state(checkpoint.get("amp"))          # written by a reference + apex run (train_hdf5_ddp.py:524-525): nothing to restore
     else:
         start_step, start_epoch = 0, 0
 
@@ -223,7 +246,12 @@ def main(pargs):
                 current_lr = scheduler.get_last_lr()[0]
                 scheduler.step()
             if step % pargs.logging_frequency == 0:
-                vals = torch.tensor([train_step.loss(), train_step.iou()], dtype=torch.float32, device=device)
+                loss_now = train_step.loss()
+                if not math.isfinite(loss_now):
+                    # the fused loss kernel turns a label outside [0, 3) into NaN (the reference's CrossEntropyLoss raises on it,
+                    # losses.py:50); one such step poisons every weight, so stop here instead of training on NaNs
+                    raise RuntimeError(f"non-finite training loss {loss_now} at step {step}: corrupt label or diverged run")
+                vals = torch.tensor([loss_now, train_step.iou()], dtype=torch.float32, device=device)
                 if size > 1:
                     dist.reduce(vals, dst=0, op=dist.ReduceOp.SUM)
                 loss_avg_train, iou_avg_train = (vals / float(size)).tolist()
@@ -262,7 +290,8 @@ def main(pargs):
                 md = {"epoch_num": epoch + 1, "step_num": step}
                 logger.log_start(key="save_start", metadata=md, sync=True)
                 if rank == 0:
-                    checkpoint = {"step": step, "epoch": epoch, "model": ddp.state_dict(), "optimizer": optimizer.state_dict()}
+                    checkpoint = {"step": step, "epoch": epoch, "model": ddp.state_dict(), "optimizer": optimizer.state_dict(),
+                                  "amp": amp_state_dict(pargs.amp_opt_level)}
                     torch.save(checkpoint, os.path.join(pargs.output_dir, pargs.model_prefix + "_step_" + str(step) + ".cpt"))
                 logger.log_end(key="save_stop", metadata=md, sync=True)
             if pargs.max_steps is not None and step >= pargs.max_steps:

@@ -52,3 +52,24 @@ def test_mllog_line_format(tmp_path, capsys):
     # the file holds the same lines
     with open(os.path.join(str(tmp_path), "logs", "t.log")) as f:
         assert [l.rstrip("\n") for l in f if l.startswith(":::MLLOG ")] == out
+
+
+def test_checkpoint_amp_entry_has_apex_loader_shape():
+    """train_hdf5_ddp.py:238-239,524-525: the checkpoint carries apex's amp.state_dict().  apex's loader (apex/amp/frontend.py,
+    load_state_dict, as published) walks 'loss_scaler%d' entries and reads v['loss_scale'] and v['unskipped']; replay that walk."""
+    from collections import OrderedDict
+    from mlperf_deepcam_amd import train
+    for level, scale in (("O0", 1.0), ("O1", 65536.0)):
+        sd = train.amp_state_dict(level)
+        assert isinstance(sd, OrderedDict) and len(sd) == 1          # one loss, one scaler (amp.initialize default num_losses=1)
+        scalers = [{}]
+        for idx, (k, v) in enumerate(sd.items()):
+            assert "loss_scaler" in k and k == "loss_scaler%d" % idx
+            scalers[idx]["_loss_scale"] = v["loss_scale"]
+            scalers[idx]["_unskipped"] = v["unskipped"]
+        assert scalers[0] == {"_loss_scale": scale, "_unskipped": 0}
+        train.check_amp_state(sd)
+    train.check_amp_state(None)
+    import pytest
+    with pytest.raises(ValueError):
+        train.check_amp_state({"loss_scaler0": {"loss_scale": 1.0}})
