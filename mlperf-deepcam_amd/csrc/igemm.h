@@ -42,6 +42,11 @@ inline long igemm256_tiles(const IgemmParams& p) {
   return (long)((p.g.Cout + 255) / 256) * ((p.M - p.m_beg + 255) / 256) * p.g.os * p.g.os * (p.ngroup > 1 ? p.ngroup : 1);
 }
 
+// igemm384.hip: pointwise layers on a (32*npb) x 384 tile, one wave per SIMD (npb = 8 or 4 pixel blocks per wave)
+bool pw384_eligible(const IgemmParams& p);
+int launch_pw384(const IgemmParams& p, int npb, hipStream_t st);
+inline long pw384_tiles(const IgemmParams& p, int npb) { return (long)((p.g.Cout + 383) / 384) * ((p.M + 32 * npb - 1) / (32 * npb)); }
+
 // thinconv.hip: the thin 3x3 stem convolutions (forward and data gradient) without LDS staging of the pixel operand
 bool thin_fwd_eligible(const GatherGeom& g, int dtype, int bias, int accumulate, int out32);
 int launch_thin_fwd(const GatherGeom& g, int N, const void* in, int ldin, const void* w, int ldw, void* out, int ldout, float* slab,

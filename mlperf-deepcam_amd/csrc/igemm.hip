@@ -492,6 +492,25 @@ static int g_igemm_mix = 0;        // mixed 256-tile / 128-tile plan (off: bit-e
 static int g_mix_cus = 256;        // workgroup slots of a 256-tile round (tuning / test switch: a small value cuts small problems)
 static int g_mix_tail_pct = 40;    // largest fill of the last round (percent) that is handed to the 128-tile kernel
 static int g_rel256 = 0;   // 0: model below; otherwise cost of a 256-tile round in percent of a 128-tile round (tuning switch)
+// Pointwise layers on the one-wave-per-SIMD kernel (igemm384.hip).  0: never, 1: where the round model below expects it to win,
+// 2 / 3: whenever eligible with 256- / 128-pixel tiles (tests and A/B runs).  Costs are in rounds of 256 x 256 tiles: a
+// 256 x 384 tile is 1.5 of them, a 128 x 384 tile 0.8 (its weight fill is not halved), a round of the 128-tile kernel about 1 at
+// the K depths in question (see igemm256_wins).  The layer must also fill most of the chip with its one workgroup per CU.
+static int g_pw384 = 1;
+static int pw384_plan(const IgemmParams& p) {
+  if (g_pw384 == 0 || !pw384_eligible(p)) return 0;
+  if (g_pw384 == 2) return 8;
+  if (g_pw384 == 3) return 4;
+  const long t128 = (long)cdiv(p.g.Cout, BN) * p.mtiles, t256 = igemm256_tiles(p);
+  const double c_old = (double)(cdiv(t256, 256) < cdiv(t128, 768) ? cdiv(t256, 256) : cdiv(t128, 768));
+  if (p.g.Cout * 10 < (long)cdiv(p.g.Cout, 384) * 384 * 9) return 0;      // a 384-wide tile that is more than a tenth empty loses
+  const long t8 = pw384_tiles(p, 8), t4 = pw384_tiles(p, 4);
+  const double c8 = t8 >= 160 ? cdiv(t8, 256) * 1.5 : 1e9, c4 = t4 >= 160 ? cdiv(t4, 256) * 0.8 : 1e9;
+  const double best = c8 < c4 ? c8 : c4;
+  if (best >= 0.9 * c_old) return 0;
+  return c8 < c4 ? 8 : 4;
+}
+
 static bool igemm256_wins(const IgemmParams& p) {
   const long t128 = (long)cdiv(p.g.Cout, BN) * p.mtiles * p.g.os * p.g.os;
   const long t256 = igemm256_tiles(p);
@@ -542,6 +561,9 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   }
   if (g_thin_fwd && thin_fwd_eligible(p.g, d->dtype, bias != nullptr, accumulate, out32))
     return launch_thin_fwd(p.g, N, in, ldin, w, p.ldw, out, ldout, slab, p.mtiles * p.g.os * p.g.os, st);
+  if (d->dtype == DC_BF16 && !out32) {
+    if (const int npb = pw384_plan(p)) return launch_pw384(p, npb, st);
+  }
   if (d->dtype == DC_BF16 && !out32 && g_igemm256 != 0) {
     if (g_igemm256 == 2 || igemm256_wins(p)) {
       // Mixed plan.  The 256-tile kernel holds one workgroup per CU, so a layer of r.f rounds pays for r+1 (the 728 -> 728
@@ -813,6 +835,7 @@ extern "C" int dc_set_option(const char* name, int value) {
     return 0;
   }
   if (name != nullptr && strcmp(name, "igemm256") == 0) { g_igemm256 = value; return 0; }
+  if (name != nullptr && strcmp(name, "pw384") == 0) { g_pw384 = value; return 0; }
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm_mix") == 0) { g_igemm_mix = value != 0; return 0; }

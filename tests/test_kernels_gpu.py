@@ -128,6 +128,65 @@ def test_conv_256_tile_wgrad_kernel(case):
         L.call("dc_set_option", b"wgrad256", 1)
 
 
+PW_CASES = [c for c in CONV_CASES if c[1] == 1 and c[2] == 1 and c[6] >= 64 and c[8] * c[9] * c[10] > 16]
+
+
+@pytest.mark.parametrize("mode", [2, 3], ids=["256x384", "128x384"])
+@pytest.mark.parametrize("case", PW_CASES, ids=[c[0] for c in PW_CASES])
+def test_conv_pointwise_384_tile_kernel(case, mode):
+    """The two-waves-per-SIMD 256 x 384 / 128 x 384 pointwise kernel (csrc/igemm384.hip), forced on every eligible forward and
+    data-gradient call, passes the same checks against F.conv2d + autograd as the other tile shapes."""
+    L.call("dc_set_option", b"pw384", mode)
+    try:
+        test_conv_fwd_dgrad_wgrad(case, torch.bfloat16)
+    finally:
+        L.call("dc_set_option", b"pw384", 1)
+
+
+@pytest.mark.parametrize("shape", [(728, 728, 3, 19, 17), (728, 728, 2, 48, 72), (136, 392, 2, 21, 13), (1536, 776, 1, 24, 20)],
+                         ids=["ragged969", "middle_flow_b2", "one_and_a_bit_tiles", "long_k_three_tiles"])
+def test_conv_pointwise_384_tile_kernel_same_bits(shape):
+    """Same MFMA instruction and K order as the 256 x 256 / 128 x 128 kernels: outputs bit-equal (forward with bias, accumulate mode,
+    data gradient through padded views), BatchNorm slabs equal up to the order of the additions; pad channels untouched."""
+    cin, cout, N, H, W = shape
+    dtype = torch.bfloat16
+    d = desc(dtype, 1, 1, 0, 1, 0, cin, cout)
+    x = q(rnd(N, cin, H, W, seed=1), dtype)
+    w = rnd(cout, cin, 1, 1, seed=2, scale=cin ** -0.5)
+    bias = rnd(cout, seed=4).to(dev())
+    gy = q(rnd(N, cout, H, W, seed=3), dtype)
+    nwf, nwb = C.c_size_t(), C.c_size_t()
+    L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
+    wf = torch.empty(nwf.value, dtype=dtype, device=dev())
+    wb = torch.empty(nwb.value, dtype=dtype, device=dev())
+    L.call("dc_conv_pack_weights", C.byref(d), vptr(w.to(dev())), vptr(wf), vptr(wb), S())
+    _, xv = to_nhwc(x, dtype, ld=cin + 16, off=8)
+    _, gyv = to_nhwc(gy, dtype)
+    rows = L.load().dc_conv_stat_rows(C.byref(d), N, H, W)
+    got = []
+    try:
+        for mode in (0, 2, 3):
+            L.call("dc_set_option", b"pw384", mode)
+            ybuf, yv = empty_nhwc(N, H, W, cout, dtype, ld=cout + 24, off=16)
+            slab = torch.full((2, rows, cout), float("nan"), device=dev())
+            L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, vptr(slab), 0, S())
+            y0 = from_nhwc(yv).clone()
+            L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), vptr(bias), vptr(yv), cout + 24, None, 1, S())
+            _, gxv = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
+            L.call("dc_conv_dgrad", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(gxv), cin + 8, 0, S())
+            torch.cuda.synchronize()
+            assert torch.isnan(ybuf[..., :16].float()).all() and torch.isnan(ybuf[..., 16 + cout:].float()).all()
+            got.append((y0, from_nhwc(yv), slab.cpu(), from_nhwc(gxv)))
+    finally:
+        L.call("dc_set_option", b"pw384", 1)
+    yref = F.conv2d(x, q(w, dtype))
+    assert_close(got[0][0], yref, dtype)
+    for other in got[1:]:
+        assert torch.equal(got[0][0], other[0]) and torch.equal(got[0][1], other[1]) and torch.equal(got[0][3], other[3])
+        assert not torch.isnan(other[2]).any()
+        np.testing.assert_allclose(got[0][2].numpy(), other[2].numpy(), rtol=2e-5, atol=1e-4)
+
+
 def conv_ref(x, w, bias, k, stride, pad, dil, transposed):
     if transposed:
         return F.conv_transpose2d(x, w, bias, 2, 1, 1)
@@ -333,7 +392,7 @@ def test_conv_mixed_tile_plan_is_invisible(case):
             got.append((from_nhwc(yv), slab.cpu(), from_nhwc(gxv)))
     finally:
         L.call("dc_set_option", b"igemm256", 1)
-        L.call("dc_set_option", b"igemm_mix", 1)
+        L.call("dc_set_option", b"igemm_mix", 0)          # the library's default
         L.call("dc_set_option", b"igemm_mix_cus", 256)
         L.call("dc_set_option", b"igemm_mix_tail", 40)
     assert_close(got[1][0], 2 * yref, dtype, bf16=4e-2)
