@@ -111,6 +111,13 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
   const int grp = wave / GC;   // pixel group (64 pixels)
   const int wc = wave % GC;    // channel group (NCB blocks of 16)
   const bool late = wave >= 4; // the second wave of its SIMD: issues its LDS-DMAs in the second half of a step
+#ifdef DC_PW384_PROBE
+  // diagnostic builds (make probes; scripts/pw384_probe.py), one library per COMPILE-TIME mask: bit 0 drops the LDS-DMA issues, bit 1
+  // the LDS fragment reads, bit 3 the epilogue stores -- what each costs in the K loop.  Results are garbage by construction.
+  constexpr int probe = DC_PW384_PROBE;
+#else
+  constexpr int probe = 0;
+#endif
 
   // XCD-aware tile order: consecutive tiles of an XCD are the channel tiles of one pixel tile (they share its pixel rows in L2)
   const int ntn = (g.Cout + TN - 1) / TN;
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
     const int kofs = stage * BK;
     const bool ok = (src[i] != 0) & (kofs + lslot * 8 < g.Cin);          // stage >= kchunks fails the K test: zero page
     const uintptr_t a = ok ? src[i] + (uintptr_t)kofs * 2 : zp;
-    __builtin_amdgcn_global_load_lds((gas_ptr)a, (lds_ptr)(smem + (stage % NST) * K::STAGE + (8 * i + wave) * 1024), 16, 0, 0);
+    if constexpr (!(probe & 1)) __builtin_amdgcn_global_load_lds((gas_ptr)a, (lds_ptr)(smem + (stage % NST) * K::STAGE + (8 * i + wave) * 1024), 16, 0, 0);
   };
 
   f32x4 acc[NCB][NPB];   // [channel block][pixel block]
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
     const uint32_t nxt_a = lds0 + ((s + 1) % NST) * K::STAGE + a_off, nxt_b = lds0 + ((s + 1) % NST) * K::STAGE + b_off;
     static_for<0, NCB>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      if constexpr (i + 2 < NCB) lds_read16<(i + 2) * 1024>(fa[(i + 2) % 3], cur_a);      // weight fragment two blocks ahead
+      if constexpr (i + 2 < NCB && !(probe & 2)) lds_read16<(i + 2) * 1024>(fa[(i + 2) % 3], cur_a);      // weight fragment two blocks ahead
       // this step's LDS-DMAs (stage s+2): waves 0..3 in blocks 0 .. IPW-1, waves 4..7 in blocks LATE .. LATE+IPW-1 (all in front of
       // the last block's wait)
       if constexpr (i < K::IPW) {
@@ -193,8 +200,10 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
         // every read of stage s has landed in registers; stage s+1 (issued during step s-1) must have landed for every wave
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * K::IPW) : "memory");
         __builtin_amdgcn_s_barrier();
-        lds_read16<0>(fa[0], nxt_a);                                                      // next step's first two weight fragments
-        lds_read16<1024>(fa[1], nxt_a);
+        if constexpr (!(probe & 2)) {
+          lds_read16<0>(fa[0], nxt_a);                                                    // next step's first two weight fragments
+          lds_read16<1024>(fa[1], nxt_a);
+        }
       }
       static_for<0, NPB>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
         if constexpr (i == 0) lgkm_wait<NPB - j>();
         else if constexpr (j == 0 && i < NCB - 1) lgkm_wait<(NCB - 1 - i < 2 ? NCB - 1 - i : 2)>();
         mfma_v(acc[i][j], fa[i % 3], fb[j]);
-        if constexpr (i == NCB - 1) lds_read16<j * 1024>(fb[j], nxt_b);                   // re-read in place for the next step
+        if constexpr (i == NCB - 1 && !(probe & 2)) lds_read16<j * 1024>(fb[j], nxt_b);   // re-read in place for the next step
       });
     });
   }
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
       v.w[1] = odd ? r1 : a1;
       v.w[2] = odd ? b0 : r0;
       v.w[3] = odd ? b1 : r1;
-      if (m < p.M && chok) {
+      if (m < p.M && chok && !(probe & 8)) {
         bf16* dst = yg + (size_t)m * p.ldy + ch0;
         float f[8];
         unpack(v, f, bf16());

@@ -21,7 +21,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 // ROWB: bytes of K per row per stage.  A "stage" is 32 KiB (ROWB 64) or 64 KiB (ROWB 128) of operands; the ring holds 128 KiB.
-// DMA: 0 none, 1 LDS-DMA, 2 global_load_dwordx4 + ds_write_b128.  NMFMA: MFMAs per wave per 32-deep K step (32 = the real kernel).
+// DMA: 0 none, 1 LDS-DMA (global_load_lds, 64-bit per-lane address), 2 global_load_dwordx4 + ds_write_b128, 3 LDS-DMA as
+// buffer_load ... offen lds (resource descriptor + 32-bit per-lane offset + scalar K offset).  NMFMA: MFMAs per wave per 32-deep K step (32 = the real kernel).
 template <int ROWB, int DMA, int NMFMA, int READS>
 __global__ __launch_bounds__(512) void fill_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ w, int M, int C, int ld, int ntn,
                                                    float* __restrict__ out, unsigned long long* __restrict__ cyc) {
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(512) void fill_kernel(const __bf16* __restrict__ x,
   const int lrow = lane / LPR, lslot = lane % LPR;
   // instruction i of this wave: operand (i < IPW/2 ? weights : pixels), rows ((i % (IPW/2)) * 8 + wave) * RPI + lrow
   const __bf16* src[IPW];
+  unsigned voff[IPW];
 #pragma unroll
   for (int i = 0; i < IPW; ++i) {
     const int r = ((i % (IPW / 2)) * 8 + wave) * RPI + lrow;
@@ -47,12 +49,18 @@ __global__ __launch_bounds__(512) void fill_kernel(const __bf16* __restrict__ x,
       int ch = nt * 256 + r;
       if (ch >= C) ch = C - 1;
       src[i] = w + (size_t)ch * ld + lslot * 8;
+      voff[i] = (unsigned)(((size_t)ch * ld + lslot * 8) * 2);
     } else {
       int m = mt * 256 + r;
       if (m >= M) m = M - 1;
       src[i] = x + (size_t)m * ld + lslot * 8;
+      voff[i] = (unsigned)(((size_t)m * ld + lslot * 8) * 2);
     }
   }
+#if defined(__HIP_DEVICE_COMPILE__)     // (the buffer-resource builtins do not exist in the host pass)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)M * ld * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((size_t)C * ld * 2), 0x00020000);
+#endif
   const int steps = (C + KPS - 1) / KPS;
   f32x4 acc[8];
 #pragma unroll
@@ -70,6 +78,10 @@ __global__ __launch_bounds__(512) void fill_kernel(const __bf16* __restrict__ x,
     char* dst = smem + (s % NSTAGE) * STAGE + (i * 8 + wave) * 1024;
     if constexpr (DMA == 1) {
       __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + k), (lds_ptr)dst, 16, 0, 0);
+    } else if constexpr (DMA == 3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(i < IPW / 2 ? rw : rx, (lds_ptr)dst, 16, voff[i], k * 2, 0, 0);
+#endif
     } else {
       const uint4 v = *reinterpret_cast<const uint4*>(src[i] + k);
       *reinterpret_cast<uint4*>(dst + lane * 16) = v;
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(512) void fill_kernel(const __bf16* __restrict__ x,
   float sink = 0.f;
   for (int s = 0; s < steps; ++s) {
     // everything but the newest (NSTAGE-2) stages has landed -> stage s is readable
-    if constexpr (DMA == 1) {
+    if constexpr (DMA == 1 || DMA == 3) {
       if constexpr (NSTAGE == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -268,6 +280,34 @@ void run4(const char* name, const __bf16* x, const __bf16* w, int M, int C, int 
          mean / ksteps32, 128 * NCB, 2.0 * M * C * (double)C / us * 1e-6);
 }
 
+// Does an out-of-range lane of buffer_load ... lds write zeros into LDS (usable as padding) or leave the bytes alone?
+__global__ void oob_kernel(const float* src, int nbytes, float* out) {
+  __shared__ __attribute__((aligned(16))) float lds[256];
+  for (int i = threadIdx.x; i < 256; i += 64) lds[i] = 123.f;
+  __syncthreads();
+  // lanes 0..31 in range, lanes 32..63 far out of range
+  const unsigned off = threadIdx.x < 32 ? threadIdx.x * 16 : 0x40000000u + threadIdx.x * 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, nbytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr)lds, 16, off, 0, 0, 0);
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += 64) out[i] = lds[i];
+}
+void oob_test() {
+  float *src, *out;
+  CK(hipMalloc(&src, 4096));
+  CK(hipMalloc(&out, 1024));
+  std::vector<float> h(1024, 7.f), o(256);
+  CK(hipMemcpy(src, h.data(), 4096, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(oob_kernel, dim3(1), dim3(64), 0, 0, src, 4096, out);
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(o.data(), out, 1024, hipMemcpyDeviceToHost));
+  printf("--- buffer_load ... lds, lanes 32..63 out of range: in-range lane dword %g, out-of-range lane dwords %g %g %g %g (123 = LDS untouched, 0 = zero-filled)\n",
+         o[0], o[128], o[129], o[200], o[255]);
+}
+
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 27648, C = argc > 2 ? atoi(argv[2]) : 728;
   const int ld = (C + 63) / 64 * 64;
@@ -290,11 +330,16 @@ int main(int argc, char** argv) {
     run<128, 1, 0, 0>("LDS-DMA only, 128-byte rows", x, w, M, C, ld, out, cyc, nwg);
     run<64, 2, 0, 0>("load + ds_write only, 64-byte rows", x, w, M, C, ld, out, cyc, nwg);
     run<128, 2, 0, 0>("load + ds_write only, 128-byte rows", x, w, M, C, ld, out, cyc, nwg);
+    run<64, 3, 0, 0>("buffer LDS-DMA only, 64-byte rows", x, w, M, C, ld, out, cyc, nwg);
+    run<128, 3, 0, 0>("buffer LDS-DMA only, 128-byte rows", x, w, M, C, ld, out, cyc, nwg);
+    run<64, 3, 32, 0>("buffer LDS-DMA + MFMA, 64-byte rows", x, w, M, C, ld, out, cyc, nwg);
+    run<128, 3, 32, 0>("buffer LDS-DMA + MFMA, 128-byte rows", x, w, M, C, ld, out, cyc, nwg);
     run<64, 1, 32, 0>("LDS-DMA + MFMA, 64-byte rows", x, w, M, C, ld, out, cyc, nwg);
     run<128, 1, 32, 0>("LDS-DMA + MFMA, 128-byte rows", x, w, M, C, ld, out, cyc, nwg);
     run<64, 1, 32, 6>("LDS-DMA + MFMA + 12 ds_read, 64-byte rows", x, w, M, C, ld, out, cyc, nwg);
     run<128, 1, 32, 6>("LDS-DMA + MFMA + 12 ds_read, 128-byte rows", x, w, M, C, ld, out, cyc, nwg);
   }
+  oob_test();
   printf("--- one wave per SIMD, 256 x 384 tile, 4 waves\n");
   run4<0, 0, 12>("256x384: MFMA only (96 per K step per wave)", x, w, M, C, ld, out, cyc);
   run4<1, 0, 12>("256x384: LDS-DMA + MFMA", x, w, M, C, ld, out, cyc);
