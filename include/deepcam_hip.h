@@ -103,6 +103,15 @@ int dc_conv_fwd_dilated_group(const dc_conv_desc* d, int N, int Hi, int Wi, int 
 /* dx = conv_backward_data(dy, w).  Hi, Wi are the FORWARD input extents (= extents of dx). */
 int dc_conv_dgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb,
                   void* dx, int lddx, int accumulate, void* stream);
+/* The same data gradient when dx is the gradient w.r.t. a BatchNorm(+ReLU) output act(bn(y)) that feeds only this conv
+ * (deeplab_xception.py:361-374 and the other conv -> BatchNorm -> ReLU -> conv chains): the BatchNorm's backward sums (sum g,
+ * sum g*xhat; g = the stored dx masked by y*mscale + mshift > 0 when relu) are taken in the epilogue into slab[2][rows][C],
+ * rows = dc_conv_dgrad_bnstats_rows (0: this layer is not served), so dc_bn_bwd_reduce's pass over dx and y is not needed.
+ * dx is written, never accumulated. */
+int dc_conv_dgrad_bnstats_rows(const dc_conv_desc* d, int N, int Hi, int Wi);
+int dc_conv_dgrad_bnstats(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb, void* dx,
+                          int lddx, const void* y, int ldy, const float* mean, const float* invstd, const float* mscale,
+                          const float* mshift, int relu, float* slab, void* stream);
 
 /* grad_w (fp32, PyTorch master layout) = conv_backward_weight(x, dy).  Split over the pixel axis into fp32
  * partial slabs in `workspace` (dc_conv_wgrad_workspace bytes), then reduced deterministically. */
@@ -206,6 +215,12 @@ int dc_head_fwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ld
  * 27-tap gradient image).  workspace: dc_head_workspace bytes, 256-byte aligned. */
 int dc_head_bwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
                 const float* w, void* dx, int lddx, float* grad_w, void* workspace, void* stream);
+/* dc_head_bwd when x = act(bn(bn_y)) (upsample.deconv3: ConvTranspose2d -> BatchNorm2d -> ReLU, deeplab_xception.py:371-373): the
+ * data gradient also leaves that BatchNorm's backward sums in bn_slab[2][cdiv(N*Hi*Wi, 128)][Cin] (see dc_conv_dgrad_bnstats). */
+int dc_head_bwd_bnstats(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
+                        const float* w, void* dx, int lddx, float* grad_w, void* workspace, const void* bn_y, int bn_ldy,
+                        const float* bn_mean, const float* bn_invstd, const float* bn_mscale, const float* bn_mshift,
+                        int bn_relu, float* bn_slab, void* stream);
 
 /* NCHW fp32 (the layout train_hdf5_ddp.py:348 hands over) -> NHWC `dtype`: the one layout pass of the step. */
 int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, void* out, int ldo, void* stream);

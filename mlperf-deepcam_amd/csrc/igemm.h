@@ -4,6 +4,19 @@
 
 namespace dc {
 
+// Optional epilogue of a data-gradient launch whose output is the gradient w.r.t. a BatchNorm(+ReLU) output: the BatchNorm's
+// backward sums (sum g, sum g * xhat; g = the stored gradient masked by the ReLU, recomputed as y * mscale + mshift > 0) are taken
+// from the values on their way out, into the statistics slab, instead of a separate pass over dx and y (bn.hip, colred MODE 1).
+struct BnBwdEpi {
+  const void* y;        // BatchNorm input (raw conv output), same shape and dtype as the produced gradient; null: off
+  int ldy;
+  const float* mean;
+  const float* invstd;
+  const float* mscale;  // forward scale / shift (only read when relu)
+  const float* mshift;
+  int relu;
+};
+
 struct IgemmParams {
   const void* x;
   const void* w;
@@ -25,6 +38,7 @@ struct IgemmParams {
   // launch.  g holds the unit-dilation tap table (dy, dx in {-1,0,1}); member b gathers at dy*gdil[b], dx*gdil[b], multiplies
   // by gw[b] and writes gy[b] / gslab[b].  Member 0 is (w, y, slab) above with gdil[0].  ngroup <= 1: plain launch.
   static constexpr int MAXGROUP = 4;
+  BnBwdEpi bst;            // 128- and 256-tile kernels (LDS epilogue): slab receives BatchNorm-backward sums instead of (sum, sum of squares)
   int ngroup;
   int gdil[MAXGROUP];
   const void* gw[MAXGROUP - 1];

@@ -351,19 +351,59 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
   for (int e = 0; e < KPVO; ++e) ssum[e] = ssq[e] = 0.f;
   TO* __restrict__ yg = reinterpret_cast<TO*>(p.y);
+  // BatchNorm-backward sums instead of (sum, sum of squares): this thread's channels are fixed, their vectors live in registers
+  const bool bwd_stats = p.bst.y != nullptr;
+  const TO* __restrict__ by = reinterpret_cast<const TO*>(p.bst.y);
+  float bmu[KPVO], bis[KPVO], bms[KPVO], bmh[KPVO];
+#pragma unroll
+  for (int e = 0; e < KPVO; ++e) {
+    const bool ok = bwd_stats && ch0 + e < g.Cout;
+    bmu[e] = ok ? p.bst.mean[ch0 + e] : 0.f;
+    bis[e] = ok ? p.bst.invstd[ch0 + e] : 0.f;
+    bms[e] = (ok && p.bst.relu) ? p.bst.mscale[ch0 + e] : 0.f;
+    bmh[e] = (ok && p.bst.relu) ? p.bst.mshift[ch0 + e] : 0.f;
+  }
+  auto out_pixel = [&](int m) -> size_t {
+    if (g.os == 1) return (size_t)m;          // the phase grid IS the output, pixel index = m
+    const int n = fast_div(m, g.div_hw);
+    const int rem = m - n * (g.Qh * g.Qw);
+    const int qy = fast_div(rem, g.div_w), qx = rem - qy * g.Qw;
+    return (size_t)(n * g.Hout + qy * g.os + py) * g.Wout + qx * g.os + px;
+  };
+  if (bwd_stats) {
+    // BatchNorm-backward form of the store loop: the BatchNorm inputs of all passes are requested together in front of it (see
+    // igemm256.hip)
+    vec16 yq[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int m = m0 + rsub + ps * RPP;
+      yq[ps] = (m < p.M && chok) ? ldg16(by + out_pixel(m) * p.bst.ldy + ch0) : zero16();
+    }
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int row = rsub + ps * RPP;
+      const int m = m0 + row;
+      if (m < p.M && chok) {
+        const vec16 v = *reinterpret_cast<const vec16*>(ct + row * CROW + grp * 16);
+        stg16(yg + out_pixel(m) * p.ldy + ch0, v);
+        float f[KPVO], yv[KPVO];
+        unpack(v, f, TO());
+        unpack(yq[ps], yv, TO());
+#pragma unroll
+        for (int e = 0; e < KPVO; ++e) {
+          const float gm = (!p.bst.relu || fmaf(yv[e], bms[e], bmh[e]) > 0.f) ? f[e] : 0.f;
+          ssum[e] += gm;
+          ssq[e] = fmaf(gm, (yv[e] - bmu[e]) * bis[e], ssq[e]);
+        }
+      }
+    }
+  } else {
 #pragma unroll 2
   for (int ps = 0; ps < PASSES; ++ps) {
     const int row = rsub + ps * RPP;
     const int m = m0 + row;
     if (m < p.M && chok) {
-      size_t opix = (size_t)m;              // os == 1: the phase grid IS the output, pixel index = m
-      if (g.os != 1) {
-        const int n = fast_div(m, g.div_hw);
-        const int rem = m - n * (g.Qh * g.Qw);
-        const int qy = fast_div(rem, g.div_w), qx = rem - qy * g.Qw;
-        opix = (size_t)(n * g.Hout + qy * g.os + py) * g.Wout + qx * g.os + px;
-      }
-      TO* dst = yg + opix * p.ldy + ch0;
+      TO* dst = yg + out_pixel(m) * p.ldy + ch0;
       vec16 v = *reinterpret_cast<const vec16*>(ct + row * CROW + grp * 16);
       float f[KPVO];
       unpack(v, f, TO());
@@ -382,6 +422,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         ssq[e] += f[e] * f[e];
       }
     }
+  }
   }
   if (p.slab != nullptr) {
     __syncthreads();  // everyone is done reading the C tile
@@ -527,7 +568,7 @@ static int check_view(const void* ptr, int ld, int c, int dtype, const char* wha
 
 static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int Wi, const void* in, int ldin,
                       const void* w, const float* bias, void* out, int ldout, float* slab, int accumulate,
-                      void* stream, bool out32 = false) {
+                      void* stream, bool out32 = false, const BnBwdEpi* bst = nullptr) {
   DC_REQUIRE(d != nullptr, "dc_conv: null descriptor");
   DC_REQUIRE(d->dtype == DC_F32 || d->dtype == DC_BF16, "dc_conv: bad dtype");
   DC_REQUIRE(d->transposed || d->k == 1 || d->k == 3, "dc_conv: kernel size must be 1 or 3");
@@ -550,18 +591,25 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   p.phase_fast = 0;
   p.zero_page = nullptr;
   p.ngroup = 0;
+  p.bst = BnBwdEpi{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
+  if (bst != nullptr) {
+    DC_REQUIRE(slab != nullptr && !accumulate && !out32 && bias == nullptr, "dc_conv_dgrad_bnstats: needs a slab, no bias, no accumulate");
+    if (int e = check_view(bst->y, bst->ldy, p.g.Cout, d->dtype, "dc_conv_dgrad_bnstats y")) return e;
+    DC_REQUIRE(bst->mean && bst->invstd && (!bst->relu || (bst->mscale && bst->mshift)), "dc_conv_dgrad_bnstats: missing BatchNorm vectors");
+    p.bst = *bst;
+  }
   p.mtiles = cdiv(M, BM);
   p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
-  if (!out32 && p.M <= TINY_M && p.g.ntaps == 1 && p.g.os == 1 && p.g.is == 1 && p.g.taps[0].dy == 0 && p.g.taps[0].dx == 0) {
+  if (bst == nullptr && !out32 && p.M <= TINY_M && p.g.ntaps == 1 && p.g.os == 1 && p.g.is == 1 && p.g.taps[0].dy == 0 && p.g.taps[0].dx == 0) {
     if (d->dtype == DC_BF16) hipLaunchKernelGGL(tiny_gemm_kernel<bf16>, dim3(cdiv(p.g.Cout, 4)), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(tiny_gemm_kernel<float>, dim3(cdiv(p.g.Cout, 4)), dim3(256), 0, st, p);
     DC_CHECK_LAUNCH();
     return 0;
   }
-  if (g_thin_fwd && thin_fwd_eligible(p.g, d->dtype, bias != nullptr, accumulate, out32))
+  if (bst == nullptr && g_thin_fwd && thin_fwd_eligible(p.g, d->dtype, bias != nullptr, accumulate, out32))
     return launch_thin_fwd(p.g, N, in, ldin, w, p.ldw, out, ldout, slab, p.mtiles * p.g.os * p.g.os, st);
-  if (d->dtype == DC_BF16 && !out32) {
+  if (d->dtype == DC_BF16 && !out32 && bst == nullptr) {      // (the BatchNorm-backward epilogue lives in the LDS-epilogue kernels)
     if (const int npb = pw384_plan(p)) return launch_pw384(p, npb, st);
   }
   if (d->dtype == DC_BF16 && !out32 && g_igemm256 != 0) {
@@ -912,6 +960,7 @@ extern "C" int dc_conv_fwd_dilated_group(const dc_conv_desc* d, int N, int Hi, i
   const long M = (long)N * p.g.Qh * p.g.Qw;
   DC_REQUIRE(N > 0 && M < (1L << 31) - BM, "dc_conv_fwd_dilated_group: bad pixel count");
   p.x = x; p.w = wfs[0]; p.y = ys[0]; p.bias = nullptr; p.slab = stat_slabs ? stat_slabs[0] : nullptr;
+  p.bst = BnBwdEpi{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
   p.N = N; p.ldx = ldx; p.ldy = ldy;
   p.ldw = (p.g.Cin + 31) / 32 * 32;
   p.M = (int)M; p.m_beg = 0; p.reg_epilogue = 0; p.phase_fast = 0; p.zero_page = nullptr;
@@ -937,6 +986,23 @@ extern "C" int dc_conv_fwd_f32out(const dc_conv_desc* d, int N, int Hi, int Wi, 
 extern "C" int dc_conv_dgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy,
                              const void* wb, void* dx, int lddx, int accumulate, void* stream) {
   return run_gather(d, kDgrad, N, Hi, Wi, dy, lddy, wb, nullptr, dx, lddx, nullptr, accumulate, stream);
+}
+
+// Data gradient whose output is the gradient w.r.t. a BatchNorm(+ReLU) output y_bn = act(bn(y)): also leaves that BatchNorm's
+// backward sums in `slab` ([2][rows][C], rows = dc_conv_dgrad_bnstats_rows), so that dc_bn_bwd_reduce is not needed.
+extern "C" int dc_conv_dgrad_bnstats_rows(const dc_conv_desc* d, int N, int Hi, int Wi) {
+  if (d == nullptr) return 0;
+  GatherGeom g;
+  if (!build_geom(*d, Hi, Wi, kDgrad, &g)) return 0;
+  const long M = (long)N * g.Qh * g.Qw;
+  return (int)(cdiv(M, BM) * g.os * g.os);
+}
+
+extern "C" int dc_conv_dgrad_bnstats(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb,
+                                     void* dx, int lddx, const void* y, int ldy, const float* mean, const float* invstd,
+                                     const float* mscale, const float* mshift, int relu, float* slab, void* stream) {
+  const BnBwdEpi bst{y, ldy, mean, invstd, mscale, mshift, relu};
+  return run_gather(d, kDgrad, N, Hi, Wi, dy, lddy, wb, nullptr, dx, lddx, slab, 0, stream, false, &bst);
 }
 
 extern "C" int dc_conv_packed_elems(const dc_conv_desc* d, size_t* wf_elems, size_t* wb_elems) {

@@ -454,6 +454,57 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
     for (int e = 0; e < 8; ++e) ssum[h][e] = ssq[h][e] = 0.f;
   bf16* __restrict__ yg = reinterpret_cast<bf16*>(ysel);
   const bool do_stats = slabsel != nullptr;
+  // BatchNorm-backward sums instead of (sum, sum of squares): this thread's channels are fixed, their vectors live in registers
+  const bool bwd_stats = p.bst.y != nullptr;
+  const bf16* __restrict__ by = reinterpret_cast<const bf16*>(p.bst.y);
+  float bmu[8], bis[8], bms[8], bmh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool ok = bwd_stats && ch0 + e < g.Cout;
+    bmu[e] = ok ? p.bst.mean[ch0 + e] : 0.f;
+    bis[e] = ok ? p.bst.invstd[ch0 + e] : 0.f;
+    bms[e] = (ok && p.bst.relu) ? p.bst.mscale[ch0 + e] : 0.f;
+    bmh[e] = (ok && p.bst.relu) ? p.bst.mshift[ch0 + e] : 0.f;
+  }
+  auto out_pixel = [&](int m) -> size_t {
+    if (g.os == 1) return (size_t)m;
+    const int n = fast_div(m, g.div_hw);
+    const int rem = m - n * (g.Qh * g.Qw);
+    const int qy = fast_div(rem, g.div_w), qx = rem - qy * g.Qw;
+    return (size_t)(n * g.Hout + qy * g.os + py) * g.Wout + qx * g.os + px;
+  };
+  if (do_stats && bwd_stats) {
+    // BatchNorm-backward form of the store loop.  The BatchNorm inputs of a half (8 rows per thread) are requested together in front
+    // of it: one load in flight per thread (512 threads on a CU that holds nothing else) made the epilogue a chain of memory
+    // latencies, slower than the separate dc_bn_bwd_reduce pass it replaces.
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      vec16 yq[PASSES / 2];
+#pragma unroll
+      for (int ps = 0; ps < PASSES / 2; ++ps) {
+        const int m = m0 + rsub + (h * (PASSES / 2) + ps) * RPP;
+        yq[ps] = (m < p.M && chok) ? ldg16(by + out_pixel(m) * p.bst.ldy + ch0) : zero16();
+      }
+#pragma unroll
+      for (int ps = 0; ps < PASSES / 2; ++ps) {
+        const int row = rsub + (h * (PASSES / 2) + ps) * RPP;
+        const int m = m0 + row;
+        if (m < p.M && chok) {
+          const vec16 v = *reinterpret_cast<const vec16*>(ct + row * CROW + cgrp * 16);
+          stg16(yg + out_pixel(m) * p.ldy + ch0, v);
+          float f[8], yv[8];
+          unpack(v, f, bf16());
+          unpack(yq[ps], yv, bf16());
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gm = (!p.bst.relu || fmaf(yv[e], bms[e], bmh[e]) > 0.f) ? f[e] : 0.f;
+            ssum[h][e] += gm;
+            ssq[h][e] = fmaf(gm, (yv[e] - bmu[e]) * bis[e], ssq[h][e]);
+          }
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll 2
@@ -461,14 +512,7 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
       const int row = rsub + (h * (PASSES / 2) + ps) * RPP;
       const int m = m0 + row;
       if (m < p.M && chok) {
-        size_t opix = (size_t)m;
-        if (g.os != 1) {
-          const int n = fast_div(m, g.div_hw);
-          const int rem = m - n * (g.Qh * g.Qw);
-          const int qy = fast_div(rem, g.div_w), qx = rem - qy * g.Qw;
-          opix = (size_t)(n * g.Hout + qy * g.os + py) * g.Wout + qx * g.os + px;
-        }
-        bf16* dst = yg + opix * p.ldy + ch0;
+        bf16* dst = yg + out_pixel(m) * p.ldy + ch0;
         vec16 v = *reinterpret_cast<const vec16*>(ct + row * CROW + cgrp * 16);
         float f[8];
         unpack(v, f, bf16());
@@ -490,6 +534,7 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
         }
       }
     }
+  }
   }
   if (slabsel != nullptr) {
     __syncthreads();   // everyone is done reading the C tile
@@ -554,7 +599,7 @@ int launch_igemm256(const IgemmParams& p_in, hipStream_t st) {
   if (init_err != hipSuccess) return dc_set_error(init_err, __FILE__, __LINE__);
   IgemmParams p = p_in;
   p.zero_page = zero_dev;
-  p.reg_epilogue = g_reg_epilogue;
+  p.reg_epilogue = p.bst.y != nullptr ? 0 : g_reg_epilogue;      // the BatchNorm-backward sums live in the LDS epilogue
   p.phase_fast = g_phase_fast;
   hipLaunchKernelGGL(igemm256_kernel, dim3((unsigned)igemm256_tiles(p)), dim3(512), lds, st, p);
   DC_CHECK_LAUNCH();

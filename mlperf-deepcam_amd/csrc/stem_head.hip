@@ -548,8 +548,15 @@ extern "C" int dc_head_fwd(int dtype, int N, int Cin, int Hi, int Wi, const void
   return 0;
 }
 
-extern "C" int dc_head_bwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
-                           const float* w, void* dx, int lddx, float* grad_w, void* workspace, void* stream) {
+extern "C" int dc_conv_dgrad_bnstats(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb,
+                                     void* dx, int lddx, const void* y, int ldy, const float* mean, const float* invstd,
+                                     const float* mscale, const float* mshift, int relu, float* slab, void* stream);
+
+// bn_y != nullptr: x is act(bn(bn_y)) and the data gradient also leaves that BatchNorm's backward sums in bn_slab
+static int head_bwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
+                         const float* w, void* dx, int lddx, float* grad_w, void* workspace, void* stream, const void* bn_y, int bn_ldy,
+                         const float* bn_mean, const float* bn_invstd, const float* bn_mscale, const float* bn_mshift, int bn_relu,
+                         float* bn_slab) {
   if (int e = dc_check_view(x, ldx, Cin, dtype, "dc_head_bwd x")) return e;
   if (int e = dc_check_view(dx, lddx, Cin, dtype, "dc_head_bwd dx")) return e;
   DC_REQUIRE(w && dlogits_nchw && grad_w && workspace && N > 0, "dc_head_bwd: bad argument");
@@ -571,7 +578,25 @@ extern "C" int dc_head_bwd(int dtype, int N, int Cin, int Hi, int Wi, const void
   if (int e = dc_conv_wgrad(&d, N, Hi, Wi, x, ldx, ws.dP, HEAD_NP, ws.slabs, ws.slab_bytes, ws.tmp, stream)) return e;
   hipLaunchKernelGGL(head_wfinish_kernel, dim3(cdiv(Cin * HEAD_NC * 9, 256)), dim3(256), 0, st, (const float*)ws.tmp, grad_w, Cin);
   DC_CHECK_LAUNCH();
+  if (bn_y != nullptr)
+    return dc_conv_dgrad_bnstats(&d, N, Hi, Wi, ws.dP, HEAD_NP, ws.wb, dx, lddx, bn_y, bn_ldy, bn_mean, bn_invstd, bn_mscale, bn_mshift,
+                                 bn_relu, bn_slab, stream);
   return dc_conv_dgrad(&d, N, Hi, Wi, ws.dP, HEAD_NP, ws.wb, dx, lddx, 0, stream);
+}
+
+extern "C" int dc_head_bwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
+                           const float* w, void* dx, int lddx, float* grad_w, void* workspace, void* stream) {
+  return head_bwd_impl(dtype, N, Cin, Hi, Wi, x, ldx, dlogits_nchw, w, dx, lddx, grad_w, workspace, stream, nullptr, 0, nullptr, nullptr,
+                       nullptr, nullptr, 0, nullptr);
+}
+
+extern "C" int dc_head_bwd_bnstats(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
+                                   const float* w, void* dx, int lddx, float* grad_w, void* workspace, const void* bn_y, int bn_ldy,
+                                   const float* bn_mean, const float* bn_invstd, const float* bn_mscale, const float* bn_mshift,
+                                   int bn_relu, float* bn_slab, void* stream) {
+  DC_REQUIRE(bn_y != nullptr && bn_slab != nullptr, "dc_head_bwd_bnstats: needs the BatchNorm input and a slab");
+  return head_bwd_impl(dtype, N, Cin, Hi, Wi, x, ldx, dlogits_nchw, w, dx, lddx, grad_w, workspace, stream, bn_y, bn_ldy, bn_mean, bn_invstd,
+                       bn_mscale, bn_mshift, bn_relu, bn_slab);
 }
 
 extern "C" int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, void* out, int ldo, void* stream) {

@@ -163,6 +163,10 @@ class Engine:
         self.fuse_bn_reduce = os.environ.get("DC_FUSE_BN_REDUCE", "1") != "0"   # BN backward sums taken in the consumer dw data-gradient kernel
         self.fuse_bn_into_dw = os.environ.get("DC_FUSE_BN_DW", "1") != "0"   # BN(+ReLU) applied in the consumer depthwise kernel's LDS tile
         self.mask_from_y = os.environ.get("DC_MASK_FROM_Y", "1") != "0"
+        # BatchNorm backward sums taken in the epilogue of the consuming dense conv's data gradient (dc_conv_dgrad_bnstats /
+        # dc_head_bwd_bnstats) instead of a dc_bn_bwd_reduce pass over the gradient and the BatchNorm input
+        self.fuse_bn_conv = os.environ.get("DC_FUSE_BN_CONV", "1") != "0"
+        self.fuse_bn_head = os.environ.get("DC_FUSE_BN_HEAD", "1") != "0"
         # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
         # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 41.23 -> 41.28 -- the fp32 split slabs
         # (256 KiB per workgroup whatever the batch) are a third of a 728-channel weight gradient's time at batch 2.
@@ -327,9 +331,11 @@ class Engine:
     # ------------------------------------------------------------------------------------------------ op builders
     def _conv(self, x: Act, wname: str, cout: int, k: int = 1, stride: int = 1, pad: int = 0, dil: int = 1,
               transposed: bool = False, out: Act = None, stats: bool = True, bias: str = None, name: str = None,
-              need_dx: bool = True, f32: bool = False, fwd_group: list = None):
+              need_dx: bool = True, f32: bool = False, fwd_group: list = None, sole_consumer: bool = False):
         """Dense conv (implicit GEMM).  Returns (y, slab, rows).  fwd_group: a list that collects (dilation, wf, y, slab) instead
-        of this layer's own forward launch (the caller then launches the members together: _dilated_group_fwd)."""
+        of this layer's own forward launch (the caller then launches the members together: _dilated_group_fwd).
+        sole_consumer: x is a stored BatchNorm(+ReLU) output that feeds this conv and nothing else; its BatchNorm's backward sums
+        are then taken in this layer's data-gradient epilogue (dc_conv_dgrad_bnstats) instead of a pass of their own."""
         lib = L.load()
         dt, tdtype = (L.DC_F32, torch.float32) if f32 else (self.dt, self.dtype)
         d = L.ConvDesc(dt, 3 if transposed else k, stride, pad, dil, 1 if transposed else 0, x.C, cout)
@@ -377,6 +383,12 @@ class Engine:
 
             # Weight gradients of consecutive layers of ONE geometry (the 728 -> 728 pointwise convs of the middle flow) are
             # deferred and launched together (dc_conv_wgrad_group): _group_wgrads() fixes the roles once the program is resolved.
+            bsrc = getattr(x, "bn_src", None) if (sole_consumer and need_dx and self.fuse_bn_conv and not self.shift_side) else None
+            srows = lib.dc_conv_dgrad_bnstats_rows(C.byref(d), N, H, W) if (bsrc is not None and mode == 0 and x.parent is None) else 0
+            if srows > 0:
+                sslab = self._f32(2 * srows * x.C)
+                x.fused_bwd = (sslab, srows)       # read by the BatchNorm's make_bwd, which runs after this one
+                by = bsrc["y"]
             rec = {"key": (dt, d.k, stride, pad, dil, d.transposed, x.C, cout, N, H, W, x.ld, dy.ld), "d": d, "x": x, "dy": dy,
                    "gw": gw, "wname": wname, "ready": ready, "role": "solo", "group": None, "bias": bool(bias)}
             self._wg_recs.append(rec)
@@ -403,7 +415,11 @@ class Engine:
                     wgrad()
                     return
                 wgrad()
-                if need_dx:
+                if need_dx and srows > 0:
+                    L.call("dc_conv_dgrad_bnstats", C.byref(d), N, H, W, dy.ptr, dy.ld, L.dptr(wb), dx.ptr, dx.ld, by.ptr, by.ld,
+                           L.dptr(bsrc["mean"]), L.dptr(bsrc["invstd"]), L.dptr(bsrc["scale"]), L.dptr(bsrc["shift"]), bsrc["relu"],
+                           L.dptr(sslab), self._st())
+                elif need_dx:
                     L.call("dc_conv_dgrad", C.byref(d), N, H, W, dy.ptr, dy.ld, L.dptr(wb), dx.ptr, dx.ld, mode, self._st())
             return bwd, ready
 
@@ -526,6 +542,11 @@ class Engine:
         lz = LazyAct(y, scale, shift, relu, (name or bname) + ".lazy") if lazy else None
         if lz is not None:
             lz.mean, lz.invstd, lz.fused_bwd = mean, invstd, None
+        elif residual is None and out is None and (self.mask_from_y or not relu):
+            # a stored BatchNorm(+ReLU) output whose ReLU mask is recomputed from y: a sole dense-conv consumer may take this
+            # BatchNorm's backward sums in its data-gradient epilogue (_conv(..., sole_consumer=True), the classifier head)
+            o.bn_src = {"y": y, "scale": scale, "shift": shift, "mean": mean, "invstd": invstd, "relu": relu_i}
+            o.fused_bwd = None
 
         self.fwd_train.append(fwd_train)
         self.fwd_eval.append(fwd_eval)
@@ -548,7 +569,8 @@ class Engine:
             optr = (lambda: None) if from_y else (lambda: o.ptr)
             old_ = 0 if from_y else o.ld
 
-            fused = lz.fused_bwd if lazy else None      # set by the consumer depthwise conv (its make_bwd ran before this one)
+            # set by the consumer (a depthwise conv for a lazy output, a dense conv / the head for a stored one): its make_bwd ran first
+            fused = lz.fused_bwd if lazy else getattr(o, "fused_bwd", None)
             rslab, rrows = (fused[0], fused[1]) if fused is not None else (bslab, brows)
 
             def bwd():
@@ -737,15 +759,15 @@ class Engine:
         yl, slab, rows = self._conv(low, "conv2.weight", 48, name="lowproj")
         self._bn(yl, slab, rows, "bn2", True, out=cat2.slice("low48", 256, 48))
         U = "upsample."
-        y, slab, rows = self._conv(p, U + "deconv1.0.weight", 256, transposed=True, name="deconv1")
+        y, slab, rows = self._conv(p, U + "deconv1.0.weight", 256, transposed=True, name="deconv1", sole_consumer=True)
         a = self._bn(y, slab, rows, U + "deconv1.1", True)
-        y, slab, rows = self._conv(a, U + "deconv2.0.weight", 256, transposed=True, name="deconv2")
+        y, slab, rows = self._conv(a, U + "deconv2.0.weight", 256, transposed=True, name="deconv2", sole_consumer=True)
         self._bn(y, slab, rows, U + "deconv2.1", True, out=cat2.slice("up256", 0, 256))
         y, slab, rows = self._conv(cat2, U + "conv1.0.weight", 256, k=3, pad=1, name="dec.conv0")
         a = self._bn(y, slab, rows, U + "conv1.1", True)
-        y, slab, rows = self._conv(a, U + "conv1.3.weight", 256, k=3, pad=1, name="dec.conv3")
+        y, slab, rows = self._conv(a, U + "conv1.3.weight", 256, k=3, pad=1, name="dec.conv3", sole_consumer=True)
         a = self._bn(y, slab, rows, U + "conv1.4", True)
-        y, _, _ = self._conv(a, U + "conv1.6.weight", 256, stats=False, bias=U + "conv1.6.bias", name="dec.conv6")
+        y, _, _ = self._conv(a, U + "conv1.6.weight", 256, stats=False, bias=U + "conv1.6.bias", name="dec.conv6", sole_consumer=True)
         y, slab, rows = self._conv(y, U + "deconv3.0.weight", 256, transposed=True, name="deconv3")
         a = self._bn(y, slab, rows, U + "deconv3.1", True)
 
@@ -765,8 +787,19 @@ class Engine:
         def head_bwd_make():
             assert a.take_grad_mode() == 0
             da = a.grad
+            bsrc = getattr(a, "bn_src", None) if self.fuse_bn_head else None
+            if bsrc is not None:
+                srows = (a.M + 127) // 128
+                sslab = self._f32(2 * srows * 256)
+                a.fused_bwd = (sslab, srows)
+                by = bsrc["y"]
 
             def bwd():
+                if bsrc is not None:
+                    L.call("dc_head_bwd_bnstats", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, L.dptr(self.dlogits), self.pptr(wl), da.ptr, da.ld,
+                           self.gptr(wl), hptr, by.ptr, by.ld, L.dptr(bsrc["mean"]), L.dptr(bsrc["invstd"]), L.dptr(bsrc["scale"]),
+                           L.dptr(bsrc["shift"]), bsrc["relu"], L.dptr(sslab), self._st())
+                    return
                 L.call("dc_head_bwd", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, L.dptr(self.dlogits), self.pptr(wl), da.ptr, da.ld,
                        self.gptr(wl), hptr, self._st())
             return bwd, [wl]

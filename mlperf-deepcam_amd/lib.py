@@ -48,6 +48,8 @@ _SIGS = {
     "dc_conv_fwd_f32out": (I, [CD, I, I, I, P, I, P, P, I, P]),
     "dc_conv_fwd_dilated_group": (I, [CD, I, I, I, I, P, P, I, P, P, I, P, P]),
     "dc_conv_dgrad": (I, [CD, I, I, I, P, I, P, P, I, I, P]),
+    "dc_conv_dgrad_bnstats_rows": (I, [CD, I, I, I]),
+    "dc_conv_dgrad_bnstats": (I, [CD, I, I, I, P, I, P, P, I, P, I, P, P, P, P, I, P, P]),
     "dc_conv_wgrad_workspace": (SZ, [CD, I, I, I]),
     "dc_conv_wgrad": (I, [CD, I, I, I, P, I, P, I, P, SZ, P, P]),
     "dc_conv_wgrad_group_workspace": (SZ, [CD, I, I, I, I]),
@@ -76,6 +78,7 @@ _SIGS = {
     "dc_head_workspace": (SZ, [I, I, I, I, I]),
     "dc_head_fwd": (I, [I, I, I, I, I, P, I, P, P, P, P]),
     "dc_head_bwd": (I, [I, I, I, I, I, P, I, P, P, P, I, P, P, P]),
+    "dc_head_bwd_bnstats": (I, [I, I, I, I, I, P, I, P, P, P, I, P, P, P, I, P, P, P, P, I, P, P]),
     "dc_nchw_to_nhwc": (I, [I, I, I, I, I, P, P, I, P]),
     "dc_input_normalize_hwc": (I, [I, L, I, I, P, P, P, P, P, I, P]),
     "dc_input_normalize_hwc_to_nchw": (I, [I, L, I, I, P, P, P, P, P, P]),

@@ -28,6 +28,8 @@ NBUF, REPS = 4, 40
 lib = L.load()
 if os.environ.get("DW_TPB"):
     L.call("dc_set_option", b"dw_wgrad_tpb", int(os.environ["DW_TPB"]))
+if os.environ.get("DW_CG"):
+    L.call("dc_set_option", b"dw_cg", int(os.environ["DW_CG"]))
 if os.environ.get("BN_CGW"):
     L.call("dc_set_option", b"bn_cgw", int(os.environ["BN_CGW"]))
 if os.environ.get("BN_ROWS"):

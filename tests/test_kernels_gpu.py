@@ -187,6 +187,72 @@ def test_conv_pointwise_384_tile_kernel_same_bits(shape):
         np.testing.assert_allclose(got[0][2].numpy(), other[2].numpy(), rtol=2e-5, atol=1e-4)
 
 
+BNSTAT_CASES = [
+    # name, k, stride, pad, dil, transposed, cin, cout, N, H, W
+    ("dense3x3", 3, 1, 1, 1, 0, 256, 256, 2, 12, 20),
+    ("convT", 3, 2, 1, 1, 1, 256, 256, 2, 9, 7),
+    ("pw_bias_layer", 1, 1, 0, 1, 0, 256, 256, 2, 19, 13),
+    ("head_like_k32", 1, 1, 0, 1, 0, 256, 32, 2, 24, 36),
+    ("ragged_c", 3, 1, 1, 1, 0, 72, 40, 1, 11, 9),
+]
+
+
+@pytest.mark.parametrize("relu", [1, 0])
+@pytest.mark.parametrize("tile", [0, 2], ids=["tile128", "tile256"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", BNSTAT_CASES, ids=[c[0] for c in BNSTAT_CASES])
+def test_conv_dgrad_with_fused_bn_backward_statistics(case, dtype, tile, relu):
+    """dc_conv_dgrad_bnstats = dc_conv_dgrad followed by dc_bn_bwd_reduce (mask recomputed from y): same dx bits, the same
+    per-channel sums (sum g, sum g*xhat) up to the order of the additions."""
+    name, k, stride, pad, dil, tr, cin, cout, N, H, W = case
+    if dtype == torch.float32 and tile == 2:
+        pytest.skip("the 256-tile kernel is bf16 only")
+    d = desc(dtype, k, stride, pad, dil, tr, cin, cout)
+    kk = 3 if tr else k
+    wshape = (cin, cout, kk, kk) if tr else (cout, cin, kk, kk)
+    w = rnd(*wshape, seed=2, scale=(cout * kk * kk) ** -0.5)
+    Ho, Wo = C.c_int(), C.c_int()
+    L.call("dc_conv_out_hw", C.byref(d), H, W, C.byref(Ho), C.byref(Wo))
+    Ho, Wo = Ho.value, Wo.value
+    gy = q(rnd(N, cout, Ho, Wo, seed=3), dtype)
+    ybn = q(rnd(N, cin, H, W, seed=5), dtype)                # the BatchNorm's INPUT, same shape as dx
+    mean, invstd = rnd(cin, seed=6, scale=0.3).to(dev()), (rnd(cin, seed=7).abs() + 0.5).to(dev())
+    mscale, mshift = rnd(cin, seed=8).to(dev()), rnd(cin, seed=9, scale=0.5).to(dev())
+    nwf, nwb = C.c_size_t(), C.c_size_t()
+    L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
+    wf = torch.empty(nwf.value, dtype=dtype, device=dev())
+    wb = torch.empty(nwb.value, dtype=dtype, device=dev())
+    L.call("dc_conv_pack_weights", C.byref(d), vptr(w.to(dev())), vptr(wf), vptr(wb), S())
+    _, gyv = to_nhwc(gy, dtype)
+    _, ybv = to_nhwc(ybn, dtype, ld=cin + 16, off=8)
+    M = N * H * W
+    try:
+        L.call("dc_set_option", b"igemm256", tile)
+        _, dx_ref = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
+        L.call("dc_conv_dgrad", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(dx_ref), cin + 8, 0, S())
+        rrows = L.load().dc_bn_stat_rows(M)
+        rslab = torch.zeros(2, rrows, cin, device=dev())
+        L.call("dc_bn_bwd_reduce", L.dtype_code(dtype), M, cin, vptr(dx_ref), cin + 8, vptr(ybv), cin + 16, None, 0, 2 if relu else 0,
+               vptr(mean), vptr(invstd), vptr(rslab), vptr(mscale), vptr(mshift), S())
+        rows = L.load().dc_conv_dgrad_bnstats_rows(C.byref(d), N, H, W)
+        assert rows > 0
+        slab = torch.full((2, rows, cin), float("nan"), device=dev())
+        _, dx = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
+        L.call("dc_conv_dgrad_bnstats", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(dx), cin + 8, vptr(ybv), cin + 16,
+               vptr(mean), vptr(invstd), vptr(mscale), vptr(mshift), relu, vptr(slab), S())
+        torch.cuda.synchronize()
+    finally:
+        L.call("dc_set_option", b"igemm256", 1)
+    assert torch.equal(from_nhwc(dx), from_nhwc(dx_ref))
+    assert not torch.isnan(slab).any()
+    got, ref = slab.double().sum(1).cpu(), rslab.double().sum(1).cpu()
+    scale = ref.abs().max().item() + 1e-12
+    assert (got - ref).abs().max().item() <= 2e-5 * scale + 1e-6, ((got - ref).abs().max().item(), scale)
+    with pytest.raises(L.DeepcamHipError):      # statistics and accumulate do not go together; neither does a missing slab
+        L.call("dc_conv_dgrad_bnstats", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(dx), cin + 8, vptr(ybv), cin + 16,
+               vptr(mean), vptr(invstd), vptr(mscale), vptr(mshift), relu, None, S())
+
+
 def conv_ref(x, w, bias, k, stride, pad, dil, transposed):
     if transposed:
         return F.conv_transpose2d(x, w, bias, 2, 1, 1)
@@ -840,6 +906,26 @@ def test_head(dtype):
     torch.cuda.synchronize()
     assert_close(from_nhwc(gxv), gx_ref, dtype, bf16=1.5e-2)
     assert_close(gw.cpu(), gw_ref, dtype, f32=2e-4, bf16=1e-2)
+    # the same call with the BatchNorm-backward sums of the layer in front of the head taken in the data gradient's epilogue
+    M = N * H * W
+    ybn = q(rnd(N, Cin, H, W, seed=5), dtype)
+    _, ybv = to_nhwc(ybn, dtype)
+    mean, invstd = rnd(Cin, seed=6, scale=0.3).to(dev()), (rnd(Cin, seed=7).abs() + 0.5).to(dev())
+    mscale, mshift = rnd(Cin, seed=8).to(dev()), rnd(Cin, seed=9, scale=0.5).to(dev())
+    rows = (M + 127) // 128
+    slab = torch.full((2, rows, Cin), float("nan"), device=dev())
+    _, gxv2 = empty_nhwc(N, H, W, Cin, dtype)
+    gw2 = torch.full((Cin, 3, 3, 3), float("nan"), device=dev())
+    L.call("dc_head_bwd_bnstats", dt, N, Cin, H, W, vptr(xv), Cin + 8, vptr(gld), vptr(wd), vptr(gxv2), Cin, vptr(gw2), wsp, vptr(ybv), Cin,
+           vptr(mean), vptr(invstd), vptr(mscale), vptr(mshift), 1, vptr(slab), S())
+    rrows = L.load().dc_bn_stat_rows(M)
+    rslab = torch.zeros(2, rrows, Cin, device=dev())
+    L.call("dc_bn_bwd_reduce", dt, M, Cin, vptr(gxv), Cin, vptr(ybv), Cin, None, 0, 2, vptr(mean), vptr(invstd), vptr(rslab), vptr(mscale),
+           vptr(mshift), S())
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(gxv2), from_nhwc(gxv)) and torch.equal(gw2, gw)
+    got, ref2 = slab.double().sum(1).cpu(), rslab.double().sum(1).cpu()
+    assert (got - ref2).abs().max().item() <= 2e-5 * (ref2.abs().max().item() + 1e-12) + 1e-6
 
 
 @pytest.mark.parametrize("shape", [(2, 20, 70), (1, 9, 229), (1, 8, 32)], ids=["3x3tiles", "8tiles_wide", "one_exact_tile"])
