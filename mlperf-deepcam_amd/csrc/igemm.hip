@@ -542,6 +542,7 @@ static int pw384_plan(const IgemmParams& p) {
   if (g_pw384 == 0 || !pw384_eligible(p)) return 0;
   if (g_pw384 == 2) return 8;
   if (g_pw384 == 3) return 4;
+  if (g_pw384 == 4) return 64;      // 256 x 384 tiles, 64-deep stages of 128-byte rows
   const long t128 = (long)cdiv(p.g.Cout, BN) * p.mtiles, t256 = igemm256_tiles(p);
   const double c_old = (double)(cdiv(t256, 256) < cdiv(t128, 768) ? cdiv(t256, 256) : cdiv(t128, 768));
   if (p.g.Cout * 10 < (long)cdiv(p.g.Cout, 384) * 384 * 9) return 0;      // a 384-wide tile that is more than a tenth empty loses

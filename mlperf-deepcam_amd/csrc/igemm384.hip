@@ -87,22 +87,30 @@ __device__ inline void static_for(F&& f) {
   }
 }
 
-template <int GP>      // pixel groups: 4 (256 x 384 tile) or 2 (128 x 384)
+// GP: pixel groups, 4 (256 x 384 tile) or 2 (128 x 384).  K64: 128-byte K rows (whole L2 lines per LDS-DMA row piece, 8 rows per
+// wave-instruction) in a ring of TWO 64-deep stages, against 64-byte rows in a ring of three 32-deep stages.
+template <int GP, bool K64>
 struct Cfg {
   static constexpr int GC = 8 / GP;                       // channel groups
   static constexpr int NCB = TN / 16 / GC;                // channel blocks per wave: 12 / 6
   static constexpr int TM = GP * NPB * 16;                // pixels per workgroup: 256 / 128
-  static constexpr int STAGE = (TN + TM) * ROWB;          // 40 / 32 KiB
-  static constexpr int NI = (TN + TM) / 16;               // LDS-DMA instructions per stage
-  static constexpr int IPW = NI / 8;                      // per wave: 5 / 4
-  static constexpr int LATE = NCB - 1 - IPW;              // first block in which waves 4..7 issue theirs (the last block waits)
-  static constexpr int RING = NST * STAGE;
-  static_assert(NI % 8 == 0 && IPW <= NCB - 1, "instruction split");
+  static constexpr int RB = K64 ? 128 : 64;               // bytes of K per row and stage
+  static constexpr int NSTG = K64 ? 2 : NST;              // ring stages
+  static constexpr int STAGE = (TN + TM) * RB;            // 40 / 32 KiB (80 KiB: K64)
+  static constexpr int NI = STAGE / 1024;                 // LDS-DMA instructions per stage
+  static constexpr int IPW = NI / 8;                      // per wave: 5 / 4 (10: K64)
+  // first block in which waves 4..7 issue theirs (the last block waits)
+  static constexpr int LATE = K64 ? NCB - IPW : NCB - 1 - IPW;
+  static constexpr int RING = NSTG * STAGE;
+  static constexpr int BLK = 16 * RB;                     // bytes between the fragments of consecutive 16-row blocks
+  static_assert(NI % 8 == 0 && IPW <= NCB - 1 && LATE >= 0 && RING <= 160 * 1024, "instruction split");
 };
 
-template <int GP>
+template <int GP, bool K64>
 __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
-  typedef Cfg<GP> K;
+  typedef Cfg<GP, K64> K;
+  constexpr int KS = K64 ? 64 : 32;          // K elements per stage
+  constexpr int BLK = K::BLK;
   constexpr int NCB = K::NCB, GC = K::GC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GatherGeom& g = p.g;
@@ -125,21 +133,24 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + xslot;
   const int n0 = (tile % ntn) * TN, m0 = (tile / ntn) * K::TM;
-  const int kchunks = (g.Cin + BK - 1) / BK;
+  const int kchunks = (g.Cin + KS - 1) / KS;     // stages
 
   // ---- LDS-DMA bookkeeping.  Instruction i of this wave fills rows (8i + wave)*16 .. +15 of the stage image: rows [0, 384) are
   // weight rows (channels n0 ..), rows [384, 384 + TM) pixel rows (m0 ..).  A lane's source is its operand row or the zero page
   // (K tail, rows past Cout / M, stages past the last one): a select on the address, never a branch.
-  const int lrow = lane >> 2, pslot = lane & 3;
-  const int lslot = pslot ^ ((lrow >> 1) & 3);          // logical 16-byte slot this lane fetches (swizzle on the source side)
+  // (K64: 8 rows of 128 bytes per instruction, slot swizzle pslot ^ ((row >> 1) & 7); the row's parity-of-chunk term is wave & 1)
+  const int lrow = K64 ? lane >> 3 : lane >> 2, pslot = K64 ? lane & 7 : lane & 3;
+  const int lslot = K64 ? pslot ^ ((((wave & 1) << 2) + (lrow >> 1)) & 7)
+                        : pslot ^ ((lrow >> 1) & 3);          // logical 16-byte slot this lane fetches (swizzle on the source side)
+  constexpr int RPI = K64 ? 8 : 16;                           // rows per instruction
   const uintptr_t zp = (uintptr_t)p.zero_page;
   const bf16* __restrict__ xg = reinterpret_cast<const bf16*>(p.x);
   const bf16* __restrict__ wg = reinterpret_cast<const bf16*>(p.w);
   uintptr_t src[K::IPW];
 #pragma unroll
   for (int i = 0; i < K::IPW; ++i) {
-    const int r = (8 * i + wave) * 16 + lrow;
-    if (r < TN) {          // wave-uniform per instruction: 16-row groups never straddle the operand boundary
+    const int r = (8 * i + wave) * RPI + lrow;
+    if (r < TN) {          // wave-uniform per instruction: row groups never straddle the operand boundary
       const int ch = n0 + r;
       src[i] = ch < g.Cout ? (uintptr_t)(wg + (size_t)ch * p.ldw + lslot * 8) : 0;
     } else {
@@ -148,10 +159,10 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
     }
   }
   auto issue = [&](int i, int stage) {
-    const int kofs = stage * BK;
+    const int kofs = stage * KS;
     const bool ok = (src[i] != 0) & (kofs + lslot * 8 < g.Cin);          // stage >= kchunks fails the K test: zero page
     const uintptr_t a = ok ? src[i] + (uintptr_t)kofs * 2 : zp;
-    if constexpr (!(probe & 1)) __builtin_amdgcn_global_load_lds((gas_ptr)a, (lds_ptr)(smem + (stage % NST) * K::STAGE + (8 * i + wave) * 1024), 16, 0, 0);
+    if constexpr (!(probe & 1)) __builtin_amdgcn_global_load_lds((gas_ptr)a, (lds_ptr)(smem + (stage % K::NSTG) * K::STAGE + (8 * i + wave) * 1024), 16, 0, 0);
   };
 
   f32x4 acc[NCB][NPB];   // [channel block][pixel block]
@@ -160,49 +171,42 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < NPB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fg = lane >> 4;
-  const int a_off = swz64(wc * (NCB * 16) + fr, fg);                  // weight fragment of channel block 0; block i: + i * 1024
-  const int b_off = TN * ROWB + swz64(grp * (NPB * 16) + fr, fg);     // pixel fragment of pixel block 0; block j: + j * 1024
-  // (16 rows of 64 bytes = 1024: the swizzle term depends on (row >> 1) & 3, which is the same for row and row + 16)
-
-  // ---- prologue: stages 0 and 1 in flight, stage 0 landed, first fragments requested ---------------------------------------
-#pragma unroll
-  for (int q = 0; q < NST - 1; ++q)
-#pragma unroll
-    for (int i = 0; i < K::IPW; ++i) issue(i, q);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * K::IPW) : "memory");
-  __builtin_amdgcn_s_barrier();
+  // fragment of block 0 (block i: + i * BLK; the swizzle term depends on (row >> 1) & 3 or & 7, the same for row and row + 16).
+  // K64: the fragment of K half h sits at logical slot 4h + fg, physical slot (4h + fg) ^ ((row >> 1) & 7): half 1 = half 0 ^ 64 bytes.
+  const int a_off = K64 ? (wc * (NCB * 16) + fr) * 128 + ((fg ^ ((fr >> 1) & 7)) << 4) : swz64(wc * (NCB * 16) + fr, fg);
+  const int b_off = TN * K::RB + (K64 ? (grp * (NPB * 16) + fr) * 128 + ((fg ^ ((fr >> 1) & 7)) << 4) : swz64(grp * (NPB * 16) + fr, fg));
   // LDS byte addresses (the kernel's only LDS object is the dynamic array, so its address-space-3 pointer is the offset)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem;
   // Weight fragments are requested TWO channel blocks ahead (a block is only 4 MFMAs, 64 cycles of this wave: one block of distance
   // left every block waiting on its ds_read: 2 700 cycles per step); fa[i % 3] holds block i (NCB is a multiple of 3).
   static_assert(NCB % 3 == 0, "fa ring");
   bf16x8 fa[3], fb[NPB];
-  lds_read16<0>(fa[0], lds0 + a_off);
-  lds_read16<1024>(fa[1], lds0 + a_off);
-  static_for<0, NPB>([&](auto jc) { lds_read16<decltype(jc)::value * 1024>(fb[decltype(jc)::value], lds0 + b_off); });
-  // outstanding LDS reads at the top of every step, oldest first: fa[0], fa[1], fb[0] .. fb[NPB-1]
 
-  for (int s = 0; s < kchunks; ++s) {
-    const uint32_t cur_a = lds0 + (s % NST) * K::STAGE + a_off;
-    const uint32_t nxt_a = lds0 + ((s + 1) % NST) * K::STAGE + a_off, nxt_b = lds0 + ((s + 1) % NST) * K::STAGE + b_off;
+  // One 32-deep step: the fragments come from cur_*; the last block requests the next step's fragments from nxt_*.  stage_end: the
+  // next step reads ANOTHER ring stage, so every wave first waits for its LDS-DMAs of that stage (VMW instructions may stay in flight)
+  // and all meet at a barrier.  dma: which stage to issue LDS-DMAs for during this step (-1: none).
+  auto step = [&](uint32_t cur_a, uint32_t nxt_a, uint32_t nxt_b, bool stage_end, int dma, auto vmw_tag) {
+    constexpr int VMW = decltype(vmw_tag)::value;
     static_for<0, NCB>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      if constexpr (i + 2 < NCB && !(probe & 2)) lds_read16<(i + 2) * 1024>(fa[(i + 2) % 3], cur_a);      // weight fragment two blocks ahead
-      // this step's LDS-DMAs (stage s+2): waves 0..3 in blocks 0 .. IPW-1, waves 4..7 in blocks LATE .. LATE+IPW-1 (all in front of
-      // the last block's wait)
+      if constexpr (i + 2 < NCB && !(probe & 2)) lds_read16<(i + 2) * BLK>(fa[(i + 2) % 3], cur_a);      // weight fragment two blocks ahead
+      // this step's LDS-DMAs: waves 0..3 in blocks 0 .. IPW-1, waves 4..7 in blocks LATE .. LATE+IPW-1
       if constexpr (i < K::IPW) {
-        if (!late) issue(i, s + NST - 1);
+        if (!late && dma >= 0) issue(i, dma);
       }
       if constexpr (i >= K::LATE && i < K::LATE + K::IPW) {
-        if (late) issue(i - K::LATE, s + NST - 1);
+        if (late && dma >= 0) issue(i - K::LATE, dma);
       }
       if constexpr (i == NCB - 1) {
-        // every read of stage s has landed in registers; stage s+1 (issued during step s-1) must have landed for every wave
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * K::IPW) : "memory");
-        __builtin_amdgcn_s_barrier();
+        if (stage_end) {
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VMW) : "memory");
+          __builtin_amdgcn_s_barrier();
+        } else {
+          lgkm_wait<0>();
+        }
         if constexpr (!(probe & 2)) {
           lds_read16<0>(fa[0], nxt_a);                                                    // next step's first two weight fragments
-          lds_read16<1024>(fa[1], nxt_a);
+          lds_read16<BLK>(fa[1], nxt_a);
         }
       }
       static_for<0, NPB>([&](auto jc) {
@@ -212,9 +216,43 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
         if constexpr (i == 0) lgkm_wait<NPB - j>();
         else if constexpr (j == 0 && i < NCB - 1) lgkm_wait<(NCB - 1 - i < 2 ? NCB - 1 - i : 2)>();
         mfma_v(acc[i][j], fa[i % 3], fb[j]);
-        if constexpr (i == NCB - 1 && !(probe & 2)) lds_read16<j * 1024>(fb[j], nxt_b);   // re-read in place for the next step
+        if constexpr (i == NCB - 1 && !(probe & 2)) lds_read16<j * BLK>(fb[j], nxt_b);    // re-read in place for the next step
       });
     });
+  };
+
+  if constexpr (!K64) {
+    // ---- prologue: stages 0 and 1 in flight, stage 0 landed, first fragments requested -------------------------------------
+#pragma unroll
+    for (int q = 0; q < NST - 1; ++q)
+#pragma unroll
+      for (int i = 0; i < K::IPW; ++i) issue(i, q);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * K::IPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    lds_read16<0>(fa[0], lds0 + a_off);
+    lds_read16<BLK>(fa[1], lds0 + a_off);
+    static_for<0, NPB>([&](auto jc) { lds_read16<decltype(jc)::value * BLK>(fb[decltype(jc)::value], lds0 + b_off); });
+    // outstanding LDS reads at the top of every step, oldest first: fa[0], fa[1], fb[0] .. fb[NPB-1]
+    for (int s = 0; s < kchunks; ++s) {
+      const uint32_t cur = lds0 + (s % NST) * K::STAGE, nxt = lds0 + ((s + 1) % NST) * K::STAGE;
+      // stage s+2 is issued during step s; stage s+1 (issued during step s-1) must have landed at the end of it
+      step(cur + a_off, nxt + a_off, nxt + b_off, true, s + NST - 1, std::integral_constant<int, (NST - 2) * K::IPW>{});
+    }
+  } else {
+    // ---- 64-deep stages, ring of two: stage s+1 is issued during the FIRST 32-deep half of stage s (its ring slot was released by the
+    // barrier that ended stage s-1) and lands during the second half; nothing else is in flight at the stage's end.
+#pragma unroll
+    for (int i = 0; i < K::IPW; ++i) issue(i, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    lds_read16<0>(fa[0], lds0 + a_off);
+    lds_read16<BLK>(fa[1], lds0 + a_off);
+    static_for<0, NPB>([&](auto jc) { lds_read16<decltype(jc)::value * BLK>(fb[decltype(jc)::value], lds0 + b_off); });
+    for (int s = 0; s < kchunks; ++s) {
+      const uint32_t cur = lds0 + (s & 1) * K::STAGE, nxt = lds0 + ((s + 1) & 1) * K::STAGE;
+      step(cur + a_off, cur + (a_off ^ 64), cur + (b_off ^ 64), false, s + 1, std::integral_constant<int, 0>{});
+      step(cur + (a_off ^ 64), nxt + a_off, nxt + b_off, true, -1, std::integral_constant<int, 0>{});
+    }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the zero-page fills of the last slots; the ring is reused below
   __builtin_amdgcn_s_barrier();
@@ -314,13 +352,21 @@ bool pw384_eligible(const IgemmParams& p) {
          g.Cin >= 2 * BK && g.Cin % 8 == 0 && g.Cout % 8 == 0;
 }
 
-// npb: 8 (256-pixel tiles) or 4 (128-pixel tiles): pixel blocks of 16 per 128-pixel half, the unit pw384_tiles() counts in
+// npb: 8 (256-pixel tiles) or 4 (128-pixel tiles): pixel blocks of 16 per 128-pixel half, the unit pw384_tiles() counts in;
+// 64: 256-pixel tiles with 64-deep stages of 128-byte rows
 int launch_pw384(const IgemmParams& p_in, int npb, hipStream_t st) {
   static const void* zero_dev = nullptr;
   static hipError_t init_err = hipSuccess;
+  typedef Cfg<4, false> C8;
+  typedef Cfg<2, false> C4;
+  typedef Cfg<4, true> C64;
+  auto k8 = &pw384_kernel<4, false>;
+  auto k4 = &pw384_kernel<2, false>;
+  auto k64 = &pw384_kernel<4, true>;
   DC_ONCE({
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw384_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<4>::RING);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw384_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<2>::RING);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, C8::RING);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, C4::RING);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k64), hipFuncAttributeMaxDynamicSharedMemorySize, C64::RING);
     void* zp = nullptr;
     init_err = hipGetSymbolAddress(&zp, HIP_SYMBOL(zero_page384));
     zero_dev = zp;
@@ -328,9 +374,10 @@ int launch_pw384(const IgemmParams& p_in, int npb, hipStream_t st) {
   if (init_err != hipSuccess) return dc_set_error(init_err, __FILE__, __LINE__);
   IgemmParams p = p_in;
   p.zero_page = zero_dev;
-  const long tiles = pw384_tiles(p, npb);
-  if (npb == 8) hipLaunchKernelGGL(pw384_kernel<4>, dim3((unsigned)tiles), dim3(512), Cfg<4>::RING, st, p);
-  else hipLaunchKernelGGL(pw384_kernel<2>, dim3((unsigned)tiles), dim3(512), Cfg<2>::RING, st, p);
+  const long tiles = pw384_tiles(p, npb == 64 ? 8 : npb);
+  if (npb == 64) hipLaunchKernelGGL(k64, dim3((unsigned)tiles), dim3(512), C64::RING, st, p);
+  else if (npb == 8) hipLaunchKernelGGL(k8, dim3((unsigned)tiles), dim3(512), C8::RING, st, p);
+  else hipLaunchKernelGGL(k4, dim3((unsigned)tiles), dim3(512), C4::RING, st, p);
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -9,10 +9,10 @@ as read; both counters are in KiB.
 """
 import csv, glob, json, os, sys
 
-FAMILIES = {"igemm": ("igemm_kernel", "igemm256_kernel", "tiny_gemm_kernel"),
+FAMILIES = {"igemm": ("igemm_kernel", "igemm256_kernel", "pw384_kernel", "tiny_gemm_kernel"),
             "wgrad": ("wgrad_dma_kernel", "wgrad256_kernel", "wgrad_kernel", "wgrad_reduce_kernel")}
 # launches of the C-ABI entry point = launches of the main kernel (the reduce kernel rides along with each wgrad call)
-MAIN = {"igemm": ("igemm_kernel", "igemm256_kernel", "tiny_gemm_kernel"), "wgrad": ("wgrad_dma_kernel", "wgrad256_kernel", "wgrad_kernel")}
+MAIN = {"igemm": ("igemm_kernel", "igemm256_kernel", "pw384_kernel", "tiny_gemm_kernel"), "wgrad": ("wgrad_dma_kernel", "wgrad256_kernel", "wgrad_kernel")}
 
 
 def collect(d, counter):

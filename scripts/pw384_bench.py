@@ -16,7 +16,7 @@ for (cin, cout, N, H, W) in shapes:
     wf = (torch.randn(cout * r32(cin), device=dev) * 0.05).to(dt)
     rows = lib.dc_conv_stat_rows(C.byref(desc), N, H, W)
     outs, res = [], []
-    for mode in (0, 2, 3):
+    for mode in (0, 2, 3, 4):
         L.call("dc_set_option", b"pw384", mode)
         y = torch.zeros(N, H, W, r32(cout), device=dev, dtype=dt); slab = torch.zeros(2 * rows * cout, device=dev)
         once = lambda: L.call("dc_conv_fwd", C.byref(desc), N, H, W, L.dptr(x), r32(cin), L.dptr(wf), None, L.dptr(y), r32(cout), L.dptr(slab), 0, L.stream_ptr())
@@ -31,5 +31,5 @@ for (cin, cout, N, H, W) in shapes:
         outs.append((y[..., :cout].clone(), slab.clone()))
     eq = [torch.equal(outs[0][0], o[0]) for o in outs[1:]]
     ds = [(outs[0][1] - o[1]).abs().max().item() / (outs[0][1].abs().max().item() + 1e-30) for o in outs[1:]]
-    print(f"{cin:4d}->{cout:4d} M={N*H*W:7d}: planner(old) {res[0]} | 256x384 {res[1]} | 128x384 {res[2]} | y bit-equal {eq}, slab rel diff {ds[0]:.1e} {ds[1]:.1e}", flush=True)
+    print(f"{cin:4d}->{cout:4d} M={N*H*W:7d}: planner(old) {res[0]} | 256x384 {res[1]} | 128x384 {res[2]} | 256x384 K64 {res[3]} | y bit-equal {eq}, slab rel diff {max(ds):.1e}", flush=True)
 L.call("dc_set_option", b"pw384", 1)

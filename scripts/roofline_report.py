@@ -34,6 +34,9 @@ def key_of(name):
     return k[:64]
 
 
+SHAPES = defaultdict(lambda: defaultdict(float))      # (kernel, workgroups) -> counter sums, time, dispatches: a launch shape = a layer geometry
+
+
 def read(d, counters):
     acc = defaultdict(lambda: defaultdict(float)); t = defaultdict(float); n = defaultdict(int); seen = set()
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -42,6 +45,14 @@ def read(d, counters):
                 continue
             k = key_of(r["Kernel_Name"])
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if any(f in k for f in ("igemm", "pw384", "wgrad256", "wgrad_dma")):
+                sk = (k, int(r["Grid_Size"]) // max(int(r.get("Workgroup_Size", 0) or 0), 1))
+                SHAPES[sk][r["Counter_Name"]] += float(r["Counter_Value"])
+                if (r["Dispatch_Id"], r["Counter_Name"]) not in seen and r["Counter_Name"] in ("FETCH_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
+                    seen.add((r["Dispatch_Id"], r["Counter_Name"]))
+                    if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                        SHAPES[sk]["n"] += 1
+                        SHAPES[sk]["t"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
             if r["Dispatch_Id"] not in seen:
                 seen.add(r["Dispatch_Id"]); n[k] += 1
                 t[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
@@ -79,6 +90,27 @@ for r in rows:
         pct = 100.0 * r["frac_b"]
     out.append(f"| `{r['k']}` | {r['n']} | {100 * r['ms'] / tot:.1f} % | {r['gb']:.1f} | {r['gbs']:.0f} | {100 * r['frac_b']:.0f} % | "
                f"{r['tf']:.0f} | {r['ai']:.0f} | {roof} | {pct:.0f} % | {r['util']:.0f} % |")
+steps = max(n.get(k, 0) for k in n if "pack_all" in k) if any("pack_all" in k for k in n) else 1
+tot_gb = sum(r["gb"] for r in rows)
+out.append("")
+out.append(f"**Fabric-side traffic of the whole step: {tot_gb / steps:.1f} GB per step = {tot_gb / steps / 8:.2f} GB per sample** "
+           f"({steps} profiled steps of local batch 8; MFMA kernels {sum(r['gb'] for r in rows if r['tf'] > 0) / steps:.1f} GB, the others "
+           f"{sum(r['gb'] for r in rows if r['tf'] <= 0) / steps:.1f} GB).  At the 6.29 TB/s a copy reaches that alone is "
+           f"{tot_gb / steps / 6.29:.1f} ms per step.")
+out.append("")
+out.append("Implicit-GEMM and weight-gradient launches by launch shape (kernel x workgroups = one layer geometry), largest fabric traffic first:")
+out.append("")
+out.append("| kernel | workgroups | launches per step | us per launch | MB per launch (fabric side) | MFMA util |")
+out.append("|---|---|---|---|---|---|")
+shp = []
+for (k, wgs), v in SHAPES.items():
+    if v["n"] <= 0:
+        continue
+    mb = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / 1e6 / v["n"]
+    act = v["GRBM_GUI_ACTIVE"] / 8.0
+    shp.append((mb * v["n"], k, wgs, v["n"] / steps, v["t"] / v["n"] * 1e6, mb, 100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (act * 1024.0) if act > 0 else 0.0))
+for _, k, wgs, per, us, mb, util in sorted(shp, reverse=True)[:28]:
+    out.append(f"| `{k}` | {wgs} | {per:.1f} | {us:.1f} | {mb:.1f} | {util:.0f} % |")
 text = "\n".join(out)
 print(text)
 if len(sys.argv) > 2:
