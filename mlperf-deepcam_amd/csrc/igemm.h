@@ -51,6 +51,7 @@ struct IgemmParams {
 int launch_igemm256(const IgemmParams& p, hipStream_t st);
 void igemm256_set_epilogue(int v);
 void igemm256_set_phase_fast(int v);
+void igemm256_set_tile2d(int v);
 // workgroups the 256-tile kernel would launch for this problem
 inline long igemm256_tiles(const IgemmParams& p) {
   return (long)((p.g.Cout + 255) / 256) * ((p.M - p.m_beg + 255) / 256) * p.g.os * p.g.os * (p.ngroup > 1 ? p.ngroup : 1);

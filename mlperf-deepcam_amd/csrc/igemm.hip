@@ -623,7 +623,8 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
       const long ntn = cdiv(p.g.Cout, 256), phases = (long)p.g.os * p.g.os;
       const long t256 = igemm256_tiles(p);
       const long full = t256 / g_mix_cus, tail = t256 % g_mix_cus;
-      if (g_igemm_mix && full >= 1 && tail > 0 && tail * 100 <= (long)g_mix_cus * g_mix_tail_pct) {
+      // (single-tap layers only: the two kernels add the taps of a multi-tap layer in different orders, so a cut would show in the bits)
+      if (g_igemm_mix && p.g.ntaps == 1 && full >= 1 && tail > 0 && tail * 100 <= (long)g_mix_cus * g_mix_tail_pct) {
         const long rows_a = full * g_mix_cus / (ntn * phases);          // 256-pixel row tiles that fit the whole rounds
         const long m_cut = rows_a * 256;
         const long small = (long)cdiv(p.g.Cout, BN) * cdiv(M - m_cut, BM) * phases;
@@ -885,6 +886,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   }
   if (name != nullptr && strcmp(name, "igemm256") == 0) { g_igemm256 = value; return 0; }
   if (name != nullptr && strcmp(name, "pw384") == 0) { g_pw384 = value; return 0; }
+  if (name != nullptr && strcmp(name, "igemm256_tile2d") == 0) { igemm256_set_tile2d(value); return 0; }
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm_mix") == 0) { g_igemm_mix = value != 0; return 0; }

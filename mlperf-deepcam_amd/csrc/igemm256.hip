@@ -136,9 +136,8 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
     const int m = m0 + (8 * j + wave) * 16 + lrow;
     rok[j] = m < p.M;
     const int mm = rok[j] ? m : 0;
-    const int n = fast_div(mm, g.div_hw);
-    const int rem = mm - n * (g.Qh * g.Qw);
-    const int qy = fast_div(rem, g.div_w), qx = rem - qy * g.Qw;
+    int n, qy, qx;
+    grid_pixel(g, mm, n, qy, qx);
     rown[j] = n * g.Hin;
     riy[j] = qy * g.is;
     rix[j] = qx * g.is;
@@ -199,10 +198,23 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
 
   // ---- prologue: stages 0..2 in flight, stage 0 landed ---------------------------------------------------------------
   int itap = 0, ikc = 0;   // (tap, K chunk) of the next stage to issue
+  // K order: groups of KG channel chunks OUTER, taps in the middle, the group's chunks inner.  With the taps outermost, a workgroup
+  // swept its 256 pixels x ALL channels once per tap; the CUs of an XCD together pull more than its 4 MiB L2 through per sweep, so
+  // each of the 9 taps of a 3 x 3 layer fetched the (shifted) input again from the fabric: 3.5 x the tensor on the 192 x 288 decoder
+  // convolutions, 7 x on the atrous ASPP ones (FETCH_SIZE per launch, scripts/fetch_by_grid.py).  Taps innermost (every step another
+  // tap) brings that down to 1.0-1.3 x but recomputes the per-tap row pointers and bounds every step: 9-24 % slower.  Groups of four
+  // chunks (256 bytes per pixel; ~2.6 MB per XCD and tap sweep) keep the nine sweeps of a group in L2 and change tap every 4th step.
+  constexpr int KG = 4;
+  int kbeg = 0, kend = kchunks < KG ? kchunks : KG;
   auto advance = [&]() {
-    if (++ikc == kchunks) {
-      ikc = 0;
-      ++itap;
+    if (++ikc == kend) {
+      ikc = kbeg;
+      if (++itap == ntap) {
+        itap = 0;
+        kbeg = kend;
+        kend = kend + KG < kchunks ? kend + KG : kchunks;
+        ikc = kbeg;
+      }
     }
   };
 #pragma unroll
@@ -332,11 +344,10 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
       const int m = m0 + grp * 128 + j * 16 + fr;
       pok[j] = m < p.M;
       opix[j] = (size_t)m;
-      if (g.os != 1) {
+      if (g.os != 1 || g.tile2d) {
         const int mm = pok[j] ? m : 0;
-        const int n = fast_div(mm, g.div_hw);
-        const int rem = mm - n * (g.Qh * g.Qw);
-        const int qy = fast_div(rem, g.div_w), qx = rem - qy * g.Qw;
+        int n, qy, qx;
+        grid_pixel(g, mm, n, qy, qx);
         opix[j] = (size_t)(n * g.Hout + qy * g.os + py) * g.Wout + qx * g.os + px;
       }
     }
@@ -467,10 +478,9 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
     bmh[e] = (ok && p.bst.relu) ? p.bst.mshift[ch0 + e] : 0.f;
   }
   auto out_pixel = [&](int m) -> size_t {
-    if (g.os == 1) return (size_t)m;
-    const int n = fast_div(m, g.div_hw);
-    const int rem = m - n * (g.Qh * g.Qw);
-    const int qy = fast_div(rem, g.div_w), qx = rem - qy * g.Qw;
+    if (g.os == 1 && !g.tile2d) return (size_t)m;
+    int n, qy, qx;
+    grid_pixel(g, m, n, qy, qx);
     return (size_t)(n * g.Hout + qy * g.os + py) * g.Wout + qx * g.os + px;
   };
   if (do_stats && bwd_stats) {
@@ -583,6 +593,8 @@ extern "C" int dc_debug_stamp_buf256(void* buf) {
 // finishing together (32 MB at HBM speed), not LDS or instruction time.
 static int g_reg_epilogue = 0;
 void igemm256_set_epilogue(int v) { g_reg_epilogue = v ? 1 : 0; }
+static int g_tile2d = 1;         // 16 x 16 pixel blocks per workgroup on multi-tap layers (A/B switch "igemm256_tile2d")
+void igemm256_set_tile2d(int v) { g_tile2d = v ? 1 : 0; }
 static int g_phase_fast = 1;     // tile order of multi-phase (transposed / strided) launches: phase fastest (A/B switch "igemm256_phase_fast")
 void igemm256_set_phase_fast(int v) { g_phase_fast = v ? 1 : 0; }
 
@@ -599,6 +611,8 @@ int launch_igemm256(const IgemmParams& p_in, hipStream_t st) {
   if (init_err != hipSuccess) return dc_set_error(init_err, __FILE__, __LINE__);
   IgemmParams p = p_in;
   p.zero_page = zero_dev;
+  // 16 x 16 pixel blocks for multi-tap layers on grids that divide (the 3 x 3 and transposed convolutions of the decoder)
+  p.g.tile2d = (g_tile2d && p.g.ntaps > 1 && p.m_beg == 0 && p.g.Qh % 16 == 0 && p.g.Qw % 16 == 0) ? 1 : 0;
   p.reg_epilogue = p.bst.y != nullptr ? 0 : g_reg_epilogue;      // the BatchNorm-backward sums live in the LDS epilogue
   p.phase_fast = g_phase_fast;
   hipLaunchKernelGGL(igemm256_kernel, dim3((unsigned)igemm256_tiles(p)), dim3(512), lds, st, p);
