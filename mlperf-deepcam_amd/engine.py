@@ -168,10 +168,11 @@ class Engine:
         self.fuse_bn_conv = os.environ.get("DC_FUSE_BN_CONV", "1") != "0"
         self.fuse_bn_head = os.environ.get("DC_FUSE_BN_HEAD", "1") != "0"
         # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
-        # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 41.23 -> 41.28 -- the fp32 split slabs
-        # (256 KiB per workgroup whatever the batch) are a third of a 728-channel weight gradient's time at batch 2.
+        # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 40.31 -> 40.10 (round 3; 1 / 2 / 3 / 4 layers:
+        # 40.31 / 40.28 / 40.10 / 40.18) -- the fp32 split slabs (256 KiB per workgroup whatever the batch) are a third of a 728-channel
+        # weight gradient's time at batch 2, and a group of three writes and re-reads a third of them.
         wg = os.environ.get("DC_WGRAD_GROUP", "auto")
-        self.wgrad_group = (3 if batch < 8 else 1) if wg == "auto" else max(1, min(4, int(wg)))
+        self.wgrad_group = 3 if wg == "auto" else max(1, min(4, int(wg)))
         self._wg_recs: List[dict] = []
         self.shift_side = os.environ.get("DC_SIDE_SCHEDULE", "eager") == "shift"   # complementary pairing of the two streams
         self._side_deferred: List = []
