@@ -155,6 +155,17 @@ int dc_dwconv_dgrad_bnstats_rows(int dtype, int C, int stride, int dil, int N, i
 int dc_dwconv_dgrad_bnstats(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
                             const float* wp, void* dx, int lddx, const void* ybn, int ldybn, const float* save_mean,
                             const float* save_invstd, const float* mscale, const float* mshift, int relu, float* slab, void* stream);
+/* dc_dwconv_dgrad_bnstats that ALSO takes this depthwise layer's weight gradient (reference: SeparableConv2d_same.conv1,
+ * deeplab_xception.py:54-66, whose .grad autograd fills at train_hdf5_ddp.py:363) from the same dy window: the layer's forward input
+ * is the never-stored act(ybn*mscale + mshift), recomputed from the ybn the statistics read anyway.  wslab: dc_dwconv_dgrad_wgrad_rows
+ * rows (0: shape not served -- stride 2, large images) of [9][C] floats; dc_dwconv_wgrad_reduce adds the rows into grad_w (master
+ * layout [C][1][3][3]) in a fixed order and may run on another stream once the producing call has been ordered before it. */
+int dc_dwconv_dgrad_wgrad_rows(int dtype, int C, int stride, int dil, int N, int Hi, int Wi);
+int dc_dwconv_dgrad_bnstats_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                  const float* w_packed, void* dx, int lddx, const void* ybn, int ldybn, const float* save_mean,
+                                  const float* save_invstd, const float* mscale, const float* mshift, int relu, float* slab,
+                                  float* wslab, void* stream);
+int dc_dwconv_wgrad_reduce(int C, int rows, const float* wslab, float* grad_w, void* stream);
 size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int stride);
 int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
                     const void* dy, int lddy, void* workspace, float* grad_w, const float* pscale, const float* pshift,

@@ -535,10 +535,42 @@ extern "C" int dc_dwconv_dgrad_bnstats(int dtype, int C, int stride, int dil, in
   DC_REQUIRE(dc_dwconv_dgrad_bnstats_rows(dtype, C, stride, dil, N, Hi, Wi) > 0, "dc_dwconv_dgrad_bnstats: shape not served by the tiled kernels");
   DwBnStats bs;
   bs.y = ybn; bs.ldy = ldybn; bs.mean = save_mean; bs.invstd = save_invstd; bs.mscale = mscale; bs.mshift = mshift; bs.relu = relu ? 1 : 0;
-  bs.slab = slab; bs.rows = 0;
+  bs.slab = slab; bs.rows = 0; bs.wslab = nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1) return launch_dw_tile(dtype, dil, true, dy, lddy, w, nullptr, 0, dx, lddx, N, Hi, Wi, C, st, nullptr, nullptr, 0, &bs);
   return launch_dw_tile_s2(dtype, 1, N, Hi, Wi, C, dy, lddy, w, nullptr, 0, dx, lddx, nullptr, nullptr, st, nullptr, nullptr, 0, &bs);
+}
+
+// The same with THIS depthwise layer's weight gradient taken from the same dy window (stride 1, tiled path, at most DWT_MAX_ROWS pixel
+// tiles): wslab receives dc_dwconv_dgrad_wgrad_rows rows of [9][C] partial sums; dc_dwconv_wgrad_reduce adds them into grad_w.  The
+// layer's forward input is act(ybn*mscale + mshift) (the never-stored BatchNorm output), so nothing is read that the data gradient
+// with statistics does not read already.
+extern "C" int dc_dwconv_dgrad_wgrad_rows(int dtype, int C, int stride, int dil, int N, int Hi, int Wi) {
+  if (stride != 1 || (dil != 1 && dil != 2) || !g_dw_tile) return 0;
+  if (dc_dwconv_dgrad_bnstats_rows(dtype, C, stride, dil, N, Hi, Wi) <= 0) return 0;
+  const int rows = dw_tile_rows(dtype, C, N, Hi, Wi);
+  return rows <= DWT_MAX_ROWS ? rows : 0;
+}
+
+extern "C" int dc_dwconv_dgrad_bnstats_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                             const float* w, void* dx, int lddx, const void* ybn, int ldybn, const float* save_mean,
+                                             const float* save_invstd, const float* mscale, const float* mshift, int relu, float* slab,
+                                             float* wslab, void* stream) {
+  if (int e = dw_check(dtype, C, stride, dil, N, Hi, Wi)) return e;
+  if (int e = dc_check_view(dy, lddy, C, dtype, "dc_dwconv_dgrad_bnstats_wgrad dy")) return e;
+  if (int e = dc_check_view(dx, lddx, C, dtype, "dc_dwconv_dgrad_bnstats_wgrad dx")) return e;
+  if (int e = dc_check_view(ybn, ldybn, C, dtype, "dc_dwconv_dgrad_bnstats_wgrad y")) return e;
+  DC_REQUIRE(w && save_mean && save_invstd && slab && wslab && mscale && mshift, "dc_dwconv_dgrad_bnstats_wgrad: null argument");
+  DC_REQUIRE(dc_dwconv_dgrad_wgrad_rows(dtype, C, stride, dil, N, Hi, Wi) > 0, "dc_dwconv_dgrad_bnstats_wgrad: shape not served");
+  DwBnStats bs;
+  bs.y = ybn; bs.ldy = ldybn; bs.mean = save_mean; bs.invstd = save_invstd; bs.mscale = mscale; bs.mshift = mshift; bs.relu = relu ? 1 : 0;
+  bs.slab = slab; bs.rows = 0; bs.wslab = wslab;
+  return launch_dw_tile(dtype, dil, true, dy, lddy, w, nullptr, 0, dx, lddx, N, Hi, Wi, C, (hipStream_t)stream, nullptr, nullptr, 0, &bs);
+}
+
+extern "C" int dc_dwconv_wgrad_reduce(int C, int rows, const float* wslab, float* grad_w, void* stream) {
+  DC_REQUIRE(C > 0 && rows > 0 && wslab && grad_w, "dc_dwconv_wgrad_reduce: bad argument");
+  return dw_tile_reduce(wslab, grad_w, rows, C, (hipStream_t)stream);
 }
 
 extern "C" size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int stride) {

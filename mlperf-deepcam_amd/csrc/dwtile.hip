@@ -61,7 +61,7 @@ __device__ inline void stage_halo(char* smem, const T* __restrict__ in, int ldin
 }
 
 // forward (FLIP = false) and data gradient (FLIP = true: the same stencil with the taps reversed, plus an optional addend)
-template <typename T, int DIL, bool FLIP, int CG>
+template <typename T, int DIL, bool FLIP, int CG, bool WG = false>
 __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int ldin, const float* __restrict__ wp,
                                                   const T* __restrict__ addend, int ldadd, T* __restrict__ out, int ldout, int H, int W,
                                                   int C, int ncgb, int ntx, int nty, const float* __restrict__ pscale,
@@ -95,6 +95,14 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
   if (!cok && !stats) return;
   BnAcc<KH> bn;
   if (stats) bn.init(st, ch0);
+  // WG: the weight gradient of THIS depthwise layer, taken from the same dy window (see DwBnStats::wslab); dwa[t] for tap t
+  float dwa[WG ? 9 : 1][KH];
+  if constexpr (WG) {
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+      for (int e = 0; e < KH; ++e) dwa[t9][e] = 0.f;
+  }
 
   const char* tile = smem + h * 8;
 #pragma unroll 1
@@ -129,6 +137,29 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
     for (int j = 0; j < DT_PX; ++j)
 #pragma unroll
       for (int e = 0; e < KH; ++e) acc[j][e] = 0.f;
+    // WG: the forward input of this layer at the strip's own pixels, xhat = act(y*ms + mh) rounded to T exactly as the forward
+    // kernel's prologue did (bn_transform_tile), zero outside the image
+    float xh[WG ? DT_PX : 1][KH];
+    if constexpr (WG) {
+#pragma unroll
+      for (int j = 0; j < DT_PX; ++j) {
+        const bool in = oy < H && x0 + xs + j < W;
+        float yf[KH];
+        unpack8(yv[j], yf, T());
+#pragma unroll
+        for (int e = 0; e < KH; ++e) {
+          const float v = fmaf(yf[e], bn.ms[e], bn.mh[e]);
+          yf[e] = st.relu ? fmaxf(v, 0.f) : v;
+        }
+        vec8 r;
+        pack8(r, yf, T());
+        unpack8(r, xh[j], T());
+        if (!in) {
+#pragma unroll
+          for (int e = 0; e < KH; ++e) xh[j][e] = 0.f;
+        }
+      }
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -141,6 +172,11 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
           if (j >= 0 && j < DT_PX) {
 #pragma unroll
             for (int e = 0; e < KH; ++e) acc[j][e] = fmaf(f[e], wk[ky * 3 + kx][e], acc[j][e]);
+            if constexpr (WG) {
+              // window element = dy[q + (ky-1, kx-1)*DIL] = dy[q - (t - 1)*DIL] for the forward tap t = 8 - (ky*3 + kx)
+#pragma unroll
+              for (int e = 0; e < KH; ++e) dwa[8 - (ky * 3 + kx)][e] = fmaf(f[e], xh[j][e], dwa[8 - (ky * 3 + kx)][e]);
+            }
           }
         }
       }
@@ -173,6 +209,29 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
   if (stats) {
     __syncthreads();   // every thread of the workgroup gets here: the staged tile is dead
     bn_acc_store<KH, K::NSL, CG * KPV>(reinterpret_cast<float*>(smem), bn.a, bn.b, cok, h, sl, st, tile_id, cg0 * KPV, C);
+  }
+  if constexpr (WG) {
+    // fold the strip lanes (as dwt_wgrad_kernel): red[sl][9][CW], one slab row per pixel tile
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int CW = CG * KPV;
+    if (cok) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int e = 0; e < KH; ++e) red[(sl * 9 + tp) * CW + h * KH + e] = dwa[tp][e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * CW; i += 256) {
+      const int tp = i / CW, cl = i % CW;
+      const int c = cg0 * KPV + cl;
+      if (c < C) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < K::NSL; ++qq) sacc += red[(qq * 9 + tp) * CW + cl];
+        st.wslab[((size_t)tile_id * 9 + tp) * C + c] = sacc;
+      }
+    }
   }
 }
 
@@ -363,6 +422,16 @@ size_t dw_tile_wgrad_workspace(int C, int N, int H, int W) {
 template <typename T, int DIL, bool FLIP, int CG>
 static void launch_fwd1(const TileGrid& t, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out,
                         int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats& bs) {
+  if constexpr (FLIP) {
+    if (bs.wslab != nullptr) {          // data gradient + BatchNorm sums + this layer's weight-gradient rows
+      constexpr int FOLD = TileCfg<DIL, CG>::NSL * 9 * CG * Elem<T>::kPerVec * (int)sizeof(float);
+      constexpr int LDSW = TileCfg<DIL, CG>::LDS_BYTES > FOLD ? TileCfg<DIL, CG>::LDS_BYTES : FOLD;
+      DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, true, CG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW));
+      hipLaunchKernelGGL((dwt_kernel<T, DIL, true, CG, true>), dim3(t.ntiles * t.ncgb), dim3(256), LDSW, st, (const T*)in, ldin, wp,
+                         (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs);
+      return;
+    }
+  }
   constexpr int LDS = TileCfg<DIL, CG>::LDS_BYTES;
   DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, FLIP, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   hipLaunchKernelGGL((dwt_kernel<T, DIL, FLIP, CG>), dim3(t.ntiles * t.ncgb), dim3(256), LDS, st, (const T*)in, ldin, wp,
@@ -384,7 +453,7 @@ int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, cons
   const TileGrid t = tile_grid(C / kpv, N, H, W);
   DC_REQUIRE((long)t.ntiles * t.ncgb < (1L << 31) && (long)N * H * W < (1L << 31), "dc_dwconv: tensor too large for the tiled path");
   DwBnStats bs;
-  if (bnstats != nullptr) bs = *bnstats; else { bs.slab = nullptr; bs.y = nullptr; bs.ldy = 0; bs.mean = bs.invstd = bs.mscale = bs.mshift = nullptr; bs.relu = 0; bs.rows = 0; }
+  if (bnstats != nullptr) bs = *bnstats; else { bs.slab = nullptr; bs.y = nullptr; bs.ldy = 0; bs.mean = bs.invstd = bs.mscale = bs.mshift = nullptr; bs.relu = 0; bs.rows = 0; bs.wslab = nullptr; }
   if (bs.slab != nullptr) bs.rows = t.ntiles;
 #define DWT(TT, D, F) launch_fwd2<TT, D, F>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs)
   if (dtype == DC_BF16) {

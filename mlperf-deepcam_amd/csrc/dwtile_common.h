@@ -67,18 +67,23 @@ struct DwBnStats {
   int relu;
   float* slab;          // null: statistics off
   int rows;
+  // stride-1 tiled kernel only: the depthwise WEIGHT gradient rides along too (dW[t] = sum_q xhat[q] * dy[q - t]: the dy window is the
+  // one the data gradient reads, xhat = act(y*mscale + mshift) is recomputed from the y this epilogue loads anyway), one row of
+  // [9][C] partial sums per pixel tile into wslab; null: off
+  float* wslab;
 };
 
 template <int KH>
 struct BnAcc {
   float mu[KH], is[KH], ms[KH], mh[KH], a[KH], b[KH];
   __device__ inline void init(const DwBnStats& st, int ch0) {
+    const bool affine = st.relu || st.wslab != nullptr;     // the fused weight gradient needs act(y*ms + mh) even without a ReLU
 #pragma unroll
     for (int e = 0; e < KH; ++e) {
       mu[e] = st.mean[ch0 + e];
       is[e] = st.invstd[ch0 + e];
-      ms[e] = st.relu ? st.mscale[ch0 + e] : 0.f;
-      mh[e] = st.relu ? st.mshift[ch0 + e] : 0.f;
+      ms[e] = affine ? st.mscale[ch0 + e] : 0.f;
+      mh[e] = affine ? st.mshift[ch0 + e] : 0.f;
       a[e] = b[e] = 0.f;
     }
   }

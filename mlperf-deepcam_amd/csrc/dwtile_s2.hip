@@ -383,7 +383,7 @@ int launch_dw_tile_s2(int dtype, int mode, int N, int Hi, int Wi, int C, const v
                       void* out, int ldout, float* slab, int* rows_out, hipStream_t st, const float* pscale, const float* pshift, int prelu,
                       const DwBnStats* bnstats) {
   DwBnStats bs;
-  if (bnstats != nullptr && mode == 1) bs = *bnstats; else { bs.slab = nullptr; bs.y = nullptr; bs.ldy = 0; bs.mean = bs.invstd = bs.mscale = bs.mshift = nullptr; bs.relu = 0; bs.rows = 0; }
+  if (bnstats != nullptr && mode == 1) bs = *bnstats; else { bs.slab = nullptr; bs.y = nullptr; bs.ldy = 0; bs.mean = bs.invstd = bs.mscale = bs.mshift = nullptr; bs.relu = 0; bs.rows = 0; bs.wslab = nullptr; }
   S2Args a;
   a.pscale = mode == 1 ? nullptr : pscale; a.pshift = pshift; a.prelu = prelu;
   a.Hi = Hi; a.Wi = Wi; a.Ho = (Hi - 1) / 2 + 1; a.Wo = (Wi - 1) / 2 + 1; a.C = C;

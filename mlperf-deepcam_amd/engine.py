@@ -167,6 +167,9 @@ class Engine:
         # dc_head_bwd_bnstats) instead of a dc_bn_bwd_reduce pass over the gradient and the BatchNorm input
         self.fuse_bn_conv = os.environ.get("DC_FUSE_BN_CONV", "1") != "0"
         self.fuse_bn_head = os.environ.get("DC_FUSE_BN_HEAD", "1") != "0"
+        # depthwise weight gradient taken inside the depthwise data gradient (dc_dwconv_dgrad_bnstats_wgrad) where the layer's input is a
+        # never-stored BatchNorm output: the separate dc_dwconv_wgrad launch (and its second read of dy and y) disappears
+        self.fuse_dw_wgrad = os.environ.get("DC_FUSE_DW_WGRAD", "1") != "0"
         # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
         # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 40.31 -> 40.10 (round 3; 1 / 2 / 3 / 4 layers:
         # 40.31 / 40.28 / 40.10 / 40.18) -- the fp32 split slabs (256 KiB per workgroup whatever the batch) are a third of a 728-channel
@@ -480,15 +483,28 @@ class Engine:
             # the producer is a never-stored BatchNorm output and this is its only consumer: take that BatchNorm's backward
             # sums (sum g, sum g*xhat) on the way out of the data-gradient kernel instead of re-reading dx and y for them
             srows = lib.dc_dwconv_dgrad_bnstats_rows(self.dt, Cc, stride, dil, N, H, W) if (lazy and self.fuse_bn_reduce and mode == 0) else 0
+            wrows = 0
             if srows > 0:
                 sslab = self._f32(2 * srows * Cc)
                 x.fused_bwd = (sslab, srows)
                 mean_p, invstd_p = L.dptr(x.mean), L.dptr(x.invstd)
+                if self.fuse_dw_wgrad and not self.shift_side:
+                    wrows = lib.dc_dwconv_dgrad_wgrad_rows(self.dt, Cc, stride, dil, N, H, W)
+                if wrows > 0:
+                    wslab = self._f32(wrows * 9 * Cc)      # per layer: the reduction runs on the side stream, behind the next layers
 
             def dw_wgrad(ws):
                 L.call("dc_dwconv_wgrad", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, dy.ptr, dy.ld, ws, gw, ps, psh, prelu, self._st())
 
+            def dw_wreduce(ws):
+                L.call("dc_dwconv_wgrad_reduce", Cc, wrows, L.dptr(wslab), gw, self._st())
+
             def bwd():
+                if wrows > 0:
+                    L.call("dc_dwconv_dgrad_bnstats_wgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr, dx.ld, src.ptr, src.ld,
+                           mean_p, invstd_p, ps, psh, prelu, L.dptr(sslab), L.dptr(wslab), self._st())
+                    self._on_side(dw_wreduce)           # only the fixed-order fold of the rows is left for the side stream
+                    return
                 if self.shift_side:
                     self._side_deferred.append((dw_wgrad, [wname]))
                 else:

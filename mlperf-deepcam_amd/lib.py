@@ -61,6 +61,9 @@ _SIGS = {
     "dc_dwconv_dgrad": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P]),
     "dc_dwconv_dgrad_bnstats_rows": (I, [I, I, I, I, I, I, I]),
     "dc_dwconv_dgrad_bnstats": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P, P, P, P, I, P, P]),
+    "dc_dwconv_dgrad_wgrad_rows": (I, [I, I, I, I, I, I, I]),
+    "dc_dwconv_dgrad_bnstats_wgrad": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P, P, P, P, I, P, P, P]),
+    "dc_dwconv_wgrad_reduce": (I, [I, I, P, P, P]),
     "dc_dwconv_wgrad_workspace": (SZ, [I, I, I, I, I]),
     "dc_dwconv_wgrad": (I, [I, I, I, I, I, I, I, P, I, P, I, P, P, P, P, I, P]),
     "dc_bn_stat_rows": (I, [L]),

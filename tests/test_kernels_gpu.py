@@ -687,6 +687,58 @@ def test_depthwise(case, dtype):
     assert_close(gw.cpu(), gw_ref, dtype, f32=2e-4, bf16=2e-3)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("relu", [1, 0])
+@pytest.mark.parametrize("case", [c for c in DW_CASES if c[2] == 1], ids=lambda c: c[0])
+def test_depthwise_dgrad_with_fused_weight_gradient(case, dtype, relu):
+    """dc_dwconv_dgrad_bnstats_wgrad + dc_dwconv_wgrad_reduce = dc_dwconv_dgrad_bnstats followed by dc_dwconv_wgrad with the BatchNorm
+    prologue: the same dx bits and BatchNorm sums, the same weight gradient up to the order of the additions (and both against autograd
+    on the CPU through the materialised BatchNorm output)."""
+    _, Cc, stride, dil, N, H, W = case
+    dt = L.dtype_code(dtype)
+    rows = L.load().dc_dwconv_dgrad_wgrad_rows(dt, Cc, stride, dil, N, H, W)
+    assert rows > 0
+    y = q(rnd(N, Cc, H, W, seed=1), dtype)                       # raw conv output = BatchNorm input
+    scale, shift = rnd(Cc, seed=5).abs() + 0.5, rnd(Cc, seed=6, scale=0.3)
+    mean, invstd = rnd(Cc, seed=7, scale=0.2), rnd(Cc, seed=8).abs() + 0.5
+    w = rnd(Cc, 1, 3, 3, seed=2, scale=1 / 3)
+    xhat = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if relu:
+        xhat = xhat.clamp_min(0)
+    xhat = q(xhat, dtype)
+    wr = w.clone().requires_grad_(True)
+    yref = F.conv2d(F.pad(xhat, (dil, dil, dil, dil)), wr, None, 1, 0, dil, groups=Cc)
+    gy = q(rnd(*yref.shape, seed=3), dtype)
+    (gw_ref,) = torch.autograd.grad(yref, (wr,), gy)
+    wd = torch.empty(9 * Cc, device=dev())
+    L.call("dc_dwconv_pack_weights", Cc, vptr(w.to(dev())), vptr(wd), S())
+    _, yv = to_nhwc(y, dtype, ld=Cc + 8)
+    _, gyv = to_nhwc(gy, dtype)
+    dmean, dinv, dsc, dsh = (t.to(dev()) for t in (mean, invstd, scale, shift))
+    srows = L.load().dc_dwconv_dgrad_bnstats_rows(dt, Cc, stride, dil, N, H, W)
+    # separate calls
+    _, dx_ref = empty_nhwc(N, H, W, Cc, dtype)
+    slab_ref = torch.full((2, srows, Cc), float("nan"), device=dev())
+    L.call("dc_dwconv_dgrad_bnstats", dt, Cc, stride, dil, N, H, W, vptr(gyv), Cc, vptr(wd), vptr(dx_ref), Cc, vptr(yv), Cc + 8, vptr(dmean),
+           vptr(dinv), vptr(dsc), vptr(dsh), relu, vptr(slab_ref), S())
+    ws = torch.empty(L.load().dc_dwconv_wgrad_workspace(Cc, N, H, W, stride), dtype=torch.uint8, device=dev())
+    gw_sep = torch.full((Cc, 1, 3, 3), float("nan"), device=dev())
+    L.call("dc_dwconv_wgrad", dt, Cc, stride, dil, N, H, W, vptr(yv), Cc + 8, vptr(gyv), Cc, vptr(ws), vptr(gw_sep), vptr(dsc), vptr(dsh), relu, S())
+    # one call
+    _, dx = empty_nhwc(N, H, W, Cc, dtype)
+    slab = torch.full((2, srows, Cc), float("nan"), device=dev())
+    wslab = torch.full((rows, 9, Cc), float("nan"), device=dev())
+    gw = torch.full((Cc, 1, 3, 3), float("nan"), device=dev())
+    L.call("dc_dwconv_dgrad_bnstats_wgrad", dt, Cc, stride, dil, N, H, W, vptr(gyv), Cc, vptr(wd), vptr(dx), Cc, vptr(yv), Cc + 8, vptr(dmean),
+           vptr(dinv), vptr(dsc), vptr(dsh), relu, vptr(slab), vptr(wslab), S())
+    L.call("dc_dwconv_wgrad_reduce", Cc, rows, vptr(wslab), vptr(gw), S())
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(dx), from_nhwc(dx_ref)) and torch.equal(slab, slab_ref)
+    assert not torch.isnan(wslab).any()
+    assert_close(gw.cpu(), gw_ref, dtype, f32=2e-4, bf16=2e-3)
+    np.testing.assert_allclose(gw.cpu().numpy(), gw_sep.cpu().numpy(), rtol=2e-5, atol=2e-5 * float(gw_sep.abs().max()))
+
+
 @pytest.mark.parametrize("tpb", [3, 50])
 def test_depthwise_wgrad_several_tiles_per_workgroup(tpb):
     """The weight-gradient planner gives a workgroup several tiles only on large layers; force it on a small one."""
