@@ -165,6 +165,12 @@ int dc_dwconv_dgrad_bnstats_wgrad(int dtype, int C, int stride, int dil, int N, 
                                   const float* w_packed, void* dx, int lddx, const void* ybn, int ldybn, const float* save_mean,
                                   const float* save_invstd, const float* mscale, const float* mshift, int relu, float* slab,
                                   float* wslab, void* stream);
+/* The same fusion where the layer's forward input is a stored tensor x, or act(x*pscale + pshift) of one: data gradient (written, or
+ * added onto `addend`: the first separable conv of an Xception block, whose input gradient joins the shortcut's) plus weight-gradient
+ * rows; no BatchNorm sums. */
+int dc_dwconv_dgrad_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                          const float* w_packed, const void* addend, int ldadd, void* dx, int lddx, const void* x, int ldx,
+                          const float* pscale, const float* pshift, int prelu, float* wslab, void* stream);
 int dc_dwconv_wgrad_reduce(int C, int rows, const float* wslab, float* grad_w, void* stream);
 size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int stride);
 int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,

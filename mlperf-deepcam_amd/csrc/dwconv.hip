@@ -568,6 +568,26 @@ extern "C" int dc_dwconv_dgrad_bnstats_wgrad(int dtype, int C, int stride, int d
   return launch_dw_tile(dtype, dil, true, dy, lddy, w, nullptr, 0, dx, lddx, N, Hi, Wi, C, (hipStream_t)stream, nullptr, nullptr, 0, &bs);
 }
 
+// Data gradient (optionally accumulated onto `addend`) plus this layer's weight-gradient rows when the layer's forward input is a
+// STORED tensor x (pscale == null) or act(x*pscale + pshift) of one: the first separable conv of an Xception block, whose input is the
+// block input and whose data gradient joins the shortcut's.
+extern "C" int dc_dwconv_dgrad_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                     const float* w, const void* addend, int ldadd, void* dx, int lddx, const void* x, int ldx,
+                                     const float* pscale, const float* pshift, int prelu, float* wslab, void* stream) {
+  if (int e = dw_check(dtype, C, stride, dil, N, Hi, Wi)) return e;
+  if (int e = dc_check_view(dy, lddy, C, dtype, "dc_dwconv_dgrad_wgrad dy")) return e;
+  if (int e = dc_check_view(dx, lddx, C, dtype, "dc_dwconv_dgrad_wgrad dx")) return e;
+  if (int e = dc_check_view(x, ldx, C, dtype, "dc_dwconv_dgrad_wgrad x")) return e;
+  if (addend != nullptr)
+    if (int e = dc_check_view(addend, ldadd, C, dtype, "dc_dwconv_dgrad_wgrad addend")) return e;
+  DC_REQUIRE(w && wslab && (pscale == nullptr) == (pshift == nullptr), "dc_dwconv_dgrad_wgrad: bad argument");
+  DC_REQUIRE(dc_dwconv_dgrad_wgrad_rows(dtype, C, stride, dil, N, Hi, Wi) > 0, "dc_dwconv_dgrad_wgrad: shape not served");
+  DwBnStats bs;
+  bs.y = x; bs.ldy = ldx; bs.mean = bs.invstd = nullptr; bs.mscale = pscale; bs.mshift = pshift; bs.relu = (pscale != nullptr && prelu) ? 1 : 0;
+  bs.slab = nullptr; bs.rows = 0; bs.wslab = wslab;
+  return launch_dw_tile(dtype, dil, true, dy, lddy, w, addend, ldadd, dx, lddx, N, Hi, Wi, C, (hipStream_t)stream, nullptr, nullptr, 0, &bs);
+}
+
 extern "C" int dc_dwconv_wgrad_reduce(int C, int rows, const float* wslab, float* grad_w, void* stream) {
   DC_REQUIRE(C > 0 && rows > 0 && wslab && grad_w, "dc_dwconv_wgrad_reduce: bad argument");
   return dw_tile_reduce(wslab, grad_w, rows, C, (hipStream_t)stream);

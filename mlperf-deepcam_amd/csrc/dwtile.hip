@@ -92,9 +92,10 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
     __syncthreads();
   }
   const bool stats = FLIP && st.slab != nullptr;
-  if (!cok && !stats) return;
+  if (!cok && !stats && !WG) return;
   BnAcc<KH> bn;
   if (stats) bn.init(st, ch0);
+  else if (WG) bn.init_affine(st, ch0);     // weight gradient without statistics: the layer's input is a stored tensor (or its act(y*ms+mh))
   // WG: the weight gradient of THIS depthwise layer, taken from the same dy window (see DwBnStats::wslab); dwa[t] for tap t
   float dwa[WG ? 9 : 1][KH];
   if constexpr (WG) {
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
     // the addend (gradient already accumulated in dx by another consumer) is requested before the stencil so that its latency
     // hides behind the arithmetic; so is the BatchNorm input when the statistics ride along
     vec8 yv[DT_PX];
-    if (stats) {
+    if (stats || WG) {
 #pragma unroll
       for (int j = 0; j < DT_PX; ++j) {
         const int ox = x0 + xs + j;

@@ -87,6 +87,15 @@ struct BnAcc {
       a[e] = b[e] = 0.f;
     }
   }
+  // weight gradient only (no statistics): xhat = act(y*ms + mh), the identity when the vectors are absent (a stored input tensor)
+  __device__ inline void init_affine(const DwBnStats& st, int ch0) {
+#pragma unroll
+    for (int e = 0; e < KH; ++e) {
+      mu[e] = is[e] = a[e] = b[e] = 0.f;
+      ms[e] = st.mscale != nullptr ? st.mscale[ch0 + e] : 1.f;
+      mh[e] = st.mshift != nullptr ? st.mshift[ch0 + e] : 0.f;
+    }
+  }
   // g: the gradient values as STORED (already rounded), yv: the BatchNorm input at the same pixel
   __device__ inline void add(const float (&g)[KH], const float (&yv)[KH], int relu) {
 #pragma unroll

@@ -484,6 +484,11 @@ class Engine:
             # sums (sum g, sum g*xhat) on the way out of the data-gradient kernel instead of re-reading dx and y for them
             srows = lib.dc_dwconv_dgrad_bnstats_rows(self.dt, Cc, stride, dil, N, H, W) if (lazy and self.fuse_bn_reduce and mode == 0) else 0
             wrows = 0
+            if srows == 0 and self.fuse_dw_wgrad and not self.shift_side:
+                # stored input (or a lazy one whose statistics are taken elsewhere): data gradient + weight-gradient rows in one kernel
+                wrows = lib.dc_dwconv_dgrad_wgrad_rows(self.dt, Cc, stride, dil, N, H, W)
+                if wrows > 0:
+                    wslab = self._f32(wrows * 9 * Cc)
             if srows > 0:
                 sslab = self._f32(2 * srows * Cc)
                 x.fused_bwd = (sslab, srows)
@@ -500,6 +505,11 @@ class Engine:
                 L.call("dc_dwconv_wgrad_reduce", Cc, wrows, L.dptr(wslab), gw, self._st())
 
             def bwd():
+                if wrows > 0 and srows == 0:
+                    L.call("dc_dwconv_dgrad_wgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
+                           dx.ptr, dx.ld, src.ptr, src.ld, ps, psh, prelu, L.dptr(wslab), self._st())
+                    self._on_side(dw_wreduce)
+                    return
                 if wrows > 0:
                     L.call("dc_dwconv_dgrad_bnstats_wgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr, dx.ld, src.ptr, src.ld,
                            mean_p, invstd_p, ps, psh, prelu, L.dptr(sslab), L.dptr(wslab), self._st())

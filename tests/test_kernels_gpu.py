@@ -685,6 +685,20 @@ def test_depthwise(case, dtype):
     L.call("dc_dwconv_wgrad", dt, Cc, stride, dil, N, H, W, vptr(xv), Cc + 8, vptr(gyv), Cc, vptr(ws), vptr(gw), None, None, 0, S())
     torch.cuda.synchronize()
     assert_close(gw.cpu(), gw_ref, dtype, f32=2e-4, bf16=2e-3)
+    # data gradient (onto an addend) and weight gradient in ONE kernel, where the tiled stride-1 path serves the shape
+    rows = L.load().dc_dwconv_dgrad_wgrad_rows(dt, Cc, stride, dil, N, H, W)
+    assert (rows > 0) == (stride == 1)
+    if rows > 0:
+        _, gxv2 = empty_nhwc(N, H, W, Cc, dtype)
+        wslab = torch.full((rows, 9, Cc), float("nan"), device=dev())
+        gw2 = torch.full((Cc, 1, 3, 3), float("nan"), device=dev())
+        L.call("dc_dwconv_dgrad_wgrad", dt, Cc, stride, dil, N, H, W, vptr(gyv), Cc, vptr(wd), vptr(addv), Cc, vptr(gxv2), Cc, vptr(xv), Cc + 8,
+               None, None, 0, vptr(wslab), S())
+        L.call("dc_dwconv_wgrad_reduce", Cc, rows, vptr(wslab), vptr(gw2), S())
+        torch.cuda.synchronize()
+        assert torch.equal(from_nhwc(gxv2), from_nhwc(gxv))
+        assert_close(gw2.cpu(), gw_ref, dtype, f32=2e-4, bf16=2e-3)
+        np.testing.assert_allclose(gw2.cpu().numpy(), gw.cpu().numpy(), rtol=2e-5, atol=2e-5 * float(gw.abs().max()))
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
