@@ -165,11 +165,14 @@ class Engine:
         self.mask_from_y = os.environ.get("DC_MASK_FROM_Y", "1") != "0"
         # BatchNorm backward sums taken in the epilogue of the consuming dense conv's data gradient (dc_conv_dgrad_bnstats /
         # dc_head_bwd_bnstats) instead of a dc_bn_bwd_reduce pass over the gradient and the BatchNorm input
-        self.fuse_bn_conv = os.environ.get("DC_FUSE_BN_CONV", "1") != "0"
-        self.fuse_bn_head = os.environ.get("DC_FUSE_BN_HEAD", "1") != "0"
+        # (time-neutral at local batch 8 and 4, where it saves 2.8 GB of reads per step; +0.08 ms at batch 2: off there)
+        self.fuse_bn_conv = os.environ.get("DC_FUSE_BN_CONV", "1" if batch >= 4 else "0") != "0"
+        self.fuse_bn_head = os.environ.get("DC_FUSE_BN_HEAD", "1" if batch >= 4 else "0") != "0"
         # depthwise weight gradient taken inside the depthwise data gradient (dc_dwconv_dgrad_bnstats_wgrad) where the layer's input is a
         # never-stored BatchNorm output: the separate dc_dwconv_wgrad launch (and its second read of dy and y) disappears
-        self.fuse_dw_wgrad = os.environ.get("DC_FUSE_DW_WGRAD", "1") != "0"
+        # (local batch 8: 39.97 -> 39.74 ms/step; batch 4 / 2: +0.25 / +0.15 ms -- the fused kernel holds 232 registers, two workgroups
+        # per CU instead of three, which the few tiles of a small batch do not hide: on from batch 8)
+        self.fuse_dw_wgrad = os.environ.get("DC_FUSE_DW_WGRAD", "1" if batch >= 8 else "0") != "0"
         # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
         # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 40.31 -> 40.10 (round 3; 1 / 2 / 3 / 4 layers:
         # 40.31 / 40.28 / 40.10 / 40.18) -- the fp32 split slabs (256 KiB per workgroup whatever the batch) are a third of a 728-channel
