@@ -228,6 +228,13 @@ int dc_stem_wgrad(int dtype, int N, int Cin, int H, int W, const float* x_nchw, 
 size_t dc_head_workspace(int dtype, int N, int Cin, int Hi, int Wi);
 int dc_head_fwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx,
                 const float* w /*[Cin][3][3][3]*/, float* logits_nchw, void* workspace, void* stream);
+/* dc_head_fwd with the loss pass of dc_wce_fused on the logits while they are in registers (reference: upsample.last_deconv,
+ * deeplab_xception.py:374,382, followed by fp_loss, utils/losses.py:35-50, argmax train_hdf5_ddp.py:406 and the IoU counts of
+ * utils/utils.py:32-60): same logits, loss, gradient, predictions and counts bit for bit as the two calls.  logits_nchw may be
+ * null (bf16, Cin = 256: the fused kernel then never stores them); the loss arguments are dc_wce_fused's. */
+int dc_head_fwd_loss(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* w, float* logits_nchw,
+                     void* workspace, const void* labels, int label_dtype_bytes, const float* class_weights, float grad_scale,
+                     double* loss_sum, float* dlogits, int64_t* pred, int64_t* counts, void* stream);
 /* dx = d(loss)/dx and grad_w (master layout) from the NCHW fp32 logit gradient, in one call (they share the gathered
  * 27-tap gradient image).  workspace: dc_head_workspace bytes, 256-byte aligned. */
 int dc_head_bwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,

@@ -231,8 +231,31 @@ constexpr int HF_PX = (HF_TY + 1) * (HF_TX + 1);        // 165 product pixels pe
 constexpr int HF_MB = (HF_PX + 15) / 16;                // 11 MFMA row blocks
 constexpr int HF_TILES = 6;                             // tiles per workgroup (along x), amortises the weight image
 
+// LOSS: the weighted cross-entropy pass (loss.hip: wce_kernel, same arithmetic statement for statement, so the same bits) runs on the
+// logits of a tile while they are still in registers: the fp32 NCHW logits are then written only if the caller wants them (`out`
+// may be null) and never read back (reference: upsample.last_deconv, deeplab_xception.py:374,382, followed by utils/losses.py:35-50).
+struct HeadLoss {
+  const void* labels;
+  int lbytes;
+  const float* cw;
+  float grad_scale;
+  double* loss_sum;
+  float* dlogits;
+  int64_t* pred;
+  unsigned long long* counts;
+};
+
+__device__ inline int head_load_label(const void* labels, int bytes, size_t i) {
+  long long v;
+  if (bytes == 8) v = reinterpret_cast<const int64_t*>(labels)[i];
+  else if (bytes == 4) v = reinterpret_cast<const int32_t*>(labels)[i];
+  else v = reinterpret_cast<const uint8_t*>(labels)[i];
+  return (v >= 0 && v < HEAD_NC) ? (int)v : -1;
+}
+
+template <bool LOSS>
 __global__ __launch_bounds__(256) void head_fused_fwd_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ wf,
-                                                             float* __restrict__ out, int N, int Hi, int Wi, int Cin, int ntx) {
+                                                             float* __restrict__ out, int N, int Hi, int Wi, int Cin, int ntx, const HeadLoss hl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* P = reinterpret_cast<float*>(smem);                       // [HF_MB*16][HEAD_NP]
   char* wl = smem + HF_MB * 16 * HEAD_NP * 4;                      // weight image [32][Cin] bf16, 64-byte K rows swizzled per 16-B slot
@@ -252,6 +275,8 @@ __global__ __launch_bounds__(256) void head_fused_fwd_kernel(const bf16* __restr
   const int ty = b % nty, n = b / nty;
   const int y0 = ty * HF_TY;
   const int Ho = 2 * Hi, Wo = 2 * Wi;
+  [[maybe_unused]] double lsum = 0.0;
+  [[maybe_unused]] unsigned long long cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int tt = 0; tt < HF_TILES; ++tt) {
     const int tx = strip * HF_TILES + tt;
     if (tx >= ntx) break;
@@ -291,23 +316,106 @@ __global__ __launch_bounds__(256) void head_fused_fwd_kernel(const bf16* __restr
       for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
     }
     __syncthreads();
-    // combine: 2*HF_TY x 2*HF_TX outputs per class, consecutive lanes along x
-    for (int i = tid; i < HEAD_NC * 2 * HF_TY * 2 * HF_TX; i += 256) {
-      const int ox_l = i % (2 * HF_TX);
-      const int t2 = i / (2 * HF_TX);
-      const int oy_l = t2 % (2 * HF_TY), co = t2 / (2 * HF_TY);
-      const int qy_l = oy_l >> 1, py = oy_l & 1, qx_l = ox_l >> 1, px = ox_l & 1;
-      const int qy = y0 + qy_l, qx = x0 + qx_l;
-      if (qy < Hi && qx < Wi) {
-        const float* p00 = P + (qy_l * (HF_TX + 1) + qx_l) * HEAD_NP + co * 9;
-        const float* p01 = p00 + HEAD_NP;
-        const float* p10 = p00 + (HF_TX + 1) * HEAD_NP;
-        const float* p11 = p10 + HEAD_NP;
-        float o;
-        if (py == 0) o = px == 0 ? p00[4] : p00[5] + p01[3];
-        else o = px == 0 ? p00[7] + p10[1] : ((p00[8] + p01[6]) + p10[2]) + p11[0];
-        out[(((size_t)n * HEAD_NC + co) * Ho + 2 * qy + py) * Wo + 2 * qx + px] = o;
+    if constexpr (!LOSS) {
+      // combine: 2*HF_TY x 2*HF_TX outputs per class, consecutive lanes along x
+      for (int i = tid; i < HEAD_NC * 2 * HF_TY * 2 * HF_TX; i += 256) {
+        const int ox_l = i % (2 * HF_TX);
+        const int t2 = i / (2 * HF_TX);
+        const int oy_l = t2 % (2 * HF_TY), co = t2 / (2 * HF_TY);
+        const int qy_l = oy_l >> 1, py = oy_l & 1, qx_l = ox_l >> 1, px = ox_l & 1;
+        const int qy = y0 + qy_l, qx = x0 + qx_l;
+        if (qy < Hi && qx < Wi) {
+          const float* p00 = P + (qy_l * (HF_TX + 1) + qx_l) * HEAD_NP + co * 9;
+          const float* p01 = p00 + HEAD_NP;
+          const float* p10 = p00 + (HF_TX + 1) * HEAD_NP;
+          const float* p11 = p10 + HEAD_NP;
+          float o;
+          if (py == 0) o = px == 0 ? p00[4] : p00[5] + p01[3];
+          else o = px == 0 ? p00[7] + p10[1] : ((p00[8] + p01[6]) + p10[2]) + p11[0];
+          out[(((size_t)n * HEAD_NC + co) * Ho + 2 * qy + py) * Wo + 2 * qx + px] = o;
+        }
       }
+    } else {
+      // combine one output PIXEL per thread and pass (its three logits with the same addition order as above), then the loss on them
+      constexpr int NPIX = 2 * HF_TY * 2 * HF_TX;   // 512: two wave-uniform passes
+#pragma unroll
+      for (int it = 0; it < NPIX / 256; ++it) {
+        const int i = tid + it * 256;
+        const int ox_l = i % (2 * HF_TX), oy_l = i / (2 * HF_TX);
+        const int qy_l = oy_l >> 1, py = oy_l & 1, qx_l = ox_l >> 1, px = ox_l & 1;
+        const int qy = y0 + qy_l, qx = x0 + qx_l;
+        const bool ok = qy < Hi && qx < Wi;
+        float l[HEAD_NC] = {0.f, 0.f, 0.f};
+        int y = 0, am = 0;
+        if (ok) {
+#pragma unroll
+          for (int co = 0; co < HEAD_NC; ++co) {
+            const float* p00 = P + (qy_l * (HF_TX + 1) + qx_l) * HEAD_NP + co * 9;
+            const float* p01 = p00 + HEAD_NP;
+            const float* p10 = p00 + (HF_TX + 1) * HEAD_NP;
+            const float* p11 = p10 + HEAD_NP;
+            if (py == 0) l[co] = px == 0 ? p00[4] : p00[5] + p01[3];
+            else l[co] = px == 0 ? p00[7] + p10[1] : ((p00[8] + p01[6]) + p10[2]) + p11[0];
+          }
+          const size_t HWo = (size_t)Ho * Wo;
+          const size_t pix = (size_t)(2 * qy + py) * Wo + 2 * qx + px;
+          if (out != nullptr) {
+#pragma unroll
+            for (int co = 0; co < HEAD_NC; ++co) out[((size_t)n * HEAD_NC + co) * HWo + pix] = l[co];
+          }
+          const size_t gi = (size_t)n * HWo + pix;
+          y = head_load_label(hl.labels, hl.lbytes, gi);
+          float best = l[0];
+          if (l[1] > best) { best = l[1]; am = 1; }
+          if (l[2] > best) { best = l[2]; am = 2; }
+          const float e0 = expf(l[0] - best), e1 = expf(l[1] - best), e2 = expf(l[2] - best);
+          const float se = e0 + e1 + e2;
+          const float lse = best + logf(se);
+          float* gp = hl.dlogits != nullptr ? hl.dlogits + (size_t)n * HEAD_NC * HWo + pix : nullptr;
+          if ((unsigned)y < (unsigned)HEAD_NC) {
+            const float wy = hl.cw[y];
+            const float ly = y == 0 ? l[0] : (y == 1 ? l[1] : l[2]);
+            lsum += (double)(wy * (lse - ly));
+            if (gp != nullptr) {
+              const float inv = 1.0f / se;
+              const float sc = wy * hl.grad_scale;
+              gp[0] = sc * (e0 * inv - (y == 0 ? 1.f : 0.f));
+              gp[HWo] = sc * (e1 * inv - (y == 1 ? 1.f : 0.f));
+              gp[2 * HWo] = sc * (e2 * inv - (y == 2 ? 1.f : 0.f));
+            }
+          } else {   // a label outside [0, 3) poisons the loss and this pixel's gradient, as dc_wce_fused does
+            lsum += (double)__builtin_nanf("");
+            if (gp != nullptr) gp[0] = gp[HWo] = gp[2 * HWo] = __builtin_nanf("");
+          }
+          if (hl.pred != nullptr) hl.pred[gi] = am;
+        }
+        if (hl.counts != nullptr) {
+          const bool eq = ok && (am == y), ne = ok && (am != y);
+#pragma unroll
+          for (int j = 0; j < HEAD_NC; ++j) {
+            cnt[j] += __popcll(__ballot(eq && y == j));
+            cnt[3 + j] += __popcll(__ballot(ne && am == j));
+            cnt[6 + j] += __popcll(__ballot(ne && y == j));
+          }
+        }
+      }
+    }
+  }
+  if constexpr (LOSS) {
+    __syncthreads();                                  // P is dead: reuse its first bytes for the block's partial sums
+    double* s_loss = reinterpret_cast<double*>(smem);
+    unsigned long long* s_cnt = reinterpret_cast<unsigned long long*>(smem + 64);
+    lsum = wave_sum(lsum);
+    if (lane == 0) {
+      s_loss[wave] = lsum;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s_cnt[wave * 9 + k] = cnt[k];
+    }
+    __syncthreads();
+    if (tid == 0 && hl.loss_sum != nullptr) atomicAdd(hl.loss_sum, s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3]);
+    if (tid < 9 && hl.counts != nullptr) {
+      const unsigned long long c = s_cnt[tid] + s_cnt[9 + tid] + s_cnt[18 + tid] + s_cnt[27 + tid];
+      if (c) atomicAdd(&hl.counts[tid], c);
     }
   }
 }
@@ -520,10 +628,14 @@ static HeadWs head_ws(int dtype, int N, int Cin, int Hi, int Wi, void* base) {
 
 extern "C" size_t dc_head_workspace(int dtype, int N, int Cin, int Hi, int Wi) { return head_ws(dtype, N, Cin, Hi, Wi, nullptr).total; }
 
-extern "C" int dc_head_fwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* w,
-                           float* logits_nchw, void* workspace, void* stream) {
+extern "C" int dc_wce_fused(int B, int H, int W, const float* logits_nchw, const void* labels, int label_dtype_bytes,
+                            const float* class_weights, float grad_scale, double* loss_sum, float* dlogits, int64_t* pred,
+                            int64_t* counts, void* stream);
+
+static int head_fwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* w, float* logits_nchw,
+                         void* workspace, void* stream, const HeadLoss* hl) {
   if (int e = dc_check_view(x, ldx, Cin, dtype, "dc_head_fwd x")) return e;
-  DC_REQUIRE(w && logits_nchw && workspace && N > 0, "dc_head_fwd: bad argument");
+  DC_REQUIRE(w && workspace && N > 0, "dc_head_fwd: bad argument");
   DC_REQUIRE(((uintptr_t)logits_nchw & 7) == 0 && ((uintptr_t)workspace & 255) == 0, "dc_head_fwd: logits / workspace alignment");
   HeadWs ws = head_ws(dtype, N, Cin, Hi, Wi, workspace);
   hipStream_t st = (hipStream_t)stream;
@@ -534,18 +646,44 @@ extern "C" int dc_head_fwd(int dtype, int N, int Cin, int Hi, int Wi, const void
   if (dtype == DC_BF16 && g_head_fused && Cin == 256) {
     const int ntx = cdiv(Wi, HF_TX), nty = cdiv(Hi, HF_TY), strips = cdiv(ntx, HF_TILES);
     const size_t lds = (size_t)HF_MB * 16 * HEAD_NP * 4 + (size_t)HEAD_NP * Cin * 2;
-    DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(head_fused_fwd_kernel, dim3(strips * nty * N), dim3(256), lds, st, (const bf16*)x, ldx, (const bf16*)ws.wf, logits_nchw,
-                       N, Hi, Wi, Cin, ntx);
+    auto k0 = &head_fused_fwd_kernel<false>;
+    auto k1 = &head_fused_fwd_kernel<true>;
+    DC_ONCE({
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (hl != nullptr)
+      hipLaunchKernelGGL(k1, dim3(strips * nty * N), dim3(256), lds, st, (const bf16*)x, ldx, (const bf16*)ws.wf, logits_nchw, N, Hi, Wi, Cin, ntx, *hl);
+    else
+      hipLaunchKernelGGL(k0, dim3(strips * nty * N), dim3(256), lds, st, (const bf16*)x, ldx, (const bf16*)ws.wf, logits_nchw, N, Hi, Wi, Cin, ntx, HeadLoss{});
     DC_CHECK_LAUNCH();
     return 0;
   }
+  DC_REQUIRE(logits_nchw != nullptr, "dc_head_fwd: this configuration (fp32, or the unfused path) needs a logits buffer");
   dc_conv_desc d{dtype, 1, 1, 0, 1, 0, Cin, HEAD_NP};
   if (int e = dc_conv_fwd_f32out(&d, N, Hi, Wi, x, ldx, ws.wf, ws.P, HEAD_NP, stream)) return e;
   const long P = (long)N * Hi * Wi;
   hipLaunchKernelGGL(head_combine_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, (const float*)ws.P, logits_nchw, N, Hi, Wi);
   DC_CHECK_LAUNCH();
+  if (hl != nullptr)     // not the fused kernel: the separate pass over the logits
+    return dc_wce_fused(N, 2 * Hi, 2 * Wi, logits_nchw, hl->labels, hl->lbytes, hl->cw, hl->grad_scale, hl->loss_sum, hl->dlogits, hl->pred,
+                        (int64_t*)hl->counts, stream);
   return 0;
+}
+
+extern "C" int dc_head_fwd(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* w,
+                           float* logits_nchw, void* workspace, void* stream) {
+  DC_REQUIRE(logits_nchw != nullptr, "dc_head_fwd: null logits");
+  return head_fwd_impl(dtype, N, Cin, Hi, Wi, x, ldx, w, logits_nchw, workspace, stream, nullptr);
+}
+
+extern "C" int dc_head_fwd_loss(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* w, float* logits_nchw,
+                                void* workspace, const void* labels, int label_dtype_bytes, const float* class_weights, float grad_scale,
+                                double* loss_sum, float* dlogits, int64_t* pred, int64_t* counts, void* stream) {
+  DC_REQUIRE(labels && class_weights, "dc_head_fwd_loss: bad argument");
+  DC_REQUIRE(label_dtype_bytes == 1 || label_dtype_bytes == 4 || label_dtype_bytes == 8, "dc_head_fwd_loss: labels must be uint8, int32 or int64");
+  HeadLoss hl{labels, label_dtype_bytes, class_weights, grad_scale, loss_sum, dlogits, pred, (unsigned long long*)counts};
+  return head_fwd_impl(dtype, N, Cin, Hi, Wi, x, ldx, w, logits_nchw, workspace, stream, &hl);
 }
 
 extern "C" int dc_conv_dgrad_bnstats(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb,

@@ -230,6 +230,7 @@ class Engine:
         self._debug_skip_side = os.environ.get("DC_DEBUG_SKIP_SIDE", "0") == "1"
         self._debug_skip_kind = os.environ.get("DC_DEBUG_SKIP_KIND", "")     # "_conv" / "_dw": skip that kind of weight gradient (timing only)
         self.region_marks: Optional[list] = None      # bench.py sets a list to collect (name, event) at the encoder boundaries
+        self.loss_args: Optional[dict] = None         # set per call by nn.TrainStep (DC_FUSE_HEAD_LOSS): loss inside the classifier's kernel
 
     # ------------------------------------------------------------------------------------------------ helpers
     def pptr(self, name: str) -> C.c_void_p:
@@ -811,7 +812,17 @@ class Engine:
         def head_fwd():
             L.call("dc_head_fwd", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, self.pptr(wl), L.dptr(self.logits), hptr, self._st())
 
-        self.fwd_train.append(head_fwd)
+        def head_fwd_train():
+            # a fused train step (nn.TrainStep) hands the loss arguments over: the classifier's kernel then computes the weighted
+            # cross-entropy, its gradient, the argmax and the IoU counts on the logits it has in registers (dc_head_fwd_loss)
+            la = self.loss_args
+            if la is None:
+                return head_fwd()
+            L.call("dc_head_fwd_loss", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, self.pptr(wl), L.dptr(self.logits) if la["store_logits"] else None,
+                   hptr, L.dptr(la["labels"]), la["labels"].element_size(), L.dptr(la["weight"]), la["grad_scale"], L.dptr(la["loss_sum"]),
+                   L.dptr(self.dlogits), L.dptr(la["pred"]), L.dptr(la["counts"]), self._st())
+
+        self.fwd_train.append(head_fwd_train)
         self.fwd_eval.append(head_fwd)
 
         def head_bwd_make():

@@ -81,6 +81,7 @@ _SIGS = {
     "dc_stem_wgrad": (I, [I, I, I, I, I, P, P, I, P, P, P]),
     "dc_head_workspace": (SZ, [I, I, I, I, I]),
     "dc_head_fwd": (I, [I, I, I, I, I, P, I, P, P, P, P]),
+    "dc_head_fwd_loss": (I, [I, I, I, I, I, P, I, P, P, P, P, I, P, F, P, P, P, P, P]),
     "dc_head_bwd": (I, [I, I, I, I, I, P, I, P, P, P, I, P, P, P]),
     "dc_head_bwd_bnstats": (I, [I, I, I, I, I, P, I, P, P, P, I, P, P, P, I, P, P, P, P, I, P, P]),
     "dc_nchw_to_nhwc": (I, [I, I, I, I, I, P, P, I, P]),

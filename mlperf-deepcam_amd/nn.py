@@ -482,6 +482,11 @@ class TrainStep:
         self.counts = torch.zeros(9, dtype=torch.int64, device=dev) if with_metrics else None
         self.npix = batch * height * width
         self.after_backward = None      # set by attach_reducer
+        # loss inside the classifier's kernel (bf16 engine; DC_FUSE_HEAD_LOSS=0: the separate dc_wce_fused pass over stored logits);
+        # store_logits: also write the fp32 NCHW logits (nobody reads them in the fused step)
+        import os as _os
+        self.fuse_head_loss = net.act_dtype == torch.bfloat16 and _os.environ.get("DC_FUSE_HEAD_LOSS", "1") != "0"
+        self.store_logits = False
 
     def attach_reducer(self, reducer) -> None:
         """Data parallelism for the fused step: the reducer's buckets are all-reduced (SUM) while backward runs, the step
@@ -499,8 +504,24 @@ class TrainStep:
         self.loss_sum.zero_()
         if self.counts is not None:
             self.counts.zero_()
-        logits = eng.forward(x, train=True)
-        wce_fused(logits, labels, self.weight, dlogits=eng.dlogits, pred=self.pred, counts=self.counts, loss_sum=self.loss_sum)
+        if self.fuse_head_loss:
+            # the loss pass rides inside the classifier's forward kernel (dc_head_fwd_loss): the logits are neither stored nor re-read
+            t = labels.squeeze(1) if labels.dim() == 4 else labels
+            if t.dtype not in (torch.uint8, torch.int32, torch.int64):
+                t = t.long()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            if tuple(t.shape) != (eng.B, eng.H, eng.W):
+                raise L.DeepcamHipError(f"TrainStep: target shape {tuple(t.shape)} does not match the engine {(eng.B, eng.H, eng.W)}")
+            eng.loss_args = {"labels": t, "weight": _cw_tensor(self.weight, eng.device), "grad_scale": 1.0 / float(self.npix),
+                             "loss_sum": self.loss_sum, "pred": self.pred, "counts": self.counts, "store_logits": self.store_logits}
+            try:
+                eng.forward(x, train=True)
+            finally:
+                eng.loss_args = None
+        else:
+            logits = eng.forward(x, train=True)
+            wce_fused(logits, labels, self.weight, dlogits=eng.dlogits, pred=self.pred, counts=self.counts, loss_sum=self.loss_sum)
         eng.backward()
         if self.after_backward is not None:
             self.after_backward()

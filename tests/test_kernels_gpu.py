@@ -1084,6 +1084,55 @@ def test_head_fused_forward_matches_gemm_plus_combine(shape):
     assert_close(outs[0].cpu(), ref, torch.float32, f32=2e-4)
 
 
+@pytest.mark.parametrize("lab_dtype", [torch.int64, torch.uint8])
+@pytest.mark.parametrize("shape", [(2, 20, 70), (1, 9, 229), (1, 8, 32)], ids=["3x3tiles", "8tiles_wide", "one_exact_tile"])
+def test_head_forward_with_fused_loss(shape, lab_dtype):
+    """dc_head_fwd_loss = dc_head_fwd followed by dc_wce_fused: logits, logit gradient, predictions and IoU counts bit for bit, the
+    fp64 loss sum up to the order of its atomics; also with the logits not stored at all, and with an out-of-range label."""
+    N, H, W = shape
+    Cin, dtype = 256, torch.bfloat16
+    dt = L.dtype_code(dtype)
+    x = q(rnd(N, Cin, H, W, seed=1), dtype)
+    w = rnd(Cin, 3, 3, 3, seed=2, scale=0.05)
+    _, xv = to_nhwc(x, dtype)
+    wd = w.to(dev())
+    ws = torch.empty(L.load().dc_head_workspace(dt, N, Cin, H, W) + 256, dtype=torch.uint8, device=dev())
+    wsp = C.c_void_p((ws.data_ptr() + 255) // 256 * 256)
+    g = torch.Generator().manual_seed(7)
+    labels = torch.randint(0, 3, (N, 2 * H, 2 * W), generator=g).to(lab_dtype).to(dev())
+    cw = torch.tensor([0.9, 2.6, 1.7], device=dev())
+    scale = 1.0 / labels.numel()
+    ref_logits = torch.full((N, 3, 2 * H, 2 * W), float("nan"), device=dev())
+    L.call("dc_head_fwd", dt, N, Cin, H, W, vptr(xv), Cin, vptr(wd), vptr(ref_logits), wsp, S())
+    ref_ls = torch.zeros(1, dtype=torch.float64, device=dev())
+    ref_dl, ref_pred = torch.full_like(ref_logits, float("nan")), torch.full((N, 2 * H, 2 * W), -1, dtype=torch.int64, device=dev())
+    ref_cnt = torch.zeros(9, dtype=torch.int64, device=dev())
+    L.call("dc_wce_fused", N, 2 * H, 2 * W, vptr(ref_logits), vptr(labels), labels.element_size(), vptr(cw), scale, vptr(ref_ls), vptr(ref_dl),
+           vptr(ref_pred), vptr(ref_cnt), S())
+    for store in (True, False):
+        logits = torch.full_like(ref_logits, float("nan"))
+        ls = torch.zeros(1, dtype=torch.float64, device=dev())
+        dl, pred = torch.full_like(ref_logits, float("nan")), torch.full_like(ref_pred, -1)
+        cnt = torch.zeros(9, dtype=torch.int64, device=dev())
+        L.call("dc_head_fwd_loss", dt, N, Cin, H, W, vptr(xv), Cin, vptr(wd), vptr(logits) if store else None, wsp, vptr(labels),
+               labels.element_size(), vptr(cw), scale, vptr(ls), vptr(dl), vptr(pred), vptr(cnt), S())
+        torch.cuda.synchronize()
+        if store:
+            assert torch.equal(logits, ref_logits)
+        else:
+            assert torch.isnan(logits).all()
+        assert torch.equal(dl, ref_dl) and torch.equal(pred, ref_pred) and torch.equal(cnt, ref_cnt)
+        assert float(ls) == pytest.approx(float(ref_ls), rel=1e-12)
+    bad = labels.clone()
+    bad[0, 1, 2] = 7
+    ls = torch.zeros(1, dtype=torch.float64, device=dev())
+    dl = torch.zeros_like(ref_logits)
+    L.call("dc_head_fwd_loss", dt, N, Cin, H, W, vptr(xv), Cin, vptr(wd), None, wsp, vptr(bad), bad.element_size(), vptr(cw), scale, vptr(ls),
+           vptr(dl), None, None, S())
+    torch.cuda.synchronize()
+    assert torch.isnan(ls).all() and torch.isnan(dl[0, :, 1, 2]).all() and int(torch.isnan(dl).sum()) == 3
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_nchw_to_nhwc(dtype):
     x = rnd(2, 16, 9, 13, seed=1)
