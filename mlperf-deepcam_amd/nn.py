@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import lib as L
+from . import ops as _ops
 from .engine import Engine
 
 CLASS_FREQ = (0.986267818390377, 0.0004578708870701058, 0.01327431072255291)   # train_hdf5_ddp.py:206
@@ -67,8 +68,7 @@ def wce_fused(logit: torch.Tensor, target: torch.Tensor, weight: Sequence[float]
         raise L.DeepcamHipError(f"fp_loss: target shape {tuple(t.shape)} does not match logits {tuple(logit.shape)}")
     if loss_sum is None:
         loss_sum = torch.zeros(1, dtype=torch.float64, device=logit.device)
-    L.call("dc_wce_fused", B, H, W, L.dptr(logit), L.dptr(t), t.element_size(), L.dptr(_cw_tensor(weight, logit.device)),
-           1.0 / float(B * H * W), L.dptr(loss_sum), L.dptr(dlogits), L.dptr(pred), L.dptr(counts), L.stream_ptr())
+    _ops.OPS.wce_fused(logit, t, _cw_tensor(weight, logit.device), 1.0 / float(B * H * W), loss_sum, dlogits, pred, counts)
     return loss_sum
 
 
@@ -113,7 +113,7 @@ def compute_score(prediction, gt, num_classes=3, device_id=None, type="iou", wei
     g = gt if gt.dtype in (torch.uint8, torch.int32, torch.int64) else gt.long()
     g = g.contiguous()
     counts = torch.zeros(9, dtype=torch.int64, device=pred.device)
-    L.call("dc_confusion_counts", pred.numel(), L.dptr(pred), L.dptr(g), g.element_size(), L.dptr(counts), L.stream_ptr())
+    _ops.OPS.confusion_counts(pred, g, counts)
     return torch.tensor(iou_from_counts(counts.cpu().tolist()), dtype=torch.float32, device=pred.device)
 
 
@@ -125,7 +125,7 @@ class _NetFn(torch.autograd.Function):
     def forward(ctx, x, anchor, module):
         eng = module.engine_for(x)
         ctx.eng, ctx.module = eng, module
-        out = eng.forward(x, train=module.training)
+        out = _ops.OPS.net_forward(x, _ops.engine_handle(eng), module.training)
         if module.training:
             if len(_dlogits_for) > 64:           # engines come and go with input shapes: drop entries of freed buffers
                 _dlogits_for.clear()
@@ -135,9 +135,7 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         eng = ctx.eng
-        if dlogits.data_ptr() != eng.dlogits.data_ptr():
-            eng.dlogits.copy_(dlogits)
-        eng.backward()
+        _ops.OPS.net_backward(dlogits, _ops.engine_handle(eng))
         red = ctx.module._ddp_reducer
         if red is not None:
             # under dist.DistributedDataParallel: wait for the bucketed all-reduces launched during backward, re-arm the
@@ -246,7 +244,7 @@ class DeepLabv3_plus(torch.nn.Module):
             self.engine_for(input)
             return _NetFn.apply(input, self._anchor, self)
         eng = self.engine_for(input)
-        return eng.forward(input, train=self.training)
+        return _ops.OPS.net_forward(input, _ops.engine_handle(eng), self.training)
 
     def load_state_dict(self, state_dict, strict: bool = True):
         if self._primary is None:
@@ -316,6 +314,10 @@ class ArenaOptimizer:
         self._scalars_copied = torch.cuda.current_stream().record_event()
 
     def launch(self) -> None:
+        """optimizer.step() through the dispatcher: torch.ops.deepcam.optimizer_step."""
+        _ops.OPS.optimizer_step(_ops.optimizer_handle(self))
+
+    def _launch_kernels(self) -> None:
         g = self.param_groups[0]
         eng = self.engine
         n = eng.layout.n_params
@@ -482,6 +484,7 @@ class TrainStep:
         self.counts = torch.zeros(9, dtype=torch.int64, device=dev) if with_metrics else None
         self.npix = batch * height * width
         self.after_backward = None      # set by attach_reducer
+        self._eng_handle = _ops.engine_handle(self.eng)
         # loss inside the classifier's kernel (bf16 engine; DC_FUSE_HEAD_LOSS=0: the separate dc_wce_fused pass over stored logits);
         # store_logits: also write the fp32 NCHW logits (nobody reads them in the fused step)
         import os as _os
@@ -516,13 +519,13 @@ class TrainStep:
             eng.loss_args = {"labels": t, "weight": _cw_tensor(self.weight, eng.device), "grad_scale": 1.0 / float(self.npix),
                              "loss_sum": self.loss_sum, "pred": self.pred, "counts": self.counts, "store_logits": self.store_logits}
             try:
-                eng.forward(x, train=True)
+                _ops.OPS.net_forward(x, self._eng_handle, True)
             finally:
                 eng.loss_args = None
         else:
-            logits = eng.forward(x, train=True)
+            logits = _ops.OPS.net_forward(x, self._eng_handle, True)
             wce_fused(logits, labels, self.weight, dlogits=eng.dlogits, pred=self.pred, counts=self.counts, loss_sum=self.loss_sum)
-        eng.backward()
+        _ops.OPS.net_backward(eng.dlogits, self._eng_handle)
         if self.after_backward is not None:
             self.after_backward()
         self.opt.launch()

@@ -56,3 +56,17 @@ def test_host_side_geometry_without_gpu():
     assert lib.dc_conv_stat_rows(C.byref(d), 1, 5, 5) == 1
     with pytest.raises(L.DeepcamHipError):
         L.call("dc_conv_dgrad", C.byref(d), 1, 5, 5, None, 64, None, None, 64, 0, None)
+
+
+def test_torch_custom_ops_are_registered():
+    """north_star: the host calls the HIP path "through custom ops": nn.py reaches the step's operators as torch.ops.deepcam.*
+    (mlperf-deepcam_amd/ops.py), each of them a dispatcher entry over the C ABI."""
+    import torch
+    from mlperf_deepcam_amd import ops  # noqa: F401
+    for name in ("net_forward", "net_backward", "wce_fused", "confusion_counts", "optimizer_step"):
+        op = getattr(torch.ops.deepcam, name)
+        assert "deepcam::" + name in str(op.default._schema)
+    with pytest.raises(L.DeepcamHipError):
+        torch.ops.deepcam.optimizer_step(12345)              # an unknown handle fails loudly
+    with pytest.raises(L.DeepcamHipError):
+        torch.ops.deepcam.net_forward(torch.zeros(1, 16, 16, 16), 999, False)
