@@ -52,6 +52,10 @@ int launch_igemm256(const IgemmParams& p, hipStream_t st);
 void igemm256_set_epilogue(int v);
 void igemm256_set_phase_fast(int v);
 void igemm256_set_tile2d(int v);
+int igemm256_phase_fast_enabled();
+// igemm256p.hip: persistent form (one workgroup per CU walks its tiles; the ring never drains between tiles)
+bool igemm256p_eligible(const IgemmParams& p);
+int launch_igemm256p(const IgemmParams& p, int workgroups, hipStream_t st);
 // workgroups the 256-tile kernel would launch for this problem
 inline long igemm256_tiles(const IgemmParams& p) {
   return (long)((p.g.Cout + 255) / 256) * ((p.M - p.m_beg + 255) / 256) * p.g.os * p.g.os * (p.ngroup > 1 ? p.ngroup : 1);

@@ -537,6 +537,9 @@ static int g_rel256 = 0;   // 0: model below; otherwise cost of a 256-tile round
 // 2 / 3: whenever eligible with 256- / 128-pixel tiles (tests and A/B runs).  Costs are in rounds of 256 x 256 tiles: a
 // 256 x 384 tile is 1.5 of them, a 128 x 384 tile 0.8 (its weight fill is not halved), a round of the 128-tile kernel about 1 at
 // the K depths in question (see igemm256_wins).  The layer must also fill most of the chip with its one workgroup per CU.
+static int g_igemm256p = 1;          // persistent 256-tile kernel for multi-round launches (A/B switch "igemm256p")
+static int g_igemm256p_wgs = 0;      // its workgroups ("igemm256p_wgs"); 0: fewest that keep the number of rounds
+static int g_igemm256p_min = 257;    // fewest tiles it is used for ("igemm256p_min")
 static int g_pw384 = 1;
 static int pw384_plan(const IgemmParams& p) {
   if (g_pw384 == 0 || !pw384_eligible(p)) return 0;
@@ -636,6 +639,8 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
           return launch_igemm<bf16, false>(b, st);
         }
       }
+      // several rounds of tiles: the persistent form keeps the operand ring full across tiles (igemm256p.hip)
+      if (g_igemm256p && bst == nullptr && igemm256p_eligible(p) && igemm256_tiles(p) >= (long)g_igemm256p_min) return launch_igemm256p(p, g_igemm256p_wgs, st);
       return launch_igemm256(p, st);
     }
   }
@@ -886,6 +891,9 @@ extern "C" int dc_set_option(const char* name, int value) {
   }
   if (name != nullptr && strcmp(name, "igemm256") == 0) { g_igemm256 = value; return 0; }
   if (name != nullptr && strcmp(name, "pw384") == 0) { g_pw384 = value; return 0; }
+  if (name != nullptr && strcmp(name, "igemm256p") == 0) { g_igemm256p = value; return 0; }
+  if (name != nullptr && strcmp(name, "igemm256p_wgs") == 0) { g_igemm256p_wgs = value; return 0; }
+  if (name != nullptr && strcmp(name, "igemm256p_min") == 0) { g_igemm256p_min = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_tile2d") == 0) { igemm256_set_tile2d(value); return 0; }
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }

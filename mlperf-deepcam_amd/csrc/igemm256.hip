@@ -600,6 +600,7 @@ static int g_tile2d = 0;
 void igemm256_set_tile2d(int v) { g_tile2d = v ? 1 : 0; }
 static int g_phase_fast = 1;     // tile order of multi-phase (transposed / strided) launches: phase fastest (A/B switch "igemm256_phase_fast")
 void igemm256_set_phase_fast(int v) { g_phase_fast = v ? 1 : 0; }
+int igemm256_phase_fast_enabled() { return g_phase_fast; }
 
 int launch_igemm256(const IgemmParams& p_in, hipStream_t st) {
   const size_t lds = (size_t)MAIN_BYTES + 128;

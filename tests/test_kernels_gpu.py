@@ -252,6 +252,74 @@ def test_conv_2d_pixel_tiles_same_bits(case):
         assert (a - b).abs().max().item() <= 2e-5 * (a.abs().max().item() + 1e-12) + 1e-6
 
 
+PERSIST_CASES = [
+    # name, k, stride, pad, dil, transposed, cin, cout, N, H, W, workgroups
+    ("pw_ragged", 1, 1, 0, 1, 0, 728, 728, 2, 40, 52, 8),          # ragged K (728 = 22.75 chunks), ragged channel and pixel tiles
+    ("pw_two_rounds", 1, 1, 0, 1, 0, 256, 512, 2, 48, 64, 16),     # 48 tiles on 16 workgroups: three tiles each
+    ("dense3x3", 3, 1, 1, 1, 0, 72, 264, 2, 32, 48, 8),
+    ("atrous6", 3, 1, 6, 6, 0, 64, 256, 1, 48, 32, 8),
+    ("convT_phases", 3, 2, 1, 1, 1, 256, 256, 2, 16, 32, 8),       # 1/2/2/4 taps per output parity class, tiles of different K
+    ("stride2", 3, 2, 1, 1, 0, 128, 256, 2, 32, 48, 8),
+    ("one_tile_each", 1, 1, 0, 1, 0, 128, 256, 1, 32, 64, 8),      # 8 tiles on 8 workgroups: no tile switch at all
+]
+
+
+@pytest.mark.parametrize("case", PERSIST_CASES, ids=[c[0] for c in PERSIST_CASES])
+def test_conv_persistent_tiles_same_bits(case):
+    """The persistent 256-tile kernel (igemm256p.hip: a workgroup walks several tiles, the operand ring never drains) against the
+    one-tile-per-workgroup kernel: outputs and data gradients bit for bit, BatchNorm sums up to the order of the additions, nothing
+    written outside the tensor's own channels."""
+    name, k, stride, pad, dil, tr, cin, cout, N, H, W, wgs = case
+    dtype = torch.bfloat16
+    d = desc(dtype, k, stride, pad, dil, tr, cin, cout)
+    kk = 3 if tr else k
+    wshape = (cin, cout, kk, kk) if tr else (cout, cin, kk, kk)
+    x = q(rnd(N, cin, H, W, seed=1), dtype)
+    w = rnd(*wshape, seed=2, scale=(cin * kk * kk) ** -0.5)
+    Ho, Wo = C.c_int(), C.c_int()
+    L.call("dc_conv_out_hw", C.byref(d), H, W, C.byref(Ho), C.byref(Wo))
+    Ho, Wo = Ho.value, Wo.value
+    gy = q(rnd(N, cout, Ho, Wo, seed=3), dtype)
+    nwf, nwb = C.c_size_t(), C.c_size_t()
+    L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
+    wf = torch.empty(nwf.value, dtype=dtype, device=dev())
+    wb = torch.empty(nwb.value, dtype=dtype, device=dev())
+    L.call("dc_conv_pack_weights", C.byref(d), vptr(w.to(dev())), vptr(wf), vptr(wb), S())
+    _, xv = to_nhwc(x, dtype, ld=cin + 16, off=8)
+    _, gyv = to_nhwc(gy, dtype)
+    rows = L.load().dc_conv_stat_rows(C.byref(d), N, H, W)
+    got = []
+    try:
+        L.call("dc_set_option", b"igemm256", 2)
+        L.call("dc_set_option", b"igemm256p_min", 1)
+        L.call("dc_set_option", b"igemm256p_wgs", wgs)
+        for persistent in (0, 1):
+            L.call("dc_set_option", b"igemm256p", persistent)
+            ybuf, yv = empty_nhwc(N, Ho, Wo, cout, dtype, ld=cout + 24, off=16)
+            slab = torch.full((2, rows, cout), float("nan"), device=dev())
+            L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, vptr(slab), 0, S())
+            ybuf2, yv2 = empty_nhwc(N, Ho, Wo, cout, dtype, ld=cout + 24, off=16)          # without statistics: the other instantiation
+            L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv2), cout + 24, None, 0, S())
+            gbuf, gxv = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
+            L.call("dc_conv_dgrad", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(gxv), cin + 8, 0, S())
+            torch.cuda.synchronize()
+            for b in (ybuf, ybuf2):
+                assert torch.isnan(b[..., :16].float()).all() and torch.isnan(b[..., 16 + cout:].float()).all()
+            assert torch.isnan(gbuf[..., cin:].float()).all()
+            got.append((from_nhwc(yv), from_nhwc(yv2), from_nhwc(gxv), slab.double().sum(1).cpu()))
+    finally:
+        L.call("dc_set_option", b"igemm256", 1)
+        L.call("dc_set_option", b"igemm256p", 1)
+        L.call("dc_set_option", b"igemm256p_min", 257)          # the library's defaults
+        L.call("dc_set_option", b"igemm256p_wgs", 0)
+    assert_close(got[0][0], conv_ref(x, q(w, dtype), None, k, stride, pad, dil, tr), dtype)
+    for i in range(3):
+        assert torch.equal(got[0][i], got[1][i]), f"output {i} differs"
+    a, b = got[0][3], got[1][3]
+    assert not torch.isnan(b).any()
+    assert (a - b).abs().max().item() <= 2e-5 * (a.abs().max().item() + 1e-12) + 1e-6
+
+
 BNSTAT_CASES = [
     # name, k, stride, pad, dil, transposed, cin, cout, N, H, W
     ("dense3x3", 3, 1, 1, 1, 0, 256, 256, 2, 12, 20),
