@@ -262,8 +262,9 @@ def main():
     barrier()
     if rank == 0:
         peak = PEAK[a.dtype]
-        names = {"igemm": f"dc::igemm256_kernel + dc::pw384_kernel + dc::igemm_kernel<{a.dtype}> (dense conv forward + data gradient: gather-form "
-                          "implicit GEMM; 256x256 / 256x384 eight-wave or 128x128 four-wave tile per layer)",
+        names = {"igemm": f"dc::igemm256_kernel + dc::igemm256p_kernel + dc::pw384_kernel + dc::igemm_kernel<{a.dtype}> (dense conv forward + data "
+                          "gradient: gather-form implicit GEMM; 256x256 (one tile per workgroup or persistent) / 256x384 eight-wave or 128x128 "
+                          "four-wave tile per layer)",
                  "wgrad": f"dc::wgrad256_kernel + dc::wgrad_dma_kernel<{a.dtype}> + dc::wgrad_reduce_kernel (dense conv weight gradient)"}
         dom = max(fams, key=lambda f: fams[f][1])
         def entry(f, src=None):

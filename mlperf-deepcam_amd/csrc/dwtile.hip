@@ -22,6 +22,9 @@ namespace dc {
 #define DT_TH_VALUE 8
 #endif
 constexpr int DT_TH = DT_TH_VALUE;   // tile rows
+#ifndef DT_PROBE_KY
+#define DT_PROBE_KY 3                // diagnostic builds only: stencil rows the forward / data-gradient loop executes (arithmetic share)
+#endif
 
 template <int DIL, int CG>
 struct TileCfg {
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
       }
     }
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
+    for (int ky = 0; ky < DT_PROBE_KY; ++ky) {
 #pragma unroll
       for (int c = 0; c < WC; ++c) {
         float f[KH];
