@@ -26,6 +26,9 @@ constexpr int WROW = WT * 2;       // bytes per LDS row (one pixel, 256 channels
 constexpr int WOPER = WBP * WROW;  // 16 KiB
 constexpr int WSTAGE = 2 * WOPER;
 constexpr int WNST = 4;
+#ifndef DC_WG256_PROBE
+#define DC_WG256_PROBE 0     // diagnostic builds only (scripts/wgrad256_probe.py): 1 = no LDS-DMA, 2 = no LDS fragment reads, 8 = no slab stores
+#endif
 
 static __device__ __attribute__((aligned(256))) unsigned char wg256_zero_page[256];
 typedef __attribute__((address_space(1))) const void* gas_ptr;
@@ -48,6 +51,12 @@ __device__ inline int swz_key(int row) { return (row & 3) | (((row >> 3) & 1) <<
 
 // one MFMA operand fragment (16 channels of chunk `c`, the 8 pixels 8*fg .. 8*fg+7 of the stage) from a [pixel][channel] tile
 __device__ inline vec16 tr_frag(const char* tile, int c, int prow, int key0, int key1, int tp) {
+  if (DC_WG256_PROBE & 2) {
+    vec16 f;
+    f.w[0] = f.w[1] = f.w[2] = f.w[3] = 0x3f803f80u + (unsigned)c;
+    asm volatile("" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]));
+    return f;
+  }
   const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(tile + prow * WROW + ((c ^ key0) << 5) + 8 * tp));
   const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(tile + (prow + 4) * WROW + ((c ^ key1) << 5) + 8 * tp));
   const uint2 t0 = __builtin_bit_cast(uint2, a0), t1 = __builtin_bit_cast(uint2, a1);
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_)
     for (int i = 0; i < 2; ++i) {
       const int j = 2 * wave + i;
       const int m = mbeg + istage * WBP + 2 * j + lrow;
-      __builtin_amdgcn_global_load_lds(pick((m < mend) & cq_ok[i], dg + offq[i]), (lds_ptr)(q + j * 1024), 16, 0, 0);
+      if (!(DC_WG256_PROBE & 1)) __builtin_amdgcn_global_load_lds(pick((m < mend) & cq_ok[i], dg + offq[i]), (lds_ptr)(q + j * 1024), 16, 0, 0);
     }
   };
   auto issue_p = [&](int slot) {
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_)
       const int m = mbeg + istage * WBP + 2 * j + lrow;
       const int iy = rqy[i] * g.is + tap.dy, ix = rqx[i] * g.is + tap.dx;
       const bool ok = (m < mend) & cp_ok[i] & ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
-      __builtin_amdgcn_global_load_lds(pick(ok, xg + offp[i]), (lds_ptr)(x_ + j * 1024), 16, 0, 0);
+      if (!(DC_WG256_PROBE & 1)) __builtin_amdgcn_global_load_lds(pick(ok, xg + offp[i]), (lds_ptr)(x_ + j * 1024), 16, 0, 0);
       // advance this row by one stage
       rqx[i] += WBP;
       if (rqx[i] < g.Qw) {
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ci = ci0 + wp * 64 + j * 16 + fr;
-        if (ci < g.Cin) out[(size_t)co * g.Cin + ci] = acc[i][j][r];
+        if (ci < g.Cin && (!(DC_WG256_PROBE & 8) || acc[i][j][r] == 123.f)) out[(size_t)co * g.Cin + ci] = acc[i][j][r];
       }
     }
 }
