@@ -88,11 +88,12 @@ def test_forward_backward_vs_oracle(oracle_small, dtype, ltol):
         assert worst[1] < 8e-2, f"worst gradient {worst}"
         assert total < 3e-2
     else:
-        # a descent direction of the right magnitude, no more (measured at this size: cosine 0.18, norm ratio 0.85)
+        # a descent direction of the right magnitude, no more (measured at this size: cosine 0.1786, norm ratio 0.8462; the run is
+        # deterministic, so the bounds sit just outside the measured values: ADVICE r02)
         cos = float((allg.double() @ allr.double()) / (allg.double().norm() * allr.double().norm()))
         ratio = float(allg.double().norm() / allr.double().norm())
         print(f"[bf16] loss {loss:.7f} vs {loss_ref:.7f}; gradient cosine with the oracle {cos:.4f}, norm ratio {ratio:.4f}")
-        assert cos > 0.05 and 0.6 < ratio < 1.4
+        assert cos > 0.15 and 0.78 < ratio < 0.95
     # BatchNorm running statistics were updated exactly once
     for k in ("xception_features.bn1", "xception_features.block4.rep.2", "global_avg_pool.2", "upsample.deconv3.1"):
         np.testing.assert_allclose(eng.buffer_view(k + ".running_mean").cpu().numpy(), sd[k + ".running_mean"].numpy(),
@@ -393,6 +394,60 @@ def _shared_point_engines(B, H, W):
     e32.backward()
     torch.cuda.synchronize()
     return e16, e32
+
+
+def _stage_of(name):
+    """Stored activation / coefficient name -> the part of the network it belongs to."""
+    if name.startswith("xception_features."):
+        rest = name[len("xception_features."):]
+        if rest.startswith("block"):
+            b = int(rest[5:].split(".")[0])
+            return "entry" if b <= 3 else ("middle" if b <= 19 else "exit")
+        return "entry" if rest[:5] in ("conv1", "conv2", "bn1.", "bn2.") or rest.startswith(("conv1", "conv2", "bn1", "bn2")) else "exit"
+    if name.startswith(("aspp", "global_avg_pool", "conv1", "bn1")):
+        return "aspp"
+    return "decoder"
+
+
+def test_forward_activations_by_stage_bf16_vs_fp32_full_size():
+    """The bf16 FORWARD kernels stage by stage: both engines run on bf16-rounded weights and the same input, each on its
+    own; every stored activation of the bf16 engine is compared with the fp32 engine's.  The error grows along the network (every
+    layer rounds its output to bf16 and the BatchNorms renormalise), so the bound is per stage; a wrong kernel in one stage shows as
+    a jump there rather than as a loss within north_star's 1e-3."""
+    B, H, W = 2, 768, 1152
+    x, _ = make_inputs(B, H, W)
+    worst = {}
+    e32 = Engine(B, H, W, torch.float32, seed=333)
+    e32.params.copy_(e32.params.to(torch.bfloat16).float())
+    e32.mark_weights_changed()
+    e32.forward(x.to(DEV), train=True)
+    torch.cuda.synchronize()
+    ref = {k: t.float().cpu() for k, t in e32.saved.items()}
+    del e32
+    torch.cuda.empty_cache()
+    e16 = Engine(B, H, W, torch.bfloat16, seed=333)
+    e16.params.copy_(e16.params.to(torch.bfloat16).float())
+    e16.mark_weights_changed()
+    e16.forward(x.to(DEV), train=True)
+    torch.cuda.synchronize()
+    assert set(ref) == set(e16.saved)
+    for k, t in e16.saved.items():
+        # forward activations only (the gradient buffers are registered under the same dictionary and hold nothing yet); the
+        # per-channel coefficient vectors are covered through the activations they produce
+        if t.numel() < 4096 or not k.startswith(("xception_features.", "aspp", "global_avg_pool", "conv1", "bn1", "conv2", "bn2", "last_conv", "upsample")):
+            continue
+        err = _rel_l2(t.float().cpu(), ref[k])
+        st = _stage_of(k)
+        if err > worst.get(st, ("", 0.0))[1]:
+            worst[st] = (k, err)
+    print("[bf16 vs fp32 forward, stored activations, worst relative L2 per stage]", worst)
+    assert set(worst) >= {"entry", "middle", "exit", "aspp", "decoder"}, sorted(worst)
+    # measured (worst tensor per stage): entry 2.3e-2 (block3), middle 0.19 (block19), exit 0.27 (bn5), ASPP 0.36, decoder 0.46 -- the
+    # network amplifies every rounding (profiles/sensitivity_r01.txt), so only the entry flow is a sharp check; behind it the bounds
+    # separate "bf16 noise, amplified" from a kernel that computes something else (error of order 1 from the first layer it touches)
+    bound = {"entry": 4e-2, "middle": 0.3, "exit": 0.4, "aspp": 0.5, "decoder": 0.6}
+    for st, (k, err) in worst.items():
+        assert err < bound[st], (st, k, err)
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (2, 768, 1152)], ids=["small", "full"])
