@@ -1,0 +1,56 @@
+"""Static checks of the gfx950 code the compiler produces for the kernels whose speed depends on it (no GPU needed: hipcc cross-compiles).
+
+The persistent 256 x 256 implicit-GEMM kernel (igemm256p.hip) runs its K loops at the register limit.  A register spill inside a K loop is a
+scratch load followed by `s_waitcnt vmcnt(0)`, i.e. a wait for every LDS-DMA in flight, once per K step; whether the compiler spills there
+changes with small edits (the first builds of that kernel held 3 - 27 scratch instructions per step).  The results stay correct either way, so
+only this test notices."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "mlperf-deepcam_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _device_asm(src, tmp_path):
+    out = os.path.join(str(tmp_path), os.path.basename(src) + ".s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                    os.path.join(CSRC, src), "-o", out], check=True, capture_output=True, timeout=600)
+    return open(out).read()
+
+
+def _kernels(asm, name):
+    """{mangled name: body lines} of every kernel whose mangled name contains `name`."""
+    out = {}
+    for m in re.finditer(r"^(_Z\w*%s\w*):" % name, asm, re.M):
+        end = asm.index("s_endpgm", m.end())
+        out[m.group(1)] = asm[m.end():end].split("\n")
+    return out
+
+
+def _loops(lines):
+    """(begin, end) line ranges of backward branches."""
+    labels = {m.group(1): n for n, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    for n, l in enumerate(lines):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if m and labels.get(m.group(1), n) < n:
+            yield labels[m.group(1)], n
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_persistent_gemm_k_loops_hold_no_spills(tmp_path):
+    kernels = _kernels(_device_asm("igemm256p.hip", tmp_path), "igemm256p_kernel")
+    assert len(kernels) == 2, sorted(kernels)
+    for name, lines in kernels.items():
+        mfma_loops = [(a, b) for a, b in _loops(lines) if any("v_mfma" in x for x in lines[a:b])]
+        assert mfma_loops, name
+        for a, b in mfma_loops:
+            body = lines[a:b]
+            assert not any("scratch_" in x for x in body), f"{name}: scratch access inside the K loop at asm lines {a}-{b}"
+            assert not any("v_accvgpr" in x for x in body), f"{name}: accumulator shuffling inside the K loop at asm lines {a}-{b}"
+        # outside the loops: the state handed from the first instantiation of the tile loop to the second, once per launch
+        assert sum("scratch_" in x for x in lines) <= 32, name
