@@ -246,6 +246,23 @@ int dc_head_bwd_bnstats(int dtype, int N, int Cin, int Hi, int Wi, const void* x
                         const float* bn_mean, const float* bn_invstd, const float* bn_mscale, const float* bn_mshift,
                         int bn_relu, float* bn_slab, void* stream);
 
+/* The head on a BatchNorm(+ReLU) output that is never stored (upsample.deconv3's BatchNorm2d + ReLU in front of last_deconv,
+ * deeplab_xception.py:371-374): y is the raw output of the convolution in front of that BatchNorm, scale / shift its forward
+ * coefficients (dc_bn_finalize / dc_bn_eval_coeffs); the head forms act(y * scale + shift) while loading (fp32 fma, rounded to bf16:
+ * the bits dc_bn_apply would have stored), so dc_bn_apply + dc_head_fwd[_loss] and these calls give the same logits bit for bit.
+ * bf16, Cin = 256 only (the fused head kernel). */
+int dc_head_fwd_bnin(int dtype, int N, int Cin, int Hi, int Wi, const void* y, int ldy, const float* scale, const float* shift,
+                     int relu, const float* w, float* logits_nchw, void* workspace, void* stream);
+int dc_head_fwd_loss_bnin(int dtype, int N, int Cin, int Hi, int Wi, const void* y, int ldy, const float* scale, const float* shift,
+                          int relu, const float* w, float* logits_nchw, void* workspace, const void* labels, int label_dtype_bytes,
+                          const float* class_weights, float grad_scale, double* loss_sum, float* dlogits, int64_t* pred,
+                          int64_t* counts, void* stream);
+/* dc_head_bwd for that case: the weight gradient forms the head's input from y itself (register-staged 128-tile kernel); bn_slab != NULL
+ * also leaves the BatchNorm's backward sums there as dc_head_bwd_bnstats does (bn_mean / bn_invstd then required). */
+int dc_head_bwd_bnin(int dtype, int N, int Cin, int Hi, int Wi, const void* y, int ldy, const float* scale, const float* shift,
+                     int relu, const float* dlogits_nchw, const float* w, void* dx, int lddx, float* grad_w, void* workspace,
+                     const float* bn_mean, const float* bn_invstd, float* bn_slab, void* stream);
+
 /* NCHW fp32 (the layout train_hdf5_ddp.py:348 hands over) -> NHWC `dtype`: the one layout pass of the step. */
 int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, void* out, int ldo, void* stream);
 

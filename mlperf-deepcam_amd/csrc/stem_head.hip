@@ -2,6 +2,7 @@
 //   stem  Conv2d(16->32, k3, s2, p1) that reads the caller's NCHW fp32 batch in place (no layout pass) and writes NHWC
 //   head  ConvTranspose2d(256->3, k3, s2, p1, op1) that reads NHWC and writes the NCHW fp32 logits of the reference API
 #include "common.h"
+#include "wgrad.h"
 
 namespace dc {
 
@@ -234,6 +235,15 @@ constexpr int HF_TILES = 6;                             // tiles per workgroup (
 // LOSS: the weighted cross-entropy pass (loss.hip: wce_kernel, same arithmetic statement for statement, so the same bits) runs on the
 // logits of a tile while they are still in registers: the fp32 NCHW logits are then written only if the caller wants them (`out`
 // may be null) and never read back (reference: upsample.last_deconv, deeplab_xception.py:374,382, followed by utils/losses.py:35-50).
+// BNIN: x is the raw output y of the convolution in front of a BatchNorm(+ReLU) and the head's real input act(y * scale + shift) is formed
+// while the fragments are loaded (fp32 fma, ReLU, rounded to bf16: the bits dc_bn_apply would have stored), so that activation is never
+// written (906 MB per local-batch-8 step and the same again read by the apply pass).  scale / shift sit in LDS behind the weight image.
+struct HeadBnIn {
+  const float* scale;
+  const float* shift;
+  int relu;
+};
+
 struct HeadLoss {
   const void* labels;
   int lbytes;
@@ -253,14 +263,22 @@ __device__ inline int head_load_label(const void* labels, int bytes, size_t i) {
   return (v >= 0 && v < HEAD_NC) ? (int)v : -1;
 }
 
-template <bool LOSS>
+template <bool LOSS, bool BNIN = false>
 __global__ __launch_bounds__(256) void head_fused_fwd_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ wf,
-                                                             float* __restrict__ out, int N, int Hi, int Wi, int Cin, int ntx, const HeadLoss hl) {
+                                                             float* __restrict__ out, int N, int Hi, int Wi, int Cin, int ntx, const HeadLoss hl,
+                                                             const HeadBnIn bi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* P = reinterpret_cast<float*>(smem);                       // [HF_MB*16][HEAD_NP]
   char* wl = smem + HF_MB * 16 * HEAD_NP * 4;                      // weight image [32][Cin] bf16, 64-byte K rows swizzled per 16-B slot
+  [[maybe_unused]] float* bnv = reinterpret_cast<float*>(wl + HEAD_NP * Cin * 2);   // BNIN: scale[Cin], shift[Cin]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
+  if constexpr (BNIN) {
+    for (int i = tid; i < Cin; i += 256) {
+      bnv[i] = bi.scale[i];
+      bnv[Cin + i] = bi.shift[i];
+    }
+  }
   // stage the weights: row j (product), K step k, slot s  ->  wl[(k*32 + j)*64 + ((s ^ ((j >> 1) & 3)) << 4)]
   for (int i = tid; i < HEAD_NP * Cin / 8; i += 256) {
     const int j = i / (Cin / 8), v = i % (Cin / 8);
@@ -284,6 +302,7 @@ __global__ __launch_bounds__(256) void head_fused_fwd_kernel(const bf16* __restr
     __syncthreads();   // weights staged (first pass) / the previous tile's combine is done with P
     // A fragments of row block mb: this lane's pixel, its 16-byte K group of each of the 8 K steps (Cin = 256); the next block's
     // loads are in flight while the current one is multiplied
+    // (BNIN: the validity of a block's rows travels with it: a padding row must stay zero, not act(shift))
     auto load_block = [&](int mb, vec16 (&fa)[8]) {
       const int idx = mb * 16 + fr;
       const int ry = idx / (HF_TX + 1), rx = idx - ry * (HF_TX + 1);
@@ -292,19 +311,41 @@ __global__ __launch_bounds__(256) void head_fused_fwd_kernel(const bf16* __restr
       const bf16* src = x + (((size_t)n * Hi + (ok ? qy : 0)) * Wi + (ok ? qx : 0)) * ldx + fg * 8;
 #pragma unroll
       for (int u = 0; u < 8; ++u) fa[u] = ok ? ldg16(src + u * 32) : zero16();
+      return ok;
     };
     vec16 cur[8], nxt[8];
-    if (wave < HF_MB) load_block(wave, cur);
+    [[maybe_unused]] bool cur_ok = false, nxt_ok = false;
+    if (wave < HF_MB) cur_ok = load_block(wave, cur);
     for (int mb = wave; mb < HF_MB; mb += 4) {
-      if (mb + 4 < HF_MB) load_block(mb + 4, nxt);
+      if (mb + 4 < HF_MB) nxt_ok = load_block(mb + 4, nxt);
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const char* wk = wl + u * 32 * 64;
         const vec16 b0 = *reinterpret_cast<const vec16*>(wk + fr * 64 + ((fg ^ ((fr >> 1) & 3)) << 4));
         const vec16 b1 = *reinterpret_cast<const vec16*>(wk + (16 + fr) * 64 + ((fg ^ (((16 + fr) >> 1) & 3)) << 4));
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[u]), __builtin_bit_cast(bf16x8, b0), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur[u]), __builtin_bit_cast(bf16x8, b1), acc1, 0, 0, 0);
+        vec16 av = cur[u];
+        if constexpr (BNIN) {
+          // this lane's channels of K step u: u * 32 + fg * 8 .. + 7
+          const float* sc = bnv + u * 32 + fg * 8;
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+          const f32x4 h0 = *reinterpret_cast<const f32x4*>(sc + Cin), h1 = *reinterpret_cast<const f32x4*>(sc + Cin + 4);
+          float f[8];
+          unpack(av, f, bf16());
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f[e] = fmaf(f[e], s0[e], h0[e]);
+            f[4 + e] = fmaf(f[4 + e], s1[e], h1[e]);
+          }
+          if (bi.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+          }
+          pack(av, f, bf16());
+          if (!cur_ok) av = zero16();
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b0), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b1), acc1, 0, 0, 0);
       }
       // D[row = pixel fg*4 + r][col = product fr]
 #pragma unroll
@@ -314,6 +355,7 @@ __global__ __launch_bounds__(256) void head_fused_fwd_kernel(const bf16* __restr
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+      cur_ok = nxt_ok;
     }
     __syncthreads();
     if constexpr (!LOSS) {
@@ -633,7 +675,7 @@ extern "C" int dc_wce_fused(int B, int H, int W, const float* logits_nchw, const
                             int64_t* counts, void* stream);
 
 static int head_fwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* w, float* logits_nchw,
-                         void* workspace, void* stream, const HeadLoss* hl) {
+                         void* workspace, void* stream, const HeadLoss* hl, const HeadBnIn* bi = nullptr) {
   if (int e = dc_check_view(x, ldx, Cin, dtype, "dc_head_fwd x")) return e;
   DC_REQUIRE(w && workspace && N > 0, "dc_head_fwd: bad argument");
   DC_REQUIRE(((uintptr_t)logits_nchw & 7) == 0 && ((uintptr_t)workspace & 255) == 0, "dc_head_fwd: logits / workspace alignment");
@@ -645,20 +687,33 @@ static int head_fwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* 
   DC_CHECK_LAUNCH();
   if (dtype == DC_BF16 && g_head_fused && Cin == 256) {
     const int ntx = cdiv(Wi, HF_TX), nty = cdiv(Hi, HF_TY), strips = cdiv(ntx, HF_TILES);
-    const size_t lds = (size_t)HF_MB * 16 * HEAD_NP * 4 + (size_t)HEAD_NP * Cin * 2;
+    const size_t lds = (size_t)HF_MB * 16 * HEAD_NP * 4 + (size_t)HEAD_NP * Cin * 2 + (size_t)2 * Cin * 4;
     auto k0 = &head_fused_fwd_kernel<false>;
     auto k1 = &head_fused_fwd_kernel<true>;
+    auto k2 = &head_fused_fwd_kernel<false, true>;
+    auto k3 = &head_fused_fwd_kernel<true, true>;
     DC_ONCE({
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
+    if (bi != nullptr) {
+      if (hl != nullptr)
+        hipLaunchKernelGGL(k3, dim3(strips * nty * N), dim3(256), lds, st, (const bf16*)x, ldx, (const bf16*)ws.wf, logits_nchw, N, Hi, Wi, Cin, ntx, *hl, *bi);
+      else
+        hipLaunchKernelGGL(k2, dim3(strips * nty * N), dim3(256), lds, st, (const bf16*)x, ldx, (const bf16*)ws.wf, logits_nchw, N, Hi, Wi, Cin, ntx, HeadLoss{}, *bi);
+      DC_CHECK_LAUNCH();
+      return 0;
+    }
     if (hl != nullptr)
-      hipLaunchKernelGGL(k1, dim3(strips * nty * N), dim3(256), lds, st, (const bf16*)x, ldx, (const bf16*)ws.wf, logits_nchw, N, Hi, Wi, Cin, ntx, *hl);
+      hipLaunchKernelGGL(k1, dim3(strips * nty * N), dim3(256), lds, st, (const bf16*)x, ldx, (const bf16*)ws.wf, logits_nchw, N, Hi, Wi, Cin, ntx, *hl, HeadBnIn{});
     else
-      hipLaunchKernelGGL(k0, dim3(strips * nty * N), dim3(256), lds, st, (const bf16*)x, ldx, (const bf16*)ws.wf, logits_nchw, N, Hi, Wi, Cin, ntx, HeadLoss{});
+      hipLaunchKernelGGL(k0, dim3(strips * nty * N), dim3(256), lds, st, (const bf16*)x, ldx, (const bf16*)ws.wf, logits_nchw, N, Hi, Wi, Cin, ntx, HeadLoss{}, HeadBnIn{});
     DC_CHECK_LAUNCH();
     return 0;
   }
+  DC_REQUIRE(bi == nullptr, "dc_head_fwd_bnin: only the fused bf16 head kernel (256 input channels) applies the BatchNorm while loading");
   DC_REQUIRE(logits_nchw != nullptr, "dc_head_fwd: this configuration (fp32, or the unfused path) needs a logits buffer");
   dc_conv_desc d{dtype, 1, 1, 0, 1, 0, Cin, HEAD_NP};
   if (int e = dc_conv_fwd_f32out(&d, N, Hi, Wi, x, ldx, ws.wf, ws.P, HEAD_NP, stream)) return e;
@@ -686,6 +741,29 @@ extern "C" int dc_head_fwd_loss(int dtype, int N, int Cin, int Hi, int Wi, const
   return head_fwd_impl(dtype, N, Cin, Hi, Wi, x, ldx, w, logits_nchw, workspace, stream, &hl);
 }
 
+// The head on a BatchNorm output that is never stored: y is the raw output of the convolution in front of the BatchNorm, the head's
+// input is act(y * scale + shift) (reference: upsample.deconv3 = ConvTranspose2d + BatchNorm2d + ReLU in front of last_deconv,
+// deeplab_xception.py:369-374).  bf16, 256 input channels (the fused head kernel); same logits bits as dc_bn_apply + dc_head_fwd.
+extern "C" int dc_head_fwd_bnin(int dtype, int N, int Cin, int Hi, int Wi, const void* y, int ldy, const float* scale, const float* shift,
+                                int relu, const float* w, float* logits_nchw, void* workspace, void* stream) {
+  DC_REQUIRE(logits_nchw != nullptr && scale != nullptr && shift != nullptr, "dc_head_fwd_bnin: null argument");
+  DC_REQUIRE(dtype == DC_BF16 && Cin == 256 && g_head_fused, "dc_head_fwd_bnin: bf16, 256 channels, fused head kernel only");
+  const HeadBnIn bi{scale, shift, relu};
+  return head_fwd_impl(dtype, N, Cin, Hi, Wi, y, ldy, w, logits_nchw, workspace, stream, nullptr, &bi);
+}
+
+extern "C" int dc_head_fwd_loss_bnin(int dtype, int N, int Cin, int Hi, int Wi, const void* y, int ldy, const float* scale, const float* shift,
+                                     int relu, const float* w, float* logits_nchw, void* workspace, const void* labels, int label_dtype_bytes,
+                                     const float* class_weights, float grad_scale, double* loss_sum, float* dlogits, int64_t* pred,
+                                     int64_t* counts, void* stream) {
+  DC_REQUIRE(labels && class_weights && scale && shift, "dc_head_fwd_loss_bnin: bad argument");
+  DC_REQUIRE(dtype == DC_BF16 && Cin == 256 && g_head_fused, "dc_head_fwd_loss_bnin: bf16, 256 channels, fused head kernel only");
+  DC_REQUIRE(label_dtype_bytes == 1 || label_dtype_bytes == 4 || label_dtype_bytes == 8, "dc_head_fwd_loss_bnin: labels must be uint8, int32 or int64");
+  HeadLoss hl{labels, label_dtype_bytes, class_weights, grad_scale, loss_sum, dlogits, pred, (unsigned long long*)counts};
+  const HeadBnIn bi{scale, shift, relu};
+  return head_fwd_impl(dtype, N, Cin, Hi, Wi, y, ldy, w, logits_nchw, workspace, stream, &hl, &bi);
+}
+
 extern "C" int dc_conv_dgrad_bnstats(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb,
                                      void* dx, int lddx, const void* y, int ldy, const float* mean, const float* invstd,
                                      const float* mscale, const float* mshift, int relu, float* slab, void* stream);
@@ -695,7 +773,13 @@ static int head_bwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* 
                          const float* w, void* dx, int lddx, float* grad_w, void* workspace, void* stream, const void* bn_y, int bn_ldy,
                          const float* bn_mean, const float* bn_invstd, const float* bn_mscale, const float* bn_mshift, int bn_relu,
                          float* bn_slab) {
-  if (int e = dc_check_view(x, ldx, Cin, dtype, "dc_head_bwd x")) return e;
+  // x == nullptr (dc_head_bwd_bnin): the head's input was never stored; the weight gradient forms act(bn_y * bn_mscale + bn_mshift) itself
+  if (x != nullptr) {
+    if (int e = dc_check_view(x, ldx, Cin, dtype, "dc_head_bwd x")) return e;
+  } else {
+    DC_REQUIRE(bn_y != nullptr && bn_mscale != nullptr && bn_mshift != nullptr && dtype == DC_BF16, "dc_head_bwd_bnin: needs the BatchNorm input and its forward scale / shift (bf16)");
+    if (int e = dc_check_view(bn_y, bn_ldy, Cin, dtype, "dc_head_bwd_bnin y")) return e;
+  }
   if (int e = dc_check_view(dx, lddx, Cin, dtype, "dc_head_bwd dx")) return e;
   DC_REQUIRE(w && dlogits_nchw && grad_w && workspace && N > 0, "dc_head_bwd: bad argument");
   DC_REQUIRE(((uintptr_t)workspace & 255) == 0, "dc_head_bwd: workspace must be 256-byte aligned");
@@ -713,10 +797,14 @@ static int head_bwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* 
   }
   DC_CHECK_LAUNCH();
   dc_conv_desc d{dtype, 1, 1, 0, 1, 0, Cin, HEAD_NP};
-  if (int e = dc_conv_wgrad(&d, N, Hi, Wi, x, ldx, ws.dP, HEAD_NP, ws.slabs, ws.slab_bytes, ws.tmp, stream)) return e;
+  if (x != nullptr) {
+    if (int e = dc_conv_wgrad(&d, N, Hi, Wi, x, ldx, ws.dP, HEAD_NP, ws.slabs, ws.slab_bytes, ws.tmp, stream)) return e;
+  } else {
+    if (int e = conv_wgrad_bnin(&d, N, Hi, Wi, bn_y, bn_ldy, bn_mscale, bn_mshift, bn_relu, ws.dP, HEAD_NP, ws.slabs, ws.slab_bytes, ws.tmp, stream)) return e;
+  }
   hipLaunchKernelGGL(head_wfinish_kernel, dim3(cdiv(Cin * HEAD_NC * 9, 256)), dim3(256), 0, st, (const float*)ws.tmp, grad_w, Cin);
   DC_CHECK_LAUNCH();
-  if (bn_y != nullptr)
+  if (bn_y != nullptr && bn_slab != nullptr)
     return dc_conv_dgrad_bnstats(&d, N, Hi, Wi, ws.dP, HEAD_NP, ws.wb, dx, lddx, bn_y, bn_ldy, bn_mean, bn_invstd, bn_mscale, bn_mshift,
                                  bn_relu, bn_slab, stream);
   return dc_conv_dgrad(&d, N, Hi, Wi, ws.dP, HEAD_NP, ws.wb, dx, lddx, 0, stream);
@@ -735,6 +823,17 @@ extern "C" int dc_head_bwd_bnstats(int dtype, int N, int Cin, int Hi, int Wi, co
   DC_REQUIRE(bn_y != nullptr && bn_slab != nullptr, "dc_head_bwd_bnstats: needs the BatchNorm input and a slab");
   return head_bwd_impl(dtype, N, Cin, Hi, Wi, x, ldx, dlogits_nchw, w, dx, lddx, grad_w, workspace, stream, bn_y, bn_ldy, bn_mean, bn_invstd,
                        bn_mscale, bn_mshift, bn_relu, bn_slab);
+}
+
+// Backward of the head on a never-stored BatchNorm(+ReLU) output (dc_head_fwd_bnin): y is the BatchNorm's input, scale / shift its forward
+// coefficients.  bn_slab != NULL additionally leaves that BatchNorm's backward sums there (as dc_head_bwd_bnstats; needs mean / invstd).
+extern "C" int dc_head_bwd_bnin(int dtype, int N, int Cin, int Hi, int Wi, const void* y, int ldy, const float* scale, const float* shift,
+                                int relu, const float* dlogits_nchw, const float* w, void* dx, int lddx, float* grad_w, void* workspace,
+                                const float* bn_mean, const float* bn_invstd, float* bn_slab, void* stream) {
+  DC_REQUIRE(y != nullptr && scale != nullptr && shift != nullptr, "dc_head_bwd_bnin: null argument");
+  DC_REQUIRE(bn_slab == nullptr || (bn_mean != nullptr && bn_invstd != nullptr), "dc_head_bwd_bnin: the BatchNorm sums need mean and invstd");
+  return head_bwd_impl(dtype, N, Cin, Hi, Wi, nullptr, 0, dlogits_nchw, w, dx, lddx, grad_w, workspace, stream, y, ldy, bn_mean, bn_invstd, scale,
+                       shift, relu, bn_slab);
 }
 
 extern "C" int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, void* out, int ldo, void* stream) {

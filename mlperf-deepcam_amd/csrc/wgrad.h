@@ -13,10 +13,18 @@ struct WgradParams {
   int M;           // pixels per phase
   int splits;
   int chunk;       // pixels per split (multiple of BP)
+  // register-staged kernel (wgrad_kernel<bf16>) only: x is the raw output y of a convolution and the real operand is act(y * xscale + xshift),
+  // the BatchNorm(+ReLU) output that was never stored (dc_head_bwd_bnin); formed in registers on the way to LDS
+  const float* xscale = nullptr;
+  const float* xshift = nullptr;
+  int xrelu = 0;
 };
 
 // 256 x 256 tile kernel (bf16 only): split plan and launch.  The slab layout [split][tap][Co][Ci] is the same as the small
 // kernel's, so wgrad_reduce_kernel serves both.
+// dc_conv_wgrad on a lazily applied BatchNorm output: the gathered operand is act(y * xscale + xshift) (stem_head.hip: the head's weight gradient)
+int conv_wgrad_bnin(const dc_conv_desc* d, int N, int Hi, int Wi, const void* y, int ldy, const float* xscale, const float* xshift, int xrelu,
+                    const void* dy, int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream);
 constexpr int WG_MAXGROUP = 4;   // layers of one geometry per grouped launch (dc_conv_wgrad_group)
 void wgrad256_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group = 1);
 void wgrad256_set_slots(int n);   // workgroups a launch of the 256-tile kernel aims for (default 256 = one per CU)

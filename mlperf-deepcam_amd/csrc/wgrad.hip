@@ -59,7 +59,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
   // each thread moves 4 vectors per operand per step: vector v = tid + 256*i -> (row = v / VPR, col = v % VPR)
   vec16 rq[4], rp[4];
+  // x = act(y * xscale + xshift) formed here (bf16 only): a thread's column, i.e. its KPV channels, is the same for its four vectors
+  // (256 is a multiple of VPR); vectors that were not loaded (padding, halo) stay zero
+  [[maybe_unused]] unsigned xvalid = 0;
+  [[maybe_unused]] float xsc[KPV], xsh[KPV];
+  const bool xform = sizeof(T) == 2 && p.xscale != nullptr;
+  if (xform) {
+    const int ci = ci0 + (tid % VPR) * KPV;
+#pragma unroll
+    for (int e = 0; e < KPV; ++e) {
+      xsc[e] = ci + e < g.Cin ? p.xscale[ci + e] : 0.f;
+      xsh[e] = ci + e < g.Cin ? p.xshift[ci + e] : 0.f;
+    }
+  }
   auto load_step = [&](int s) {
+    xvalid = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int v = tid + 256 * i;
@@ -78,8 +92,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         }
         const int ci = ci0 + col * KPV;
         const int iy = qy * g.is + tap.dy, ix = qx * g.is + tap.dx;
-        if (ci < g.Cin && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win)
+        if (ci < g.Cin && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win) {
           rp[i] = ldg16(xg + ((size_t)(n * g.Hin + iy) * g.Win + ix) * p.ldx + ci);
+          xvalid |= 1u << i;
+        }
       }
     }
   };
@@ -90,6 +106,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     for (int i = 0; i < 4; ++i) {
       const int v = tid + 256 * i;
       const int row = v / VPR, col = v % VPR;
+      if constexpr (sizeof(T) == 2) {
+        if (xform && (xvalid >> i & 1)) {
+          float f[KPV];
+          unpack(rp[i], f, T());
+#pragma unroll
+          for (int e = 0; e < KPV; ++e) {
+            f[e] = fmaf(f[e], xsc[e], xsh[e]);
+            if (p.xrelu) f[e] = fmaxf(f[e], 0.f);
+          }
+          pack(rp[i], f, T());
+        }
+      }
       *reinterpret_cast<vec16*>(q + row * ROW + col * 16) = rq[i];
       *reinterpret_cast<vec16*>(pp + row * ROW + col * 16) = rp[i];
     }
@@ -519,18 +547,23 @@ extern "C" size_t dc_conv_wgrad_workspace(const dc_conv_desc* d, int N, int Hi, 
   return (size_t)splits * g.ntaps * g.Cout * g.Cin * sizeof(float);
 }
 
-extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* dy,
-                             int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream) {
+// xscale != nullptr: x is a raw convolution output and the operand is act(x * xscale + xshift) (WgradParams::xscale): the
+// register-staged 128-tile kernel, whatever the planner would have picked
+static int conv_wgrad_impl(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* dy,
+                           int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream, const float* xscale,
+                           const float* xshift, int xrelu) {
   DC_REQUIRE(d != nullptr && grad_w != nullptr && workspace != nullptr, "dc_conv_wgrad: null argument");
+  DC_REQUIRE(xscale == nullptr || (d->dtype == DC_BF16 && xshift != nullptr), "dc_conv_wgrad: the operand transform is bf16 only");
   WgradParams p;
+  p.xscale = xscale; p.xshift = xshift; p.xrelu = xrelu;
   if (!build_geom(*d, Hi, Wi, kFwd, &p.g)) return dc_fail("dc_conv_wgrad: unsupported geometry", __FILE__, __LINE__);
   if (int e = dc_check_view(x, ldx, p.g.Cin, d->dtype, "dc_conv_wgrad x")) return e;
   if (int e = dc_check_view(dy, lddy, p.g.Cout, d->dtype, "dc_conv_wgrad dy")) return e;
   const long M = (long)N * p.g.Qh * p.g.Qw;
   DC_REQUIRE(M < (1L << 31) - 256, "dc_conv_wgrad: too many pixels for 32-bit indexing");
   const int BP = d->dtype == DC_BF16 ? 64 : 32;    // chunk granularity (a multiple of both kernels' pixels per stage)
-  const bool thin = g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi);
-  const bool big = !thin && d->dtype == DC_BF16 && wgrad256_wins(p.g);
+  const bool thin = xscale == nullptr && g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi);
+  const bool big = xscale == nullptr && !thin && d->dtype == DC_BF16 && wgrad256_wins(p.g);
   if (thin) { p.splits = thin_wgrad_splits(*d, N, Hi, Wi); p.chunk = 0; }
   else if (big) wgrad256_plan(p.g, M, &p.splits, &p.chunk);
   else plan_splits(p.g, M, BP, &p.splits, &p.chunk);
@@ -544,7 +577,7 @@ extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const
     if (int e = launch_thin_wgrad(*d, N, Hi, Wi, x, ldx, dy, lddy, p.slab, st)) return e;
   } else if (big) {
     if (int e = launch_wgrad256(p, st)) return e;
-  } else if (g_wgrad_mode == 1) {
+  } else if (g_wgrad_mode == 1 && xscale == nullptr) {
     const size_t lds = 3 * 2 * 8192;
     if (d->dtype == DC_BF16) {
       DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -565,6 +598,18 @@ extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const
   DC_CHECK_LAUNCH();
   return launch_wgrad_reduce(p.slab, grad_w, p.splits, p.g, d->transposed, st);
 }
+
+extern "C" int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* dy,
+                             int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream) {
+  return conv_wgrad_impl(d, N, Hi, Wi, x, ldx, dy, lddy, workspace, workspace_bytes, grad_w, stream, nullptr, nullptr, 0);
+}
+
+namespace dc {
+int conv_wgrad_bnin(const dc_conv_desc* d, int N, int Hi, int Wi, const void* y, int ldy, const float* xscale, const float* xshift, int xrelu,
+                    const void* dy, int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream) {
+  return conv_wgrad_impl(d, N, Hi, Wi, y, ldy, dy, lddy, workspace, workspace_bytes, grad_w, stream, xscale, xshift, xrelu);
+}
+}  // namespace dc
 
 // Grouped form: `count` layers of ONE geometry (same descriptor, extents and row strides) in one launch of the 256-tile
 // kernel and one reduction per layer.  Layers the 256-tile kernel does not serve fall back to `count` plain calls.

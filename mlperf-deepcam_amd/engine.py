@@ -168,6 +168,10 @@ class Engine:
         # (time-neutral at local batch 8 and 4, where it saves 2.8 GB of reads per step; +0.08 ms at batch 2: off there)
         self.fuse_bn_conv = os.environ.get("DC_FUSE_BN_CONV", "1" if batch >= 4 else "0") != "0"
         self.fuse_bn_head = os.environ.get("DC_FUSE_BN_HEAD", "1" if batch >= 4 else "0") != "0"
+        # the BatchNorm + ReLU in front of the classifier head (upsample.deconv3.1/.2) is applied by the head itself while it loads
+        # (dc_head_fwd_loss_bnin / dc_head_bwd_bnin): the 256-channel 384 x 576 activation is never stored (at local batch 8: a 0.35 ms
+        # dc_bn_apply pass and 1.8 GB of traffic less per step).  bf16 only (the fused head kernel).
+        self.fuse_bn_into_head = dtype == torch.bfloat16 and os.environ.get("DC_FUSE_BN_INTO_HEAD", "1") != "0"
         # depthwise weight gradient taken inside the depthwise data gradient (dc_dwconv_dgrad_bnstats_wgrad) where the layer's input is a
         # never-stored BatchNorm output: the separate dc_dwconv_wgrad launch (and its second read of dy and y) disappears
         # (local batch 8: 39.97 -> 39.74 ms/step; batch 4 / 2: +0.25 / +0.15 ms -- the fused kernel holds 232 registers, two workgroups
@@ -800,7 +804,8 @@ class Engine:
         a = self._bn(y, slab, rows, U + "conv1.4", True)
         y, _, _ = self._conv(a, U + "conv1.6.weight", 256, stats=False, bias=U + "conv1.6.bias", name="dec.conv6", sole_consumer=True)
         y, slab, rows = self._conv(y, U + "deconv3.0.weight", 256, transposed=True, name="deconv3")
-        a = self._bn(y, slab, rows, U + "deconv3.1", True)
+        a = self._bn(y, slab, rows, U + "deconv3.1", True, lazy=self.fuse_bn_into_head)
+        lazy_in = isinstance(a, LazyAct)
 
         # ---- classifier head -> NCHW fp32 logits (GEMM + sub-pixel tap combination, own workspace: P must survive to bwd? no,
         #      it is recomputed from dlogits; the workspace only has to be private to the head)
@@ -810,6 +815,10 @@ class Engine:
         hptr = C.c_void_p((hws.data_ptr() + 255) // 256 * 256)
 
         def head_fwd():
+            if lazy_in:
+                L.call("dc_head_fwd_bnin", self.dt, B, 256, a.H, a.W, a.y.ptr, a.y.ld, L.dptr(a.scale), L.dptr(a.shift), int(a.relu), self.pptr(wl),
+                       L.dptr(self.logits), hptr, self._st())
+                return
             L.call("dc_head_fwd", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, self.pptr(wl), L.dptr(self.logits), hptr, self._st())
 
         def head_fwd_train():
@@ -818,6 +827,12 @@ class Engine:
             la = self.loss_args
             if la is None:
                 return head_fwd()
+            if lazy_in:
+                L.call("dc_head_fwd_loss_bnin", self.dt, B, 256, a.H, a.W, a.y.ptr, a.y.ld, L.dptr(a.scale), L.dptr(a.shift), int(a.relu),
+                       self.pptr(wl), L.dptr(self.logits) if la["store_logits"] else None, hptr, L.dptr(la["labels"]), la["labels"].element_size(),
+                       L.dptr(la["weight"]), la["grad_scale"], L.dptr(la["loss_sum"]), L.dptr(self.dlogits), L.dptr(la["pred"]),
+                       L.dptr(la["counts"]), self._st())
+                return
             L.call("dc_head_fwd_loss", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, self.pptr(wl), L.dptr(self.logits) if la["store_logits"] else None,
                    hptr, L.dptr(la["labels"]), la["labels"].element_size(), L.dptr(la["weight"]), la["grad_scale"], L.dptr(la["loss_sum"]),
                    L.dptr(self.dlogits), L.dptr(la["pred"]), L.dptr(la["counts"]), self._st())
@@ -829,13 +844,25 @@ class Engine:
             assert a.take_grad_mode() == 0
             da = a.grad
             bsrc = getattr(a, "bn_src", None) if self.fuse_bn_head else None
-            if bsrc is not None:
+            if lazy_in:
+                bsrc = None
+                sslab = None
+                if self.fuse_bn_head:
+                    srows = (a.M + 127) // 128
+                    sslab = self._f32(2 * srows * 256)
+                    a.fused_bwd = (sslab, srows)
+            elif bsrc is not None:
                 srows = (a.M + 127) // 128
                 sslab = self._f32(2 * srows * 256)
                 a.fused_bwd = (sslab, srows)
                 by = bsrc["y"]
 
             def bwd():
+                if lazy_in:
+                    L.call("dc_head_bwd_bnin", self.dt, B, 256, a.H, a.W, a.y.ptr, a.y.ld, L.dptr(a.scale), L.dptr(a.shift), int(a.relu),
+                           L.dptr(self.dlogits), self.pptr(wl), da.ptr, da.ld, self.gptr(wl), hptr, L.dptr(a.mean), L.dptr(a.invstd),
+                           L.dptr(sslab) if sslab is not None else None, self._st())
+                    return
                 if bsrc is not None:
                     L.call("dc_head_bwd_bnstats", self.dt, B, 256, a.H, a.W, a.ptr, a.ld, L.dptr(self.dlogits), self.pptr(wl), da.ptr, da.ld,
                            self.gptr(wl), hptr, by.ptr, by.ld, L.dptr(bsrc["mean"]), L.dptr(bsrc["invstd"]), L.dptr(bsrc["scale"]),

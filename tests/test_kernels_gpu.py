@@ -1201,6 +1201,75 @@ def test_head_forward_with_fused_loss(shape, lab_dtype):
     assert torch.isnan(ls).all() and torch.isnan(dl[0, :, 1, 2]).all() and int(torch.isnan(dl).sum()) == 3
 
 
+@pytest.mark.parametrize("relu", [1, 0], ids=["relu", "affine"])
+@pytest.mark.parametrize("shape", [(2, 20, 70), (1, 9, 229), (2, 8, 32)], ids=["3x3tiles", "8tiles_wide", "exact_tiles"])
+def test_head_on_unstored_batchnorm_output(shape, relu):
+    """dc_head_fwd_bnin / dc_head_fwd_loss_bnin / dc_head_bwd_bnin (the head reads the raw output y of the convolution in front of the
+    BatchNorm and forms act(y * scale + shift) itself) against dc_bn_apply followed by the plain head calls: logits, loss, logit
+    gradient, predictions, counts, data gradient and BatchNorm-backward sums bit for bit; the weight gradient (another kernel: the
+    register-staged 128-tile one) to rounding."""
+    N, H, W = shape
+    Cin, dtype = 256, torch.bfloat16
+    dt = L.dtype_code(dtype)
+    M = N * H * W
+    y = q(rnd(N, Cin, H, W, seed=1), dtype)
+    w = rnd(Cin, 3, 3, 3, seed=2, scale=0.05)
+    _, yv = to_nhwc(y, dtype, ld=Cin + 16, off=8)
+    wd = w.to(dev())
+    scale, shift = (rnd(Cin, seed=3).abs() + 0.3).to(dev()), rnd(Cin, seed=4, scale=0.4).to(dev())
+    mean, invstd = rnd(Cin, seed=6, scale=0.3).to(dev()), (rnd(Cin, seed=7).abs() + 0.5).to(dev())
+    ws = torch.empty(L.load().dc_head_workspace(dt, N, Cin, H, W) + 256, dtype=torch.uint8, device=dev())
+    wsp = C.c_void_p((ws.data_ptr() + 255) // 256 * 256)
+    g = torch.Generator().manual_seed(7)
+    labels = torch.randint(0, 3, (N, 2 * H, 2 * W), generator=g).to(dev())
+    cw = torch.tensor([0.9, 2.6, 1.7], device=dev())
+    gs = 1.0 / labels.numel()
+    # reference: the stored activation, then the plain calls
+    _, av = empty_nhwc(N, H, W, Cin, dtype)
+    L.call("dc_bn_apply", dt, M, Cin, vptr(yv), Cin + 16, vptr(scale), vptr(shift), None, 0, relu, vptr(av), Cin, S())
+    ref_logits = torch.full((N, 3, 2 * H, 2 * W), float("nan"), device=dev())
+    ref_ls = torch.zeros(1, dtype=torch.float64, device=dev())
+    ref_dl, ref_pred = torch.full_like(ref_logits, float("nan")), torch.full((N, 2 * H, 2 * W), -1, dtype=torch.int64, device=dev())
+    ref_cnt = torch.zeros(9, dtype=torch.int64, device=dev())
+    L.call("dc_head_fwd_loss", dt, N, Cin, H, W, vptr(av), Cin, vptr(wd), vptr(ref_logits), wsp, vptr(labels), 8, vptr(cw), gs, vptr(ref_ls),
+           vptr(ref_dl), vptr(ref_pred), vptr(ref_cnt), S())
+    rows = (M + 127) // 128
+    ref_slab = torch.full((2, rows, Cin), float("nan"), device=dev())
+    _, ref_dx = empty_nhwc(N, H, W, Cin, dtype)
+    ref_gw = torch.full((Cin, 3, 3, 3), float("nan"), device=dev())
+    L.call("dc_head_bwd_bnstats", dt, N, Cin, H, W, vptr(av), Cin, vptr(ref_dl), vptr(wd), vptr(ref_dx), Cin, vptr(ref_gw), wsp, vptr(yv), Cin + 16,
+           vptr(mean), vptr(invstd), vptr(scale), vptr(shift), relu, vptr(ref_slab), S())
+    torch.cuda.synchronize()
+    # the activation never stored
+    logits = torch.full_like(ref_logits, float("nan"))
+    L.call("dc_head_fwd_bnin", dt, N, Cin, H, W, vptr(yv), Cin + 16, vptr(scale), vptr(shift), relu, vptr(wd), vptr(logits), wsp, S())
+    torch.cuda.synchronize()
+    assert torch.equal(logits, ref_logits)
+    for store in (True, False):
+        logits = torch.full_like(ref_logits, float("nan"))
+        ls = torch.zeros(1, dtype=torch.float64, device=dev())
+        dl, pred = torch.full_like(ref_logits, float("nan")), torch.full_like(ref_pred, -1)
+        cnt = torch.zeros(9, dtype=torch.int64, device=dev())
+        L.call("dc_head_fwd_loss_bnin", dt, N, Cin, H, W, vptr(yv), Cin + 16, vptr(scale), vptr(shift), relu, vptr(wd),
+               vptr(logits) if store else None, wsp, vptr(labels), 8, vptr(cw), gs, vptr(ls), vptr(dl), vptr(pred), vptr(cnt), S())
+        torch.cuda.synchronize()
+        assert torch.equal(logits, ref_logits) if store else torch.isnan(logits).all()
+        assert torch.equal(dl, ref_dl) and torch.equal(pred, ref_pred) and torch.equal(cnt, ref_cnt)
+        assert float(ls) == pytest.approx(float(ref_ls), rel=1e-12)
+    for with_sums in (True, False):
+        slab = torch.full((2, rows, Cin), float("nan"), device=dev())
+        _, dx = empty_nhwc(N, H, W, Cin, dtype)
+        gw = torch.full((Cin, 3, 3, 3), float("nan"), device=dev())
+        L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, vptr(yv), Cin + 16, vptr(scale), vptr(shift), relu, vptr(ref_dl), vptr(wd), vptr(dx), Cin,
+               vptr(gw), wsp, vptr(mean), vptr(invstd), vptr(slab) if with_sums else None, S())
+        torch.cuda.synchronize()
+        assert torch.equal(from_nhwc(dx), from_nhwc(ref_dx))
+        assert torch.equal(slab, ref_slab) if with_sums else torch.isnan(slab).all()
+        assert not torch.isnan(gw).any()
+        assert (gw - ref_gw).abs().max().item() <= 1e-5 * ref_gw.abs().max().item()
+        print(f"[head weight gradient, register-staged vs LDS-DMA kernel] bit-equal: {torch.equal(gw, ref_gw)}")
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_nchw_to_nhwc(dtype):
     x = rnd(2, 16, 9, 13, seed=1)

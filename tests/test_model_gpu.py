@@ -376,7 +376,16 @@ def _shared_point_engines(B, H, W):
     engine's forward state (every stored activation, every BatchNorm coefficient vector) copied into the fp32 engine, and the same
     d(loss)/d(logits).  Backward is then the same LINEAR map in both, evaluated in bf16 and in fp32 arithmetic."""
     x, y = make_inputs(B, H, W)
-    e16 = Engine(B, H, W, torch.bfloat16, seed=333)
+    # (the bf16 engine stores the head's input here as the fp32 engine does, so that every activation of the point can be copied)
+    old = os.environ.get("DC_FUSE_BN_INTO_HEAD")
+    os.environ["DC_FUSE_BN_INTO_HEAD"] = "0"
+    try:
+        e16 = Engine(B, H, W, torch.bfloat16, seed=333)
+    finally:
+        if old is None:
+            del os.environ["DC_FUSE_BN_INTO_HEAD"]
+        else:
+            os.environ["DC_FUSE_BN_INTO_HEAD"] = old
     e32 = Engine(B, H, W, torch.float32, seed=333)
     for e in (e16, e32):
         e.params.copy_(e.params.to(torch.bfloat16).float())
@@ -430,8 +439,11 @@ def test_forward_activations_by_stage_bf16_vs_fp32_full_size():
     e16.mark_weights_changed()
     e16.forward(x.to(DEV), train=True)
     torch.cuda.synchronize()
-    assert set(ref) == set(e16.saved)
+    # (the bf16 engine never stores the head's input, the BatchNorm + ReLU output of upsample.deconv3: Engine.fuse_bn_into_head)
+    assert {k for k in set(ref) ^ set(e16.saved) if not k.startswith("d")} <= {"upsample.deconv3.1"}
     for k, t in e16.saved.items():
+        if k not in ref:
+            continue
         # forward activations only (the gradient buffers are registered under the same dictionary and hold nothing yet); the
         # per-channel coefficient vectors are covered through the activations they produce
         if t.numel() < 4096 or not k.startswith(("xception_features.", "aspp", "global_avg_pool", "conv1", "bn1", "conv2", "bn2", "last_conv", "upsample")):
