@@ -258,10 +258,13 @@ int dc_head_fwd_loss_bnin(int dtype, int N, int Cin, int Hi, int Wi, const void*
                           const float* class_weights, float grad_scale, double* loss_sum, float* dlogits, int64_t* pred,
                           int64_t* counts, void* stream);
 /* dc_head_bwd for that case: the weight gradient forms the head's input from y itself (register-staged 128-tile kernel); bn_slab != NULL
- * also leaves the BatchNorm's backward sums there as dc_head_bwd_bnstats does (bn_mean / bn_invstd then required). */
+ * also leaves the BatchNorm's backward sums there as dc_head_bwd_bnstats does (bn_mean / bn_invstd then required).
+ * parts: 3 = everything; 1 = the gathered gradient image + the data gradient (+ sums); 2 = the weight gradient alone, which reads the
+ * image a parts = 1 call left in `workspace` -- the caller may issue it on another stream ordered behind that call (the engine's
+ * weight-gradient stream), since nothing on the chain waits for grad_w. */
 int dc_head_bwd_bnin(int dtype, int N, int Cin, int Hi, int Wi, const void* y, int ldy, const float* scale, const float* shift,
                      int relu, const float* dlogits_nchw, const float* w, void* dx, int lddx, float* grad_w, void* workspace,
-                     const float* bn_mean, const float* bn_invstd, float* bn_slab, void* stream);
+                     const float* bn_mean, const float* bn_invstd, float* bn_slab, int parts, void* stream);
 
 /* NCHW fp32 (the layout train_hdf5_ddp.py:348 hands over) -> NHWC `dtype`: the one layout pass of the step. */
 int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, void* out, int ldo, void* stream);

@@ -772,7 +772,9 @@ extern "C" int dc_conv_dgrad_bnstats(const dc_conv_desc* d, int N, int Hi, int W
 static int head_bwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
                          const float* w, void* dx, int lddx, float* grad_w, void* workspace, void* stream, const void* bn_y, int bn_ldy,
                          const float* bn_mean, const float* bn_invstd, const float* bn_mscale, const float* bn_mshift, int bn_relu,
-                         float* bn_slab) {
+                         float* bn_slab, int parts = 3) {
+  // parts: 1 = the gathered gradient image + the data gradient, 2 = the weight gradient (reads the gathered image a parts-1 call left in
+  // `workspace`: the caller may run it on another stream behind that call), 3 = both
   // x == nullptr (dc_head_bwd_bnin): the head's input was never stored; the weight gradient forms act(bn_y * bn_mscale + bn_mshift) itself
   if (x != nullptr) {
     if (int e = dc_check_view(x, ldx, Cin, dtype, "dc_head_bwd x")) return e;
@@ -781,29 +783,34 @@ static int head_bwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* 
     if (int e = dc_check_view(bn_y, bn_ldy, Cin, dtype, "dc_head_bwd_bnin y")) return e;
   }
   if (int e = dc_check_view(dx, lddx, Cin, dtype, "dc_head_bwd dx")) return e;
-  DC_REQUIRE(w && dlogits_nchw && grad_w && workspace && N > 0, "dc_head_bwd: bad argument");
+  DC_REQUIRE(w && dlogits_nchw && grad_w && workspace && N > 0 && (parts & 3) != 0 && (parts & ~3) == 0, "dc_head_bwd: bad argument");
   DC_REQUIRE(((uintptr_t)workspace & 255) == 0, "dc_head_bwd: workspace must be 256-byte aligned");
   HeadWs ws = head_ws(dtype, N, Cin, Hi, Wi, workspace);
   hipStream_t st = (hipStream_t)stream;
   const long P = (long)N * Hi * Wi;
   const int np = HEAD_NP * Cin;
   // (the packed weights are rebuilt here too: backward may follow a forward that ran in another engine / workspace)
-  if (dtype == DC_BF16) {
-    hipLaunchKernelGGL(head_pack_kernel<bf16>, dim3(cdiv(np, 256)), dim3(256), 0, st, w, (bf16*)ws.wf, (bf16*)ws.wb, Cin);
-    hipLaunchKernelGGL(head_gather_kernel<bf16>, dim3(cdiv(P, 256)), dim3(256), 0, st, dlogits_nchw, (bf16*)ws.dP, N, Hi, Wi);
-  } else {
-    hipLaunchKernelGGL(head_pack_kernel<float>, dim3(cdiv(np, 256)), dim3(256), 0, st, w, (float*)ws.wf, (float*)ws.wb, Cin);
-    hipLaunchKernelGGL(head_gather_kernel<float>, dim3(cdiv(P, 256)), dim3(256), 0, st, dlogits_nchw, (float*)ws.dP, N, Hi, Wi);
-  }
-  DC_CHECK_LAUNCH();
   dc_conv_desc d{dtype, 1, 1, 0, 1, 0, Cin, HEAD_NP};
-  if (x != nullptr) {
-    if (int e = dc_conv_wgrad(&d, N, Hi, Wi, x, ldx, ws.dP, HEAD_NP, ws.slabs, ws.slab_bytes, ws.tmp, stream)) return e;
-  } else {
-    if (int e = conv_wgrad_bnin(&d, N, Hi, Wi, bn_y, bn_ldy, bn_mscale, bn_mshift, bn_relu, ws.dP, HEAD_NP, ws.slabs, ws.slab_bytes, ws.tmp, stream)) return e;
+  if (parts & 1) {
+    if (dtype == DC_BF16) {
+      hipLaunchKernelGGL(head_pack_kernel<bf16>, dim3(cdiv(np, 256)), dim3(256), 0, st, w, (bf16*)ws.wf, (bf16*)ws.wb, Cin);
+      hipLaunchKernelGGL(head_gather_kernel<bf16>, dim3(cdiv(P, 256)), dim3(256), 0, st, dlogits_nchw, (bf16*)ws.dP, N, Hi, Wi);
+    } else {
+      hipLaunchKernelGGL(head_pack_kernel<float>, dim3(cdiv(np, 256)), dim3(256), 0, st, w, (float*)ws.wf, (float*)ws.wb, Cin);
+      hipLaunchKernelGGL(head_gather_kernel<float>, dim3(cdiv(P, 256)), dim3(256), 0, st, dlogits_nchw, (float*)ws.dP, N, Hi, Wi);
+    }
+    DC_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(head_wfinish_kernel, dim3(cdiv(Cin * HEAD_NC * 9, 256)), dim3(256), 0, st, (const float*)ws.tmp, grad_w, Cin);
-  DC_CHECK_LAUNCH();
+  if (parts & 2) {
+    if (x != nullptr) {
+      if (int e = dc_conv_wgrad(&d, N, Hi, Wi, x, ldx, ws.dP, HEAD_NP, ws.slabs, ws.slab_bytes, ws.tmp, stream)) return e;
+    } else {
+      if (int e = conv_wgrad_bnin(&d, N, Hi, Wi, bn_y, bn_ldy, bn_mscale, bn_mshift, bn_relu, ws.dP, HEAD_NP, ws.slabs, ws.slab_bytes, ws.tmp, stream)) return e;
+    }
+    hipLaunchKernelGGL(head_wfinish_kernel, dim3(cdiv(Cin * HEAD_NC * 9, 256)), dim3(256), 0, st, (const float*)ws.tmp, grad_w, Cin);
+    DC_CHECK_LAUNCH();
+  }
+  if (!(parts & 1)) return 0;
   if (bn_y != nullptr && bn_slab != nullptr)
     return dc_conv_dgrad_bnstats(&d, N, Hi, Wi, ws.dP, HEAD_NP, ws.wb, dx, lddx, bn_y, bn_ldy, bn_mean, bn_invstd, bn_mscale, bn_mshift,
                                  bn_relu, bn_slab, stream);
@@ -829,11 +836,11 @@ extern "C" int dc_head_bwd_bnstats(int dtype, int N, int Cin, int Hi, int Wi, co
 // coefficients.  bn_slab != NULL additionally leaves that BatchNorm's backward sums there (as dc_head_bwd_bnstats; needs mean / invstd).
 extern "C" int dc_head_bwd_bnin(int dtype, int N, int Cin, int Hi, int Wi, const void* y, int ldy, const float* scale, const float* shift,
                                 int relu, const float* dlogits_nchw, const float* w, void* dx, int lddx, float* grad_w, void* workspace,
-                                const float* bn_mean, const float* bn_invstd, float* bn_slab, void* stream) {
+                                const float* bn_mean, const float* bn_invstd, float* bn_slab, int parts, void* stream) {
   DC_REQUIRE(y != nullptr && scale != nullptr && shift != nullptr, "dc_head_bwd_bnin: null argument");
   DC_REQUIRE(bn_slab == nullptr || (bn_mean != nullptr && bn_invstd != nullptr), "dc_head_bwd_bnin: the BatchNorm sums need mean and invstd");
   return head_bwd_impl(dtype, N, Cin, Hi, Wi, nullptr, 0, dlogits_nchw, w, dx, lddx, grad_w, workspace, stream, y, ldy, bn_mean, bn_invstd, scale,
-                       shift, relu, bn_slab);
+                       shift, relu, bn_slab, parts);
 }
 
 extern "C" int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, void* out, int ldo, void* stream) {

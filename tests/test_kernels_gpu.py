@@ -1260,8 +1260,9 @@ def test_head_on_unstored_batchnorm_output(shape, relu):
         slab = torch.full((2, rows, Cin), float("nan"), device=dev())
         _, dx = empty_nhwc(N, H, W, Cin, dtype)
         gw = torch.full((Cin, 3, 3, 3), float("nan"), device=dev())
-        L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, vptr(yv), Cin + 16, vptr(scale), vptr(shift), relu, vptr(ref_dl), vptr(wd), vptr(dx), Cin,
-               vptr(gw), wsp, vptr(mean), vptr(invstd), vptr(slab) if with_sums else None, S())
+        for parts in ((3,) if with_sums else (1, 2)):          # in one call, or chain part and weight-gradient part one after the other
+            L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, vptr(yv), Cin + 16, vptr(scale), vptr(shift), relu, vptr(ref_dl), vptr(wd), vptr(dx), Cin,
+                   vptr(gw), wsp, vptr(mean), vptr(invstd), vptr(slab) if with_sums else None, parts, S())
         torch.cuda.synchronize()
         assert torch.equal(from_nhwc(dx), from_nhwc(ref_dx))
         assert torch.equal(slab, ref_slab) if with_sums else torch.isnan(slab).all()
