@@ -233,6 +233,9 @@ class Engine:
         self.on_grad_ready: Optional[Callable[[List[str]], None]] = None
         self._debug_skip_side = os.environ.get("DC_DEBUG_SKIP_SIDE", "0") == "1"
         self._debug_skip_kind = os.environ.get("DC_DEBUG_SKIP_KIND", "")     # "_conv" / "_dw": skip that kind of weight gradient (timing only)
+        # timing experiments only: "fwd" / "bwd" / "both" leave out the BatchNorm finalize launches (results are then garbage): what the
+        # 77 + 78 tiny kernels and the dispatch gaps around them cost the chain
+        self._debug_skip_finalize = os.environ.get("DC_DEBUG_SKIP_BN_FINALIZE", "")
         self.region_marks: Optional[list] = None      # bench.py sets a list to collect (name, event) at the encoder boundaries
         self.loss_args: Optional[dict] = None         # set per call by nn.TrainStep (DC_FUSE_HEAD_LOSS): loss inside the classifier's kernel
 
@@ -564,8 +567,17 @@ class Engine:
         rld = residual.ld if residual is not None else 0
 
         def fwd_train():
-            L.call("dc_bn_finalize", Cc, M, L.dptr(slab), rows, gam, bet, rm, rv, nbt, BN_MOMENTUM, BN_EPS, L.dptr(scale),
-                   L.dptr(shift), L.dptr(mean), L.dptr(invstd), self._st())
+            if self._debug_skip_finalize == "async":
+                # (timing experiment with realistic data: the finalize runs unordered on a stream of its own, the chain uses the previous
+                # step's coefficients)
+                if not hasattr(self, "_dbg_stream"):
+                    self._dbg_stream = torch.cuda.Stream(device=self.device)
+                with torch.cuda.stream(self._dbg_stream):
+                    L.call("dc_bn_finalize", Cc, M, L.dptr(slab), rows, gam, bet, rm, rv, nbt, BN_MOMENTUM, BN_EPS, L.dptr(scale),
+                           L.dptr(shift), L.dptr(mean), L.dptr(invstd), self._st())
+            elif self._debug_skip_finalize not in ("fwd", "both"):
+                L.call("dc_bn_finalize", Cc, M, L.dptr(slab), rows, gam, bet, rm, rv, nbt, BN_MOMENTUM, BN_EPS, L.dptr(scale),
+                       L.dptr(shift), L.dptr(mean), L.dptr(invstd), self._st())
             if not lazy:
                 L.call("dc_bn_apply", bdt, M, Cc, y.ptr, y.ld, L.dptr(scale), L.dptr(shift), rptr(), rld, relu_i, o.ptr, o.ld, self._st())
 
@@ -612,7 +624,8 @@ class Engine:
                 if fused is None:
                     L.call("dc_bn_bwd_reduce", bdt, M, Cc, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, L.dptr(mean),
                            L.dptr(invstd), L.dptr(bslab), L.dptr(scale), L.dptr(shift), self._st())
-                L.call("dc_bn_bwd_finalize", Cc, L.dptr(rslab), rrows, dgam, dbet, self._st())
+                if self._debug_skip_finalize not in ("bwd", "both"):
+                    L.call("dc_bn_bwd_finalize", Cc, L.dptr(rslab), rrows, dgam, dbet, self._st())
                 L.call("dc_bn_bwd_apply", bdt, M, Cc, M, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, gam, L.dptr(mean),
                        L.dptr(invstd), dgam, dbet, dy.ptr, dy.ld, g_out.ptr if g_out is not None else None,
                        g_out.ld if g_out is not None else 0, L.dptr(scale), L.dptr(shift), self._st())
