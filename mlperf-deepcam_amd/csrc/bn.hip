@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "bn_fin.h"
 
 namespace dc {
 
@@ -132,78 +133,9 @@ __global__ __launch_bounds__(256) void colred_kernel(long M, int C, int RED_ROWS
   }
 }
 
-// Column sums of a [rows][C] fp32 slab in fp64: 4 channels x 64 row-lanes per 256-thread block, so that even the
-// 3456-row slabs of the 384x576 layers cost ~50 dependent loads per thread instead of thousands.
-constexpr int FIN_CH = 4, FIN_RL = 64;
-__device__ inline void slab_colsum2(const float* __restrict__ s0, const float* __restrict__ s1, int rows, int C, int c,
-                                    bool ok, double (&red)[2][FIN_RL][FIN_CH], double& a, double& b) {
-  const int cl = threadIdx.x & (FIN_CH - 1), rl = threadIdx.x / FIN_CH;
-  // FIN_UR independent partial sums per thread and slab: the 13 824-row slabs of the 384 x 576 layers are 216 rows per thread, and
-  // with two loads in flight the kernel was a chain of ~100 memory latencies (63-83 us); the partials are combined in a fixed order
-  constexpr int FIN_UR = 8;
-  double xs[FIN_UR], ys[FIN_UR];
-#pragma unroll
-  for (int u = 0; u < FIN_UR; ++u) xs[u] = ys[u] = 0.0;
-  if (ok) {
-    int r = rl;
-    for (; r + (FIN_UR - 1) * FIN_RL < rows; r += FIN_UR * FIN_RL) {
-      float fx[FIN_UR], fy[FIN_UR];
-#pragma unroll
-      for (int u = 0; u < FIN_UR; ++u) {
-        fx[u] = s0[(size_t)(r + u * FIN_RL) * C + c];
-        fy[u] = s1[(size_t)(r + u * FIN_RL) * C + c];
-      }
-#pragma unroll
-      for (int u = 0; u < FIN_UR; ++u) {
-        xs[u] += (double)fx[u];
-        ys[u] += (double)fy[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < FIN_UR - 1; ++u) {          // at most FIN_UR - 1 rows left (static indices: the partials stay in registers)
-      const int rr = r + u * FIN_RL;
-      if (rr < rows) {
-        xs[u] += (double)s0[(size_t)rr * C + c];
-        ys[u] += (double)s1[(size_t)rr * C + c];
-      }
-    }
-  }
-  red[0][rl][cl] = ((xs[0] + xs[1]) + (xs[2] + xs[3])) + ((xs[4] + xs[5]) + (xs[6] + xs[7]));
-  red[1][rl][cl] = ((ys[0] + ys[1]) + (ys[2] + ys[3])) + ((ys[4] + ys[5]) + (ys[6] + ys[7]));
-  __syncthreads();
-  a = b = 0.0;
-  if (threadIdx.x < FIN_CH) {
-#pragma unroll 8
-    for (int i = 0; i < FIN_RL; ++i) {
-      a += red[0][i][threadIdx.x];
-      b += red[1][i][threadIdx.x];
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void bn_finalize_kernel(int C, double inv_count, double unbias, const float* __restrict__ slab,
-                                                          int rows, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* running_mean,
-                                                          float* running_var, int64_t* nbt, float momentum, float eps,
-                                                          float* scale, float* shift, float* save_mean, float* save_invstd) {
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinArgs a) {
   __shared__ double red[2][FIN_RL][FIN_CH];
-  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
-  double s, q;
-  slab_colsum2(slab, slab + (size_t)rows * C, rows, C, c, c < C, red, s, q);
-  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;
-  if (threadIdx.x >= FIN_CH || c >= C) return;
-  const double mean = s * inv_count;
-  double var = q * inv_count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float g = gamma[c], b = beta[c];
-  const float sc = g * invstd;
-  scale[c] = sc;
-  shift[c] = b - (float)mean * sc;
-  if (save_mean) save_mean[c] = (float)mean;
-  if (save_invstd) save_invstd[c] = invstd;
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+  bn_finalize_block(a, blockIdx.x, red);
 }
 
 __global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -410,9 +342,13 @@ extern "C" int dc_bn_finalize(int C, long count, const float* slab, int rows, co
   DC_REQUIRE(C > 0 && rows > 0 && slab && gamma && beta && scale && shift, "dc_bn_finalize: bad argument");
   if (count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
   const double unbias = (double)count / (double)(count - 1);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, (hipStream_t)stream, C, 1.0 / (double)count,
-                     unbias, slab, rows, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
-                     scale, shift, save_mean, save_invstd);
+  BnFinArgs a;
+  a.slab = slab; a.rows = rows; a.C = C; a.inv_count = 1.0 / (double)count; a.unbias = unbias;
+  a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+  a.nbt = reinterpret_cast<long long*>(num_batches_tracked); a.momentum = momentum; a.eps = eps;
+  a.scale = scale; a.shift = shift; a.save_mean = save_mean; a.save_invstd = save_invstd;
+  a.sync = nullptr; a.epoch = 0;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, (hipStream_t)stream, a);
   DC_CHECK_LAUNCH();
   return 0;
 }

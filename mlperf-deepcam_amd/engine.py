@@ -96,6 +96,11 @@ class LazyAct:
         self.N, self.H, self.W, self.C = y.N, y.H, y.W, y.C
         self._grad: Optional[Act] = None
         self.grad_init = False
+        # BatchNorm finalize inside the consumer (Engine.fuse_bn_finalize): `fin` = the finalize call's arguments (set by Engine._bn),
+        # `fin_consumer` = the consumer has taken the job (set by Engine._dw at build time), `fin_now` = it really does in this forward pass
+        self.fin: Optional[dict] = None
+        self.fin_consumer = False
+        self.fin_now = False
 
     @property
     def M(self) -> int:
@@ -171,6 +176,14 @@ class Engine:
         # the BatchNorm + ReLU in front of the classifier head (upsample.deconv3.1/.2) is applied by the head itself while it loads
         # (dc_head_fwd_loss_bnin / dc_head_bwd_bnin): the 256-channel 384 x 576 activation is never stored (at local batch 8: a 0.35 ms
         # dc_bn_apply pass and 1.8 GB of traffic less per step).  bf16 only (the fused head kernel).
+        # DC_FUSE_BN_FINALIZE=1: the finalize step of a BatchNorm whose output is never stored runs inside the depthwise kernel that consumes
+        # it (dc_dwconv_fwd_bnfin, csrc/bn_fin.h) instead of as a launch of its own.  Built because the finalize launches of the forward
+        # pass cost the chain 1.5 ms at local batch 8 (DC_DEBUG_SKIP_BN_FINALIZE=async); OFF because handing the coefficients from the
+        # leader workgroups to the others inside one kernel goes through the memory-side coherence point on an eight-XCD chip (write-through
+        # stores, a count, polls, agent-scope loads: about 12 us per layer) and that is no cheaper than the dispatch boundary it removes
+        # (38.86 vs 38.69 ms per step; scripts/bnfin_bench.py: 41.9 vs 36.6 us per layer alone).
+        self.fuse_bn_finalize = os.environ.get("DC_FUSE_BN_FINALIZE", "0") != "0"
+        self._fin_syncs: List[torch.Tensor] = []      # hand-over words of those layers; the last word of each counts waits that ran out
         self.fuse_bn_into_head = dtype == torch.bfloat16 and os.environ.get("DC_FUSE_BN_INTO_HEAD", "1") != "0"
         # depthwise weight gradient taken inside the depthwise data gradient (dc_dwconv_dgrad_bnstats_wgrad) where the layer's input is a
         # never-stored BatchNorm output: the separate dc_dwconv_wgrad launch (and its second read of dy and y) disappears
@@ -281,6 +294,11 @@ class Engine:
         self.side.wait_event(torch.cuda.current_stream().record_event())
         with torch.cuda.stream(self.side):
             fn(C.c_void_p(self.workspace2.data_ptr()))
+
+    def fin_waits_run_out(self) -> int:
+        """Workgroups (over all steps so far) whose wait for the in-kernel BatchNorm finalize ran out and that computed their coefficients
+        themselves (csrc/bn_fin.h): slower, same bits.  Zero in a healthy run; synchronises."""
+        return int(sum(int(s[-1]) for s in self._fin_syncs))
 
     # ---- independent forward branches on their own streams -----------------------------------------------------------------
     # The ASPP branches read the same encoder output and write disjoint channel slices of one buffer.  Each dilated 3x3 conv is
@@ -484,7 +502,26 @@ class Engine:
         def fwd():
             L.call("dc_dwconv_fwd", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, pw, y.ptr, y.ld, ps, psh, prelu, self._st())
 
-        self.fwd_train.append(fwd)
+        fwd_train = fwd
+        words = lib.dc_dwconv_fwd_bnfin_sync_words(self.dt, Cc, stride, dil) if (lazy and self.fuse_bn_finalize and x.fin is not None) else 0
+        if words > 0:
+            # this kernel also runs the finalize step of the BatchNorm it reads through (dc_dwconv_fwd_bnfin)
+            x.fin_consumer = True
+            f = x.fin
+            sync = torch.zeros(words, dtype=torch.int32, device=self.device)
+            self._keep += [sync, f["slab"], f["mean"], f["invstd"]]
+            self._fin_syncs.append(sync)
+            vp = lambda v: v.value if isinstance(v, C.c_void_p) else v.data_ptr()
+            bn = L.BnFin(f["count"], vp(f["slab"]), f["rows"], vp(f["gamma"]), vp(f["beta"]), vp(f["rm"]), vp(f["rv"]), vp(f["nbt"]), BN_MOMENTUM,
+                         BN_EPS, vp(f["scale"]), vp(f["shift"]), vp(f["mean"]), vp(f["invstd"]), sync.data_ptr(), 0)
+
+            def fwd_train():
+                if not x.fin_now:
+                    return fwd()
+                L.call("dc_dwconv_fwd_bnfin", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, pw, y.ptr, y.ld, C.byref(bn), prelu, self._st())
+                bn.epoch += 1
+
+        self.fwd_train.append(fwd_train)
         self.fwd_eval.append(fwd)
 
         def make_bwd():
@@ -567,6 +604,11 @@ class Engine:
         rld = residual.ld if residual is not None else 0
 
         def fwd_train():
+            if lz is not None:
+                # (a hipGraph capture keeps the two-launch form: the hand-over's launch counter is a kernel argument)
+                lz.fin_now = lz.fin_consumer and not torch.cuda.is_current_stream_capturing()
+                if lz.fin_now:
+                    return
             if self._debug_skip_finalize == "async":
                 # (timing experiment with realistic data: the finalize runs unordered on a stream of its own, the chain uses the previous
                 # step's coefficients)
@@ -589,6 +631,8 @@ class Engine:
         lz = LazyAct(y, scale, shift, relu, (name or bname) + ".lazy") if lazy else None
         if lz is not None:
             lz.mean, lz.invstd, lz.fused_bwd = mean, invstd, None
+            lz.fin = dict(count=M, slab=slab, rows=rows, gamma=gam, beta=bet, rm=rm, rv=rv, nbt=nbt, scale=scale, shift=shift, mean=mean,
+                          invstd=invstd)
         elif residual is None and out is None and (self.mask_from_y or not relu):
             # a stored BatchNorm(+ReLU) output whose ReLU mask is recomputed from y: a sole dense-conv consumer may take this
             # BatchNorm's backward sums in its data-gradient epilogue (_conv(..., sole_consumer=True), the classifier head)

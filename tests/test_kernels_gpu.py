@@ -1201,6 +1201,67 @@ def test_head_forward_with_fused_loss(shape, lab_dtype):
     assert torch.isnan(ls).all() and torch.isnan(dl[0, :, 1, 2]).all() and int(torch.isnan(dl).sum()) == 3
 
 
+BNFIN_CASES = [
+    # name, C, dil, N, H, W, rows            (rows: partial-sum rows of the slab, as the pointwise conv in front would leave them)
+    ("middle_flow_like", 728, 1, 2, 24, 36, 14),      # three channel blocks, the last one ragged (728 = 2 * 256 + 216)
+    ("one_tile", 64, 1, 1, 8, 8, 3),                  # ONE pixel tile per channel block: a single leader does every finalize block
+    ("dilated", 256, 2, 1, 16, 24, 70),               # more rows than the 64 row lanes of a finalize block
+    ("thin", 128, 1, 2, 40, 24, 600),                 # 16-group workgroups; a slab longer than one eight-row sweep per lane
+]
+
+
+@pytest.mark.parametrize("fallback", [0, 1], ids=["leaders", "wait_ran_out"])
+@pytest.mark.parametrize("case", BNFIN_CASES, ids=[c[0] for c in BNFIN_CASES])
+def test_depthwise_forward_with_batchnorm_finalize_inside(case, fallback):
+    """dc_dwconv_fwd_bnfin (the first workgroups of the depthwise grid run the BatchNorm finalize blocks, the others wait for them)
+    against dc_bn_finalize followed by dc_dwconv_fwd: output, scale / shift, saved mean / invstd, running statistics and
+    num_batches_tracked bit for bit, over three launches (the hand-over counter runs on) -- also on the path a workgroup takes when its
+    wait runs out (forced by the test switch: every workgroup computes its coefficients itself, serially, in the same order)."""
+    name, Cc, dil, N, H, W, rows = case
+    dtype = torch.bfloat16
+    dt = L.dtype_code(dtype)
+    M = N * H * W
+    x = q(rnd(N, Cc, H, W, seed=1), dtype)
+    _, xv = to_nhwc(x, dtype, ld=Cc + 8)
+    wm = rnd(Cc, 1, 3, 3, seed=2, scale=0.3).to(dev())
+    wp = torch.empty(9 * Cc, device=dev())
+    L.call("dc_dwconv_pack_weights", Cc, vptr(wm), vptr(wp), S())
+    gam, bet = (rnd(Cc, seed=3).abs() + 0.5).to(dev()), rnd(Cc, seed=4, scale=0.3).to(dev())
+    words = L.load().dc_dwconv_fwd_bnfin_sync_words(dt, Cc, 1, dil)
+    assert words == ((Cc // 8 + 31) // 32 if Cc // 8 > 16 else 1) + 1
+
+    def state():
+        return dict(rm=torch.zeros(Cc, device=dev()), rv=torch.ones(Cc, device=dev()), nbt=torch.zeros(1, dtype=torch.int64, device=dev()),
+                    scale=torch.full((Cc,), float("nan"), device=dev()), shift=torch.full((Cc,), float("nan"), device=dev()),
+                    mean=torch.full((Cc,), float("nan"), device=dev()), invstd=torch.full((Cc,), float("nan"), device=dev()))
+
+    ref, got = state(), state()
+    sync = torch.zeros(max(words, 1), dtype=torch.int32, device=dev())
+    try:
+        L.call("dc_set_option", b"dw_fin_fallback", fallback)
+        for epoch in range(3):
+            slab = (rnd(2, rows, Cc, seed=10 + epoch).abs() * (M / rows)).to(dev())          # "sums" and "sums of squares" of about M values
+            slab[1] += slab[0] ** 2 / (M / rows) * 1.5
+            _, y0 = empty_nhwc(N, H, W, Cc, dtype)
+            L.call("dc_bn_finalize", Cc, M, vptr(slab), rows, vptr(gam), vptr(bet), vptr(ref["rm"]), vptr(ref["rv"]), vptr(ref["nbt"]), 0.1, 1e-5,
+                   vptr(ref["scale"]), vptr(ref["shift"]), vptr(ref["mean"]), vptr(ref["invstd"]), S())
+            L.call("dc_dwconv_fwd", dt, Cc, 1, dil, N, H, W, vptr(xv), Cc + 8, vptr(wp), vptr(y0), Cc, vptr(ref["scale"]), vptr(ref["shift"]), 1, S())
+            _, y1 = empty_nhwc(N, H, W, Cc, dtype)
+            bn = L.BnFin(M, slab.data_ptr(), rows, gam.data_ptr(), bet.data_ptr(), got["rm"].data_ptr(), got["rv"].data_ptr(), got["nbt"].data_ptr(),
+                         0.1, 1e-5, got["scale"].data_ptr(), got["shift"].data_ptr(), got["mean"].data_ptr(), got["invstd"].data_ptr(),
+                         sync.data_ptr(), epoch)
+            L.call("dc_dwconv_fwd_bnfin", dt, Cc, 1, dil, N, H, W, vptr(xv), Cc + 8, vptr(wp), vptr(y1), Cc, C.byref(bn), 1, S())
+            torch.cuda.synchronize()
+            assert torch.equal(from_nhwc(y1), from_nhwc(y0)), f"launch {epoch}: output"
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), f"launch {epoch}: {k}"
+        # every finalize block counted once per launch; no wait ran out (the leaders are the first workgroups the dispatcher starts)
+        assert int(sync[:-1].sum()) == 3 * ((Cc + 3) // 4), sync.tolist()
+        assert int(sync[-1]) == 0, f"{int(sync[-1])} workgroups waited in vain"
+    finally:
+        L.call("dc_set_option", b"dw_fin_fallback", 0)
+
+
 @pytest.mark.parametrize("relu", [1, 0], ids=["relu", "affine"])
 @pytest.mark.parametrize("shape", [(2, 20, 70), (1, 9, 229), (2, 8, 32)], ids=["3x3tiles", "8tiles_wide", "exact_tiles"])
 def test_head_on_unstored_batchnorm_output(shape, relu):
