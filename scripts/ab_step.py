@@ -17,10 +17,13 @@ opt = dnn.make_optimizer(optn, net, 1e-3, 1e-8, 1e-2)
 step = dnn.TrainStep(net, opt, dnn.class_weights(), B, 768, 1152)
 g = torch.Generator().manual_seed(1); dev = torch.device("cuda", 0)
 x = torch.rand(B, 16, 768, 1152, generator=g).to(dev); y = torch.randint(0, 3, (B, 768, 1152), generator=g).to(dev)
-for _ in range(4): step(x, y)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(steps): step(x, y)
-torch.cuda.synchronize(); print("MS", (time.perf_counter() - t0) / steps * 1e3, step.loss())
+import contextlib
+ctx = torch.cuda.stream(torch.cuda.Stream(device=dev)) if os.environ.get("AB_OWN_STREAM", "0") == "1" else contextlib.nullcontext()   # A/B: a created stream instead of the default one
+with ctx:
+    for _ in range(4): step(x, y)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): step(x, y)
+    torch.cuda.synchronize(); print("MS", (time.perf_counter() - t0) / steps * 1e3, step.loss())
 ''' % (ROOT, ROOT)
 
 ap = argparse.ArgumentParser()
