@@ -45,6 +45,7 @@ class Act:
             self.buf = torch.empty((N, H, W, self.ld), dtype=dtype or eng.dtype, device=eng.device)
             eng.act_bytes += self.buf.numel() * self.buf.element_size()
             eng.saved[name] = self.buf
+            eng.saved_channels[name] = Cc      # (the buffer's last dimension is ld >= Cc; the pad channels hold whatever the allocator left)
         else:
             assert (parent.N, parent.H, parent.W) == (N, H, W) and off + Cc <= parent.C
             self.buf, self.ld = parent.buf, parent.ld
@@ -140,6 +141,7 @@ class Engine:
         # name -> tensor of everything forward leaves behind for backward (activations, BatchNorm coefficient vectors): lets a
         # test put two engines on ONE linearisation point (tests/test_model_gpu.py::test_backward_parity_at_shared_activations)
         self.saved: Dict[str, torch.Tensor] = {}
+        self.saved_channels: Dict[str, int] = {}
 
         # ---- flat arenas (shared between engines of different batch shape, e.g. train B=2 and validation B=1) ----
         if share_from is not None:

@@ -451,12 +451,15 @@ def test_forward_activations_by_stage_bf16_vs_fp32_full_size():
     B, H, W = 2, 768, 1152
     x, _ = make_inputs(B, H, W)
     worst = {}
+    junk = torch.full((1 << 30,), float("nan"), device=DEV)      # whatever the allocator hands out next is NaN: pad channels must not matter
+    del junk
     e32 = Engine(B, H, W, torch.float32, seed=333)
     e32.params.copy_(e32.params.to(torch.bfloat16).float())
     e32.mark_weights_changed()
     e32.forward(x.to(DEV), train=True)
     torch.cuda.synchronize()
-    ref = {k: t.float().cpu() for k, t in e32.saved.items()}
+    valid = lambda e, k, t: t[..., :e.saved_channels[k]] if k in e.saved_channels else t      # never the pad channels of a pixel row
+    ref = {k: valid(e32, k, t).float().cpu() for k, t in e32.saved.items()}
     del e32
     torch.cuda.empty_cache()
     e16 = Engine(B, H, W, torch.bfloat16, seed=333)
@@ -473,7 +476,7 @@ def test_forward_activations_by_stage_bf16_vs_fp32_full_size():
         # per-channel coefficient vectors are covered through the activations they produce
         if t.numel() < 4096 or not k.startswith(("xception_features.", "aspp", "global_avg_pool", "conv1", "bn1", "conv2", "bn2", "last_conv", "upsample")):
             continue
-        err = _rel_l2(t.float().cpu(), ref[k])
+        err = _rel_l2(valid(e16, k, t).float().cpu(), ref[k])
         st = _stage_of(k)
         if err > worst.get(st, ("", 0.0))[1]:
             worst[st] = (k, err)
