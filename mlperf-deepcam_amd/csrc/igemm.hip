@@ -881,6 +881,7 @@ extern "C" int dc_wgrad_set_256(int m);
 extern "C" int dc_wgrad_set_thin(int m);
 extern "C" int dc_wgrad_set_slots(int n);
 extern "C" int dc_head_set_fused(int v);
+extern "C" int dc_head_set_dgrad_fused(int v);
 extern "C" int dc_dw_set_option(const char* name, int value);
 extern "C" int dc_bn_set_option(const char* name, int value);
 extern "C" int dc_set_option(const char* name, int value) {
@@ -914,6 +915,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "thin_wgrad") == 0) return dc_wgrad_set_thin(value);
   if (name != nullptr && strcmp(name, "wgrad256_slots") == 0) return dc_wgrad_set_slots(value);
   if (name != nullptr && strcmp(name, "head_fused") == 0) return dc_head_set_fused(value);
+  if (name != nullptr && strcmp(name, "head_dgrad_fused") == 0) return dc_head_set_dgrad_fused(value);
   if (name != nullptr && dc_dw_set_option(name, value) == 0) return 0;
   if (name != nullptr && dc_bn_set_option(name, value) == 0) return 0;
   return dc_fail("dc_set_option: unknown option", __FILE__, __LINE__);

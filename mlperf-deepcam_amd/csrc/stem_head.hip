@@ -768,6 +768,141 @@ extern "C" int dc_conv_dgrad_bnstats(const dc_conv_desc* d, int N, int Hi, int W
                                      void* dx, int lddx, const void* y, int ldy, const float* mean, const float* invstd,
                                      const float* mscale, const float* mshift, int relu, float* slab, void* stream);
 
+// The head's data gradient as ONE streaming kernel (bf16, 256 channels): dx[px][256] = dP[px][32] . wb[256][32]^T is a GEMM with a single
+// 32-deep K step, i.e. 1.9 GB of traffic (dP in, dx out, the BatchNorm input in for the sums) around 14 GFLOP.  On the tiled GEMM kernels a
+// workgroup's life is load -> one MFMA step -> epilogue, one or three workgroups per CU: 620 us at local batch 8.  Here nothing goes
+// through LDS: a wave keeps the weight fragments of its 64 channels in registers for its whole life and, per 16 pixels, loads one dP
+// fragment and (BST) the BatchNorm input at its own outputs straight from memory, four pixel groups in flight; the output leaves from
+// the accumulators.  BST: the BatchNorm-backward sums of dc_conv_dgrad_bnstats (sum g, sum g * xhat, g masked by the ReLU recomputed
+// from y), one slab row per 128 pixels as there.  Same MFMA per output element as the tiled kernels: dx bit-equal.
+struct HeadDgradBst {
+  const bf16* y;
+  int ldy;
+  const float* mean;
+  const float* invstd;
+  const float* mscale;
+  const float* mshift;
+  int relu;
+  float* slab;     // [2][rows][256]
+  int rows;
+};
+
+__device__ inline float head_row_sum16(float v) {      // sum over the 16 lanes of a DPP row (the 16 pixels of a group)
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
+__device__ inline uint32_t head_swap_rows16(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); }   // lane ^ 16
+
+template <bool BST>
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const bf16* __restrict__ dP, const bf16* __restrict__ wb, bf16* __restrict__ dx,
+                                                         int lddx, long M, const HeadDgradBst b) {
+  constexpr int CIN = 256, GPB = 4;                     // pixel groups (of 16) requested together
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const bool odd = fg & 1;
+  // A operand: rows = channels.  Block i of this wave: channels 64 * wave + 16 * i + (0..15); this lane's row fr, K group fg
+  vec16 fa[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[i] = ldg16(wb + (size_t)(64 * wave + 16 * i + fr) * HEAD_NP + fg * 8);
+  // D[row = channel fg * 4 + r][col = pixel fr].  The lane pairs (fg, fg ^ 1) trade halves of two neighbouring channel blocks
+  // (igemm256.hip's register epilogue), after which a lane owns EIGHT consecutive channels of its pixel per block pair p:
+  //   cpair(p) = 64 * wave + (2 * p + odd) * 16 + (fg >> 1) * 8      -> 16-byte stores, 16-byte BatchNorm-input loads
+  auto cpair = [&](int p) { return 64 * wave + (2 * p + (odd ? 1 : 0)) * 16 + (fg >> 1) * 8; };
+  [[maybe_unused]] float mu[2][8], is[2][8], ms[2][8], mh[2][8];
+  if constexpr (BST) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = cpair(p) + e;
+        mu[p][e] = b.mean[c];
+        is[p][e] = b.invstd[c];
+        ms[p][e] = b.relu ? b.mscale[c] : 0.f;
+        mh[p][e] = b.relu ? b.mshift[c] : 0.f;
+      }
+  }
+  const long chunks = (M + 127) / 128;
+  for (long chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+    [[maybe_unused]] float s0[2][8], s1[2][8];
+    if constexpr (BST) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s0[p][e] = s1[p][e] = 0.f;
+    }
+#pragma unroll 1
+    for (int g0 = 0; g0 < 8; g0 += GPB) {
+      vec16 fb[GPB];
+      [[maybe_unused]] vec16 yv[GPB][2];
+      bool ok[GPB];
+#pragma unroll
+      for (int u = 0; u < GPB; ++u) {
+        const long px = chunk * 128 + (g0 + u) * 16 + fr;
+        ok[u] = px < M;
+        fb[u] = ok[u] ? ldg16(dP + (size_t)px * HEAD_NP + fg * 8) : zero16();
+        if constexpr (BST) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) yv[u][p] = ok[u] ? ldg16(b.y + (size_t)px * b.ldy + cpair(p)) : zero16();
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GPB; ++u) {
+        const long px = chunk * 128 + (g0 + u) * 16 + fr;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+          accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[2 * p]), __builtin_bit_cast(bf16x8, fb[u]), accA, 0, 0, 0);
+          accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[2 * p + 1]), __builtin_bit_cast(bf16x8, fb[u]), accB, 0, 0, 0);
+          const uint32_t a0 = pack2_bf16(accA[0], accA[1]), a1 = pack2_bf16(accA[2], accA[3]);
+          const uint32_t b0 = pack2_bf16(accB[0], accB[1]), b1 = pack2_bf16(accB[2], accB[3]);
+          const uint32_t r0 = head_swap_rows16(odd ? a0 : b0), r1 = head_swap_rows16(odd ? a1 : b1);
+          vec16 o;
+          o.w[0] = odd ? r0 : a0;
+          o.w[1] = odd ? r1 : a1;
+          o.w[2] = odd ? b0 : r0;
+          o.w[3] = odd ? b1 : r1;
+          if (ok[u]) stg16(dx + (size_t)px * lddx + cpair(p), o);
+          if constexpr (BST) {
+            if (ok[u]) {
+              // the stored (bf16-rounded) gradient and the BatchNorm input, element for element as the tiled kernels' epilogue
+              float f[8], yf[8];
+              unpack(o, f, bf16());
+              unpack(yv[u][p], yf, bf16());
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float gm = (!b.relu || fmaf(yf[e], ms[p][e], mh[p][e]) > 0.f) ? f[e] : 0.f;
+                s0[p][e] += gm;
+                s1[p][e] = fmaf(gm, (yf[e] - mu[p][e]) * is[p][e], s1[p][e]);
+              }
+            }
+          }
+        }
+      }
+    }
+    if constexpr (BST) {
+      // fold the 16 pixels of a group (the lanes of a DPP row); lane fr == 0 of every row then owns its eight channels of every pair
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t0 = head_row_sum16(s0[p][e]), t1 = head_row_sum16(s1[p][e]);
+          if (fr == 0) {
+            const int c = cpair(p) + e;
+            b.slab[((size_t)0 * b.rows + chunk) * CIN + c] = t0;
+            b.slab[((size_t)1 * b.rows + chunk) * CIN + c] = t1;
+          }
+        }
+    }
+  }
+}
+
+static int g_head_dgrad_fused = 1;   // "head_dgrad_fused": 0 = the head's data gradient on the tiled GEMM kernels (A/B, tests)
+extern "C" int dc_head_set_dgrad_fused(int v) { g_head_dgrad_fused = v ? 1 : 0; return 0; }
+
 // bn_y != nullptr: x is act(bn(bn_y)) and the data gradient also leaves that BatchNorm's backward sums in bn_slab
 static int head_bwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
                          const float* w, void* dx, int lddx, float* grad_w, void* workspace, void* stream, const void* bn_y, int bn_ldy,
@@ -811,6 +946,17 @@ static int head_bwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* 
     DC_CHECK_LAUNCH();
   }
   if (!(parts & 1)) return 0;
+  if (dtype == DC_BF16 && Cin == 256 && g_head_dgrad_fused && bn_y != nullptr && bn_slab != nullptr) {
+    // (without the BatchNorm sums the streaming kernel has too little in flight per wave and loses to the tiled kernels: 755 vs 714 us)
+    const int chunks = cdiv(P, 128);
+    const int grid = chunks < 2048 ? chunks : 2048;
+    if (int e = dc_check_view(bn_y, bn_ldy, Cin, dtype, "dc_head_bwd bn_y")) return e;
+    DC_REQUIRE(bn_mean && bn_invstd && (!bn_relu || (bn_mscale && bn_mshift)), "dc_head_bwd: missing BatchNorm vectors");
+    const HeadDgradBst b{(const bf16*)bn_y, bn_ldy, bn_mean, bn_invstd, bn_mscale, bn_mshift, bn_relu, bn_slab, chunks};
+    hipLaunchKernelGGL(head_dgrad_kernel<true>, dim3(grid), dim3(256), 0, st, (const bf16*)ws.dP, (const bf16*)ws.wb, (bf16*)dx, lddx, (long)P, b);
+    DC_CHECK_LAUNCH();
+    return 0;
+  }
   if (bn_y != nullptr && bn_slab != nullptr)
     return dc_conv_dgrad_bnstats(&d, N, Hi, Wi, ws.dP, HEAD_NP, ws.wb, dx, lddx, bn_y, bn_ldy, bn_mean, bn_invstd, bn_mscale, bn_mshift,
                                  bn_relu, bn_slab, stream);

@@ -26,7 +26,7 @@ def bench(name, fn):
     for _ in range(10): fn()
     e1.record(); torch.cuda.synchronize()
     print(f"  {name:58s} {e0.elapsed_time(e1) / 10 * 1e3:8.1f} us", flush=True)
-for opts in ("", "igemm256=0", "igemm256=2"):
+for opts in ("", "head_dgrad_fused=0"):
     for o in filter(None, opts.split(",")):
         k, v = o.split("="); L.call("dc_set_option", k.encode(), int(v))
     print(f"[{opts or 'defaults'}]")
@@ -34,6 +34,7 @@ for opts in ("", "igemm256=0", "igemm256=2"):
     bench("dc_head_fwd_loss (stored input)", lambda: L.call("dc_head_fwd_loss", dt, N, Cin, H, W, P(a), Cin, P(w), None, wsp, P(labels), 8, P(cw), 1e-7, P(ls), P(dl), P(pred), P(cnt), st))
     bench("dc_head_fwd_loss_bnin", lambda: L.call("dc_head_fwd_loss_bnin", dt, N, Cin, H, W, P(y), Cin, P(scale), P(shift), 1, P(w), None, wsp, P(labels), 8, P(cw), 1e-7, P(ls), P(dl), P(pred), P(cnt), st))
     bench("dc_head_bwd_bnstats (stored input)", lambda: L.call("dc_head_bwd_bnstats", dt, N, Cin, H, W, P(a), Cin, P(dl), P(w), P(dx), Cin, P(gw), wsp, P(y), Cin, P(mean), P(invstd), P(scale), P(shift), 1, P(slab), st))
-    bench("dc_head_bwd_bnin (with BatchNorm sums)", lambda: L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, P(y), Cin, P(scale), P(shift), 1, P(dl), P(w), P(dx), Cin, P(gw), wsp, P(mean), P(invstd), P(slab), st))
-    bench("dc_head_bwd_bnin (without)", lambda: L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, P(y), Cin, P(scale), P(shift), 1, P(dl), P(w), P(dx), Cin, P(gw), wsp, P(mean), P(invstd), None, st))
-L.call("dc_set_option", b"igemm256", 1)
+    bench("dc_head_bwd_bnin (with BatchNorm sums)", lambda: L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, P(y), Cin, P(scale), P(shift), 1, P(dl), P(w), P(dx), Cin, P(gw), wsp, P(mean), P(invstd), P(slab), 3, st))
+    bench("dc_head_bwd_bnin, chain part only (parts = 1)", lambda: L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, P(y), Cin, P(scale), P(shift), 1, P(dl), P(w), P(dx), Cin, P(gw), wsp, P(mean), P(invstd), P(slab), 1, st))
+    bench("dc_head_bwd_bnin (without)", lambda: L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, P(y), Cin, P(scale), P(shift), 1, P(dl), P(w), P(dx), Cin, P(gw), wsp, P(mean), P(invstd), None, 3, st))
+L.call("dc_set_option", b"head_dgrad_fused", 1)

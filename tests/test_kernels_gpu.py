@@ -1125,6 +1125,21 @@ def test_head(dtype):
     assert torch.equal(from_nhwc(gxv2), from_nhwc(gxv)) and torch.equal(gw2, gw)
     got, ref2 = slab.double().sum(1).cpu(), rslab.double().sum(1).cpu()
     assert (got - ref2).abs().max().item() <= 2e-5 * (ref2.abs().max().item() + 1e-12) + 1e-6
+    if dtype == torch.bfloat16:
+        # the streaming data-gradient kernel of the head (one K step, no LDS) against the tiled GEMM kernels: the same MFMA per element
+        try:
+            L.call("dc_set_option", b"head_dgrad_fused", 0)
+            slab3 = torch.full((2, rows, Cin), float("nan"), device=dev())
+            _, gxv3 = empty_nhwc(N, H, W, Cin, dtype)
+            gw3 = torch.full((Cin, 3, 3, 3), float("nan"), device=dev())
+            L.call("dc_head_bwd_bnstats", dt, N, Cin, H, W, vptr(xv), Cin + 8, vptr(gld), vptr(wd), vptr(gxv3), Cin, vptr(gw3), wsp, vptr(ybv), Cin,
+                   vptr(mean), vptr(invstd), vptr(mscale), vptr(mshift), 1, vptr(slab3), S())
+            torch.cuda.synchronize()
+        finally:
+            L.call("dc_set_option", b"head_dgrad_fused", 1)
+        assert torch.equal(from_nhwc(gxv3), from_nhwc(gxv2)) and torch.equal(gw3, gw2)
+        a3, a2 = slab3.double().sum(1).cpu(), slab.double().sum(1).cpu()
+        assert (a3 - a2).abs().max().item() <= 2e-5 * (a2.abs().max().item() + 1e-12) + 1e-6
 
 
 @pytest.mark.parametrize("shape", [(2, 20, 70), (1, 9, 229), (1, 8, 32)], ids=["3x3tiles", "8tiles_wide", "one_exact_tile"])
