@@ -541,6 +541,7 @@ static int g_igemm256p = 1;          // persistent 256-tile kernel for multi-rou
 static int g_igemm256p_wgs = 0;      // its workgroups ("igemm256p_wgs"); 0: fewest that keep the number of rounds
 static int g_igemm256p_min = 257;    // fewest tiles it is used for ("igemm256p_min")
 static int g_pw384 = 1;
+static int g_pw384_k64 = 1;         // 256 x 384 tiles with 128-byte K rows where the planner picks that tile ("pw384_k64")
 static int pw384_plan(const IgemmParams& p) {
   if (g_pw384 == 0 || !pw384_eligible(p)) return 0;
   if (g_pw384 == 2) return 8;
@@ -550,10 +551,13 @@ static int pw384_plan(const IgemmParams& p) {
   const double c_old = (double)(cdiv(t256, 256) < cdiv(t128, 768) ? cdiv(t256, 256) : cdiv(t128, 768));
   if (p.g.Cout * 10 < (long)cdiv(p.g.Cout, 384) * 384 * 9) return 0;      // a 384-wide tile that is more than a tenth empty loses
   const long t8 = pw384_tiles(p, 8), t4 = pw384_tiles(p, 4);
-  const double c8 = t8 >= 160 ? cdiv(t8, 256) * 1.5 : 1e9, c4 = t4 >= 160 ? cdiv(t4, 256) * 0.8 : 1e9;
+  // 256-pixel tiles run with 64-deep stages of 128-byte K rows (whole L2 lines per LDS-DMA row piece): 4 - 15 % faster than 32-deep stages
+  // of 64-byte rows on every shape (profiles/r03_pw384_bench.txt, second table), so a round of them is priced at 1.3 instead of 1.5
+  const bool k64 = g_pw384_k64 && p.g.Cin >= 128;
+  const double c8 = t8 >= 160 ? cdiv(t8, 256) * (k64 ? 1.3 : 1.5) : 1e9, c4 = t4 >= 160 ? cdiv(t4, 256) * 0.8 : 1e9;
   const double best = c8 < c4 ? c8 : c4;
   if (best >= 0.9 * c_old) return 0;
-  return c8 < c4 ? 8 : 4;
+  return c8 < c4 ? (k64 ? 64 : 8) : 4;
 }
 
 static bool igemm256_wins(const IgemmParams& p) {
@@ -895,6 +899,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm256p") == 0) { g_igemm256p = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256p_wgs") == 0) { g_igemm256p_wgs = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256p_min") == 0) { g_igemm256p_min = value; return 0; }
+  if (name != nullptr && strcmp(name, "pw384_k64") == 0) { g_pw384_k64 = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_tile2d") == 0) { igemm256_set_tile2d(value); return 0; }
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }

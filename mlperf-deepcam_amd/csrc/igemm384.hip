@@ -146,22 +146,28 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
   const uintptr_t zp = (uintptr_t)p.zero_page;
   const bf16* __restrict__ xg = reinterpret_cast<const bf16*>(p.x);
   const bf16* __restrict__ wg = reinterpret_cast<const bf16*>(p.w);
-  uintptr_t src[K::IPW];
+  // a lane's row as a 32-bit byte offset from its operand's base (weights for rows below TN, pixels above: uniform per instruction), ~0u
+  // for a row past Cout / M.  (64-bit addresses were 2 x IPW registers: in the 128-byte-row mode, IPW = 10, that pushed the kernel over 256
+  // registers and the compiler reloaded them from scratch -- each reload a vmcnt(0) -- inside the K loop, which is what round 3's first
+  // "128-byte rows are slower" measurement measured.)
+  const uintptr_t xbase = (uintptr_t)xg, wbase = (uintptr_t)wg;
+  unsigned src[K::IPW];
 #pragma unroll
   for (int i = 0; i < K::IPW; ++i) {
     const int r = (8 * i + wave) * RPI + lrow;
     if (r < TN) {          // wave-uniform per instruction: row groups never straddle the operand boundary
       const int ch = n0 + r;
-      src[i] = ch < g.Cout ? (uintptr_t)(wg + (size_t)ch * p.ldw + lslot * 8) : 0;
+      src[i] = ch < g.Cout ? (unsigned)(((size_t)ch * p.ldw + lslot * 8) * 2) : ~0u;
     } else {
       const int m = m0 + r - TN;
-      src[i] = m < p.M ? (uintptr_t)(xg + (size_t)m * p.ldx + lslot * 8) : 0;
+      src[i] = m < p.M ? (unsigned)(((size_t)m * p.ldx + lslot * 8) * 2) : ~0u;
     }
   }
   auto issue = [&](int i, int stage) {
     const int kofs = stage * KS;
-    const bool ok = (src[i] != 0) & (kofs + lslot * 8 < g.Cin);          // stage >= kchunks fails the K test: zero page
-    const uintptr_t a = ok ? src[i] + (uintptr_t)kofs * 2 : zp;
+    const bool ok = (src[i] != ~0u) & (kofs + lslot * 8 < g.Cin);          // stage >= kchunks fails the K test: zero page
+    const uintptr_t base = (8 * i + wave) * RPI < TN ? wbase : xbase;      // (scalar)
+    const uintptr_t a = ok ? base + (src[i] + (unsigned)kofs * 2u) : zp;
     if constexpr (!(probe & 1)) __builtin_amdgcn_global_load_lds((gas_ptr)a, (lds_ptr)(smem + (stage % K::NSTG) * K::STAGE + (8 * i + wave) * 1024), 16, 0, 0);
   };
 
@@ -349,7 +355,8 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
 bool pw384_eligible(const IgemmParams& p) {
   const GatherGeom& g = p.g;
   return g.ntaps == 1 && g.os == 1 && g.is == 1 && g.taps[0].dy == 0 && g.taps[0].dx == 0 && p.m_beg == 0 && p.ngroup <= 1 &&
-         g.Cin >= 2 * BK && g.Cin % 8 == 0 && g.Cout % 8 == 0;
+         g.Cin >= 2 * BK && g.Cin % 8 == 0 && g.Cout % 8 == 0 &&
+         (size_t)p.M * p.ldx * 2 < (1ull << 32) && (size_t)g.Cout * p.ldw * 2 < (1ull << 32);      // 32-bit row offsets
 }
 
 // npb: 8 (256-pixel tiles) or 4 (128-pixel tiles): pixel blocks of 16 per 128-pixel half, the unit pw384_tiles() counts in;

@@ -54,3 +54,17 @@ def test_persistent_gemm_k_loops_hold_no_spills(tmp_path):
             assert not any("v_accvgpr" in x for x in body), f"{name}: accumulator shuffling inside the K loop at asm lines {a}-{b}"
         # outside the loops: the state handed from the first instantiation of the tile loop to the second, once per launch
         assert sum("scratch_" in x for x in lines) <= 32, name
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src,name,count", [("igemm384.hip", "pw384_kernel", 3), ("igemm256.hip", "igemm256_kernel", 1), ("wgrad256.hip", "wgrad256_kernel", 1)])
+def test_gemm_k_loops_hold_no_spills(tmp_path, src, name, count):
+    """The other MFMA kernels that run at the register limit.  (This scan is what found the spills of the 128-byte-row mode of
+    pw384_kernel: six scratch reloads, each behind a vmcnt(0), per K step -- the reason that mode first measured slower than 64-byte rows.)"""
+    kernels = _kernels(_device_asm(src, tmp_path), name)
+    assert len(kernels) == count, sorted(kernels)
+    for kname, lines in kernels.items():
+        mfma_loops = [(a, b) for a, b in _loops(lines) if any("v_mfma" in x for x in lines[a:b])]
+        assert mfma_loops, kname
+        for a, b in mfma_loops:
+            assert not any("scratch_" in x for x in lines[a:b]), f"{kname}: scratch access inside the K loop at asm lines {a}-{b}"
