@@ -539,6 +539,7 @@ static int g_rel256 = 0;   // 0: model below; otherwise cost of a 256-tile round
 // the K depths in question (see igemm256_wins).  The layer must also fill most of the chip with its one workgroup per CU.
 static int g_igemm256p = 1;          // persistent 256-tile kernel for multi-round launches (A/B switch "igemm256p")
 static int g_igemm256p_wgs = 0;      // its workgroups ("igemm256p_wgs"); 0: fewest that keep the number of rounds
+static int g_igemm256k = 0;          // 128-byte-row form of the persistent kernel for stride-1 geometries ("igemm256k"): measured 0 - 3 % slower, off
 static int g_igemm256p_min = 257;    // fewest tiles it is used for ("igemm256p_min")
 static int g_pw384 = 1;
 static int g_pw384_k64 = 1;         // 256 x 384 tiles with 128-byte K rows where the planner picks that tile ("pw384_k64")
@@ -644,6 +645,8 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
         }
       }
       // several rounds of tiles: the persistent form keeps the operand ring full across tiles (igemm256p.hip)
+      // ... with 128-byte K rows where the geometry allows (igemm256k.hip)
+      if (g_igemm256k && g_igemm256p && bst == nullptr && igemm256k_eligible(p) && igemm256_tiles(p) >= (long)g_igemm256p_min) return launch_igemm256k(p, g_igemm256p_wgs, st);
       if (g_igemm256p && bst == nullptr && igemm256p_eligible(p) && igemm256_tiles(p) >= (long)g_igemm256p_min) return launch_igemm256p(p, g_igemm256p_wgs, st);
       return launch_igemm256(p, st);
     }
@@ -899,6 +902,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm256p") == 0) { g_igemm256p = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256p_wgs") == 0) { g_igemm256p_wgs = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256p_min") == 0) { g_igemm256p_min = value; return 0; }
+  if (name != nullptr && strcmp(name, "igemm256k") == 0) { g_igemm256k = value; return 0; }
   if (name != nullptr && strcmp(name, "pw384_k64") == 0) { g_pw384_k64 = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_tile2d") == 0) { igemm256_set_tile2d(value); return 0; }
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }

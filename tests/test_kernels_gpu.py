@@ -293,8 +293,9 @@ def test_conv_persistent_tiles_same_bits(case):
         L.call("dc_set_option", b"igemm256", 2)
         L.call("dc_set_option", b"igemm256p_min", 1)
         L.call("dc_set_option", b"igemm256p_wgs", wgs)
-        for persistent in (0, 1):
-            L.call("dc_set_option", b"igemm256p", persistent)
+        for persistent in (0, 1, 2):          # 2: the 128-byte-row form where the geometry allows (else the same kernel as 1)
+            L.call("dc_set_option", b"igemm256p", 1 if persistent else 0)
+            L.call("dc_set_option", b"igemm256k", 1 if persistent == 2 else 0)
             ybuf, yv = empty_nhwc(N, Ho, Wo, cout, dtype, ld=cout + 24, off=16)
             slab = torch.full((2, rows, cout), float("nan"), device=dev())
             L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, vptr(slab), 0, S())
@@ -310,14 +311,16 @@ def test_conv_persistent_tiles_same_bits(case):
     finally:
         L.call("dc_set_option", b"igemm256", 1)
         L.call("dc_set_option", b"igemm256p", 1)
+        L.call("dc_set_option", b"igemm256k", 1)
         L.call("dc_set_option", b"igemm256p_min", 257)          # the library's defaults
         L.call("dc_set_option", b"igemm256p_wgs", 0)
     assert_close(got[0][0], conv_ref(x, q(w, dtype), None, k, stride, pad, dil, tr), dtype)
-    for i in range(3):
-        assert torch.equal(got[0][i], got[1][i]), f"output {i} differs"
-    a, b = got[0][3], got[1][3]
-    assert not torch.isnan(b).any()
-    assert (a - b).abs().max().item() <= 2e-5 * (a.abs().max().item() + 1e-12) + 1e-6
+    for v in (1, 2):
+        for i in range(3):
+            assert torch.equal(got[0][i], got[v][i]), f"variant {v}: output {i} differs"
+        a, b = got[0][3], got[v][3]
+        assert not torch.isnan(b).any()
+        assert (a - b).abs().max().item() <= 2e-5 * (a.abs().max().item() + 1e-12) + 1e-6
 
 
 BNSTAT_CASES = [
