@@ -37,6 +37,8 @@ int dc_version(void);
  * 2 = 256 x 256 eight-wave kernel wherever eligible.  "wgrad_target_blocks": workgroups aimed at by the split-K planner.
  * "dw_tile" 0/1, "dw_wgrad_tpb", "bn_cgw", "bn_rows": depthwise / BatchNorm kernel variants (see the .hip files). */
 int dc_set_option(const char* name, int value);
+/* Every dc_set_option switch back to its default (the library's own table; also what a freshly loaded library holds). */
+int dc_reset_options(void);
 
 /* Streams for the host runtime.  The reference leaves stream management to PyTorch/apex (its DDP overlaps the all-reduce
  * on a side stream, train_hdf5_ddp.py:227,363); here the weight-gradient kernels run beside the backward chain on a stream

@@ -930,6 +930,29 @@ extern "C" int dc_set_option(const char* name, int value) {
   return dc_fail("dc_set_option: unknown option", __FILE__, __LINE__);
 }
 
+// Every tuning switch with its default, in ONE place: dc_reset_options() puts the whole set back (the test suite calls it after every test,
+// so that a switch one test leaves behind cannot change what the next one measures -- a stale "restore" of this kind once ran the model
+// tests on an experimental kernel), and the library applies the same table when it is loaded, so the table IS the default.
+static const struct { const char* name; int value; } kOptionDefaults[] = {
+    {"igemm_mode", 2}, {"igemm256", 1}, {"pw384", 1}, {"pw384_k64", 1}, {"igemm256p", 1}, {"igemm256p_wgs", 0}, {"igemm256p_min", 257},
+    {"igemm256k", 0}, {"igemm256_tile2d", 0}, {"thin_fwd", 1}, {"igemm256_rel", 0}, {"igemm_mix", 0}, {"pack_blocks", 2048},
+    {"igemm256_epi", 0}, {"igemm256_phase_fast", 1}, {"igemm_mix_cus", 256}, {"igemm_mix_tail", 40}, {"wgrad_target_blocks", 768},
+    {"wgrad_mode", 1}, {"wgrad_min_steps", 16}, {"wgrad256", 1}, {"thin_wgrad", 1}, {"wgrad256_slots", 192}, {"head_fused", 1},
+    {"head_dgrad_fused", 1}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_fin_fallback", 0}, {"bn_cgw", 32}, {"bn_rows", 32},
+};
+
+extern "C" int dc_reset_options(void) {
+  for (const auto& o : kOptionDefaults)
+    if (int e = dc_set_option(o.name, o.value)) return e;
+  return 0;
+}
+
+namespace {
+struct OptionDefaultsAtLoad {
+  OptionDefaultsAtLoad() { (void)dc_reset_options(); }
+} g_option_defaults_at_load;
+}  // namespace
+
 extern "C" int dc_conv_out_hw(const dc_conv_desc* d, int Hi, int Wi, int* Ho, int* Wo) {
   DC_REQUIRE(d != nullptr, "dc_conv_out_hw: null descriptor");
   GatherGeom g;

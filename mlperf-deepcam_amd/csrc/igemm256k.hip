@@ -460,6 +460,8 @@ bool igemm256k_eligible(const IgemmParams& p) {
   if (p.ngroup > 1 || p.bias != nullptr || p.accumulate || p.bst.y != nullptr || p.m_beg != 0) return false;
   // input pixel index = phase-grid pixel index + tap offset
   if (g.is != 1 || g.Hin != g.Qh || g.Win != g.Qw || g.Cin < BK) return false;
+  for (int ph = 0; ph < g.os * g.os; ++ph)
+    if (g.phase_beg[ph + 1] - g.phase_beg[ph] < 1) return false;      // (the data gradient of a strided 1 x 1 convolution has phases without a tap: zeros, written by igemm256_kernel)
   // the per-lane row addresses are 32-bit byte offsets from the tensor bases
   if ((size_t)p.N * g.Hin * g.Win * p.ldx * 2 >= (1ull << 32) || (size_t)9 * g.Cout * p.ldw * 2 >= (1ull << 32)) return false;
   return igemm256_tiles(p) >= 8;

@@ -44,6 +44,7 @@ _SIGS = {
     "dc_last_error": (C.c_char_p, []),
     "dc_version": (I, []),
     "dc_set_option": (I, [C.c_char_p, I]),
+    "dc_reset_options": (I, []),
     "dc_stream_create": (I, [I, P]),
     "dc_stream_destroy": (I, [P]),
     "dc_stream_priority_range": (I, [P, P]),

@@ -18,3 +18,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _library_switches_back_to_defaults(request):
+    """The library's tuning switches (dc_set_option) are process-global.  Whatever a GPU test leaves behind is put back after it, from the
+    library's own table of defaults (dc_reset_options), so that no test runs on another test's switches."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    lib_mod = sys.modules.get("mlperf_deepcam_amd.lib")
+    if lib_mod is not None and getattr(lib_mod, "_lib", None) is not None:
+        lib_mod.call("dc_reset_options")

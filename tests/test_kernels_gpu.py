@@ -261,6 +261,7 @@ PERSIST_CASES = [
     ("convT_phases", 3, 2, 1, 1, 1, 256, 256, 2, 16, 32, 8),       # 1/2/2/4 taps per output parity class, tiles of different K
     ("stride2", 3, 2, 1, 1, 0, 128, 256, 2, 32, 48, 8),
     ("one_tile_each", 1, 1, 0, 1, 0, 128, 256, 1, 32, 64, 8),      # 8 tiles on 8 workgroups: no tile switch at all
+    ("pw_stride2", 1, 2, 0, 1, 0, 128, 256, 2, 32, 48, 8),         # its data gradient has three sub-pixel phases without a tap (zeros)
 ]
 
 
@@ -311,7 +312,7 @@ def test_conv_persistent_tiles_same_bits(case):
     finally:
         L.call("dc_set_option", b"igemm256", 1)
         L.call("dc_set_option", b"igemm256p", 1)
-        L.call("dc_set_option", b"igemm256k", 1)
+        L.call("dc_set_option", b"igemm256k", 0)
         L.call("dc_set_option", b"igemm256p_min", 257)          # the library's defaults
         L.call("dc_set_option", b"igemm256p_wgs", 0)
     assert_close(got[0][0], conv_ref(x, q(w, dtype), None, k, stride, pad, dil, tr), dtype)
