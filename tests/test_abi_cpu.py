@@ -70,3 +70,11 @@ def test_torch_custom_ops_are_registered():
         torch.ops.deepcam.optimizer_step(12345)              # an unknown handle fails loudly
     with pytest.raises(L.DeepcamHipError):
         torch.ops.deepcam.net_forward(torch.zeros(1, 16, 16, 16), 999, False)
+
+
+def test_option_defaults_table_is_accepted():
+    """dc_reset_options applies the library's table of switch defaults through dc_set_option itself: every name in it must be a switch the
+    library knows (no GPU needed: the switches are host-side state)."""
+    from mlperf_deepcam_amd import lib as L
+    assert L.load().dc_reset_options() == 0, L.last_error()
+    assert L.load().dc_set_option(b"no_such_switch", 1) != 0
