@@ -77,14 +77,17 @@ class KernelTimer:
     """HIP-event timing of every launch of the two MFMA kernel families on the stream they run on:
        igemm  dc::igemm256_kernel / dc::igemm_kernel<T> / dc::tiny_gemm_kernel<T>  (dc_conv_fwd + dc_conv_dgrad: dense conv forward
               and data gradient; the library's planner picks the tile shape per layer)
-       wgrad  dc::wgrad256_kernel / dc::wgrad_dma_kernel<T>  (+ the slab reduction; dc_conv_wgrad / dc_conv_wgrad_group: dense conv
-              weight gradient; a grouped call is ONE launch of the kernel for up to four layers and counts as one)"""
+       wgrad  dc::wgrad256_kernel / dc::wgrad_dma_kernel<T>  (dc_conv_wgrad_partial: dense conv weight gradient, split-K partial sums; a
+              grouped call is ONE launch of the kernel for up to four layers and counts as one) + dc::fold_kernel (dc_fold_slabs: the
+              fixed-order sum of those slabs, which also folds the depthwise layers' rows; its time counts, it adds no launch or flop)"""
 
-    FAMILY = {"dc_conv_fwd": "igemm", "dc_conv_dgrad": "igemm", "dc_conv_wgrad": "wgrad", "dc_conv_wgrad_group": "wgrad"}
+    FAMILY = {"dc_conv_fwd": "igemm", "dc_conv_dgrad": "igemm", "dc_conv_dgrad_bnstats": "igemm", "dc_conv_wgrad": "wgrad",
+              "dc_conv_wgrad_group": "wgrad", "dc_conv_wgrad_partial": "wgrad"}
 
     def __init__(self, lib_module):
         self.L = lib_module
         self.events = {"igemm": [], "wgrad": []}
+        self.fold_events = []
         self.flops = {"igemm": 0.0, "wgrad": 0.0}
         self.bytes = {"igemm": 0.0, "wgrad": 0.0}        # algorithmic: input + output + weights, each touched once
         self._orig = lib_module.call
@@ -94,11 +97,18 @@ class KernelTimer:
 
         def call(name, *args):
             fam = timer.FAMILY.get(name)
+            if name == "dc_fold_slabs":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                timer._orig(name, *args)
+                e1.record()
+                timer.fold_events.append((e0, e1))
+                return
             if fam is None:
                 return timer._orig(name, *args)
             d = args[0]._obj
             N, Hi, Wi = args[1], args[2], args[3]
-            layers = args[4] if name == "dc_conv_wgrad_group" else 1      # one launch serves `layers` layers of one geometry
+            layers = args[4] if name in ("dc_conv_wgrad_group", "dc_conv_wgrad_partial") else 1   # one launch serves `layers` layers of one geometry
             k = 3 if d.transposed else d.k
             if d.transposed:
                 macs = N * Hi * Wi * d.cin * d.cout * 9
@@ -127,7 +137,10 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for fam, evs in self.events.items():
-            out[fam] = (self.flops[fam], sum(a.elapsed_time(b) for a, b in evs) * 1e-3, len(evs), self.bytes[fam])
+            t = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
+            if fam == "wgrad":
+                t += sum(a.elapsed_time(b) for a, b in self.fold_events) * 1e-3
+            out[fam] = (self.flops[fam], t, len(evs), self.bytes[fam])
         return out
 
 
@@ -265,7 +278,8 @@ def main():
         names = {"igemm": f"dc::igemm256_kernel + dc::igemm256p_kernel + dc::pw384_kernel + dc::igemm_kernel<{a.dtype}> (dense conv forward + data "
                           "gradient: gather-form implicit GEMM; 256x256 (one tile per workgroup or persistent) / 256x384 eight-wave or 128x128 "
                           "four-wave tile per layer)",
-                 "wgrad": f"dc::wgrad256_kernel + dc::wgrad_dma_kernel<{a.dtype}> + dc::wgrad_reduce_kernel (dense conv weight gradient)"}
+                 "wgrad": f"dc::wgrad256_kernel + dc::wgrad_dma_kernel<{a.dtype}> + dc::fold_kernel (dense conv weight gradient: split-K partial sums, "
+                          "then the fixed-order fold of the slabs)"}
         dom = max(fams, key=lambda f: fams[f][1])
         def entry(f, src=None):
             fl, secs, n, nbytes = (src or fams)[f]

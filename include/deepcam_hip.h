@@ -153,6 +153,29 @@ int dc_conv_wgrad_group(const dc_conv_desc* d, int N, int Hi, int Wi, int count,
                         const void* const* dys, int lddy, void* workspace, size_t workspace_bytes,
                         float* const* grad_ws, void* stream);
 
+/* Slab-only form of the two calls above: the split-K partial sums of `count` layers of one geometry (count > 1: the grouped launch
+ * must serve the layer, dc_conv_wgrad_plan fails otherwise) are left in slabs[l] ([splits][taps][Cout][Cin] floats each,
+ * dc_conv_wgrad_plan's slab_bytes) and NOT reduced: dc_fold_slabs adds the slabs of many layers in one launch.  `splits` must be the
+ * value dc_conv_wgrad_plan returned (the call fails if tuning options changed the plan in between).  Same reference call site:
+ * autograd's conv_backward_weight at train_hdf5_ddp.py:363. */
+int dc_conv_wgrad_plan(const dc_conv_desc* d, int N, int Hi, int Wi, int count, int* splits, size_t* slab_bytes);
+int dc_conv_wgrad_partial(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const void* const* xs, int ldx,
+                          const void* const* dys, int lddy, float* const* slabs, int splits, void* stream);
+
+/* grad (fp32, PyTorch master layout) = fixed-order sum of the partial slabs of n layers, ONE launch per 24 entries (host array; the
+ * table travels in the kernel arguments).  kind DC_FOLD_CONV: slab [splits][taps][co][ci] -> grad [co][ci][taps] (Conv2d.weight);
+ * DC_FOLD_CONVT: -> grad [ci][co][taps] (ConvTranspose2d.weight); DC_FOLD_DW: slab [splits = rows][9][co = C] -> grad [C][1][3][3]
+ * (taps = 9, ci = 1; the rows dc_dwconv_dgrad_bnstats_wgrad / dc_dwconv_dgrad_wgrad leave).  Bit-identical to the per-layer
+ * reductions inside dc_conv_wgrad / dc_dwconv_wgrad_reduce whatever the grouping.  Replaces the accumulation step of autograd's
+ * conv_backward_weight for all layers of an Xception block at once (train_hdf5_ddp.py:363). */
+enum { DC_FOLD_CONV = 0, DC_FOLD_CONVT = 1, DC_FOLD_DW = 2 };
+typedef struct dc_fold_entry {
+  const float* slab;
+  float* grad;
+  int kind, splits, taps, co, ci;
+} dc_fold_entry;
+int dc_fold_slabs(const dc_fold_entry* entries, int n, void* stream);
+
 /* grad_bias[c] = sum over M rows of dy (the one biased conv, deeplab_xception.py:366). */
 int dc_colsum(int dtype, long M, int C, const void* dy, int lddy, float* out, void* workspace, void* stream);
 size_t dc_colsum_workspace(long M, int C);

@@ -547,37 +547,39 @@ extern "C" size_t dc_conv_wgrad_workspace(const dc_conv_desc* d, int N, int Hi, 
   return (size_t)splits * g.ntaps * g.Cout * g.Cin * sizeof(float);
 }
 
-// xscale != nullptr: x is a raw convolution output and the operand is act(x * xscale + xshift) (WgradParams::xscale): the
-// register-staged 128-tile kernel, whatever the planner would have picked
-static int conv_wgrad_impl(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* dy,
-                           int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream, const float* xscale,
-                           const float* xshift, int xrelu) {
-  DC_REQUIRE(d != nullptr && grad_w != nullptr && workspace != nullptr, "dc_conv_wgrad: null argument");
-  DC_REQUIRE(xscale == nullptr || (d->dtype == DC_BF16 && xshift != nullptr), "dc_conv_wgrad: the operand transform is bf16 only");
-  WgradParams p;
-  p.xscale = xscale; p.xshift = xshift; p.xrelu = xrelu;
-  if (!build_geom(*d, Hi, Wi, kFwd, &p.g)) return dc_fail("dc_conv_wgrad: unsupported geometry", __FILE__, __LINE__);
-  if (int e = dc_check_view(x, ldx, p.g.Cin, d->dtype, "dc_conv_wgrad x")) return e;
-  if (int e = dc_check_view(dy, lddy, p.g.Cout, d->dtype, "dc_conv_wgrad dy")) return e;
-  const long M = (long)N * p.g.Qh * p.g.Qw;
+// Which kernel serves a layer and how its pixel axis is split: shared by the reducing calls (dc_conv_wgrad, dc_conv_wgrad_group) and the
+// slab-only calls (dc_conv_wgrad_partial + dc_fold_slabs).  transform: the operand is act(x * xscale + xshift) (register-staged kernel).
+enum WgradKernel { WK_THIN, WK_256, WK_DMA, WK_REG };
+static int plan_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, bool transform, int count, WgradParams* p, WgradKernel* kind) {
+  if (!build_geom(*d, Hi, Wi, kFwd, &p->g)) return dc_fail("dc_conv_wgrad: unsupported geometry", __FILE__, __LINE__);
+  const long M = (long)N * p->g.Qh * p->g.Qw;
   DC_REQUIRE(M < (1L << 31) - 256, "dc_conv_wgrad: too many pixels for 32-bit indexing");
+  p->N = N; p->M = (int)M;
+  if (count > 1) {
+    DC_REQUIRE(count <= WG_MAXGROUP && !transform && d->dtype == DC_BF16 && !(g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi)) && wgrad256_wins(p->g),
+               "dc_conv_wgrad: this layer is not served by the grouped launch");
+    *kind = WK_256;
+    wgrad256_plan(p->g, M, &p->splits, &p->chunk, count);
+    return 0;
+  }
   const int BP = d->dtype == DC_BF16 ? 64 : 32;    // chunk granularity (a multiple of both kernels' pixels per stage)
-  const bool thin = xscale == nullptr && g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi);
-  const bool big = xscale == nullptr && !thin && d->dtype == DC_BF16 && wgrad256_wins(p.g);
-  if (thin) { p.splits = thin_wgrad_splits(*d, N, Hi, Wi); p.chunk = 0; }
-  else if (big) wgrad256_plan(p.g, M, &p.splits, &p.chunk);
-  else plan_splits(p.g, M, BP, &p.splits, &p.chunk);
-  const size_t need = (size_t)p.splits * p.g.ntaps * p.g.Cout * p.g.Cin * sizeof(float);
-  DC_REQUIRE(workspace_bytes >= need, "dc_conv_wgrad: workspace too small");
-  p.x = x; p.dy = dy; p.slab = (float*)workspace;
-  p.N = N; p.ldx = ldx; p.lddy = lddy; p.M = (int)M;
-  hipStream_t st = (hipStream_t)stream;
+  const bool thin = !transform && g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi);
+  const bool big = !transform && !thin && d->dtype == DC_BF16 && wgrad256_wins(p->g);
+  if (thin) { p->splits = thin_wgrad_splits(*d, N, Hi, Wi); p->chunk = 0; *kind = WK_THIN; }
+  else if (big) { wgrad256_plan(p->g, M, &p->splits, &p->chunk); *kind = WK_256; }
+  else { plan_splits(p->g, M, BP, &p->splits, &p->chunk); *kind = (g_wgrad_mode == 1 && !transform) ? WK_DMA : WK_REG; }
+  return 0;
+}
+
+// the split-K partial sums of one layer (or of `group` layers of one geometry: 256-tile kernel only) into p.slab (slabs[]); no reduction
+static int launch_wgrad_partial(const dc_conv_desc* d, const WgradParams& p, WgradKernel kind, int N, int Hi, int Wi, hipStream_t st, int group = 1,
+                                const void* const* xs = nullptr, const void* const* dys = nullptr, float* const* slabs = nullptr) {
   dim3 grid(cdiv(p.g.Cin, 128) * cdiv(p.g.Cout, 128) * p.g.ntaps * p.splits);
-  if (thin) {
-    if (int e = launch_thin_wgrad(*d, N, Hi, Wi, x, ldx, dy, lddy, p.slab, st)) return e;
-  } else if (big) {
-    if (int e = launch_wgrad256(p, st)) return e;
-  } else if (g_wgrad_mode == 1 && xscale == nullptr) {
+  if (kind == WK_THIN) {
+    if (int e = launch_thin_wgrad(*d, N, Hi, Wi, p.x, p.ldx, p.dy, p.lddy, p.slab, st)) return e;
+  } else if (kind == WK_256) {
+    if (int e = launch_wgrad256(p, st, group, xs, dys, slabs)) return e;
+  } else if (kind == WK_DMA) {
     const size_t lds = 3 * 2 * 8192;
     if (d->dtype == DC_BF16) {
       DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -596,6 +598,28 @@ static int conv_wgrad_impl(const dc_conv_desc* d, int N, int Hi, int Wi, const v
     hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), lds, st, p);
   }
   DC_CHECK_LAUNCH();
+  return 0;
+}
+
+// xscale != nullptr: x is a raw convolution output and the operand is act(x * xscale + xshift) (WgradParams::xscale): the
+// register-staged 128-tile kernel, whatever the planner would have picked
+static int conv_wgrad_impl(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* dy,
+                           int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream, const float* xscale,
+                           const float* xshift, int xrelu) {
+  DC_REQUIRE(d != nullptr && grad_w != nullptr && workspace != nullptr, "dc_conv_wgrad: null argument");
+  DC_REQUIRE(xscale == nullptr || (d->dtype == DC_BF16 && xshift != nullptr), "dc_conv_wgrad: the operand transform is bf16 only");
+  WgradParams p;
+  WgradKernel kind;
+  p.xscale = xscale; p.xshift = xshift; p.xrelu = xrelu;
+  if (int e = plan_wgrad(d, N, Hi, Wi, xscale != nullptr, 1, &p, &kind)) return e;
+  if (int e = dc_check_view(x, ldx, p.g.Cin, d->dtype, "dc_conv_wgrad x")) return e;
+  if (int e = dc_check_view(dy, lddy, p.g.Cout, d->dtype, "dc_conv_wgrad dy")) return e;
+  const size_t need = (size_t)p.splits * p.g.ntaps * p.g.Cout * p.g.Cin * sizeof(float);
+  DC_REQUIRE(workspace_bytes >= need, "dc_conv_wgrad: workspace too small");
+  p.x = x; p.dy = dy; p.slab = (float*)workspace;
+  p.ldx = ldx; p.lddy = lddy;
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = launch_wgrad_partial(d, p, kind, N, Hi, Wi, st)) return e;
   return launch_wgrad_reduce(p.slab, grad_w, p.splits, p.g, d->transposed, st);
 }
 
@@ -659,4 +683,34 @@ extern "C" int dc_conv_wgrad_group(const dc_conv_desc* d, int N, int Hi, int Wi,
   for (int l = 0; l < count; ++l)
     if (int e = launch_wgrad_reduce(slabs[l], grad_ws[l], p.splits, p.g, d->transposed, st)) return e;
   return 0;
+}
+
+// ---- slab-only form: the partial sums stay in per-layer slabs and dc_fold_slabs (fold.hip) adds the slabs of many layers in one launch.
+// The 83 per-layer reductions of a step (17 MB of slabs each on average: launch- and latency-bound at 1.8 TB/s) become part of ~50 larger
+// folds that also take the depthwise layers' rows.
+extern "C" int dc_conv_wgrad_plan(const dc_conv_desc* d, int N, int Hi, int Wi, int count, int* splits, size_t* slab_bytes) {
+  DC_REQUIRE(d != nullptr && splits != nullptr && slab_bytes != nullptr && count >= 1, "dc_conv_wgrad_plan: bad argument");
+  WgradParams p;
+  WgradKernel kind;
+  if (int e = plan_wgrad(d, N, Hi, Wi, false, count, &p, &kind)) return e;
+  *splits = p.splits;
+  *slab_bytes = (size_t)p.splits * p.g.ntaps * p.g.Cout * p.g.Cin * sizeof(float);
+  return 0;
+}
+
+extern "C" int dc_conv_wgrad_partial(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const void* const* xs, int ldx,
+                                     const void* const* dys, int lddy, float* const* slabs, int splits, void* stream) {
+  DC_REQUIRE(d != nullptr && xs != nullptr && dys != nullptr && slabs != nullptr && count >= 1, "dc_conv_wgrad_partial: bad argument");
+  WgradParams p;
+  WgradKernel kind;
+  if (int e = plan_wgrad(d, N, Hi, Wi, false, count, &p, &kind)) return e;
+  DC_REQUIRE(p.splits == splits, "dc_conv_wgrad_partial: the split plan changed since dc_conv_wgrad_plan (tuning options were switched in between)");
+  for (int l = 0; l < count; ++l) {
+    DC_REQUIRE(slabs[l] != nullptr, "dc_conv_wgrad_partial: null slab");
+    if (int e = dc_check_view(xs[l], ldx, p.g.Cin, d->dtype, "dc_conv_wgrad_partial x")) return e;
+    if (int e = dc_check_view(dys[l], lddy, p.g.Cout, d->dtype, "dc_conv_wgrad_partial dy")) return e;
+  }
+  p.x = xs[0]; p.dy = dys[0]; p.slab = slabs[0];
+  p.ldx = ldx; p.lddy = lddy;
+  return launch_wgrad_partial(d, p, kind, N, Hi, Wi, (hipStream_t)stream, count, xs, dys, slabs);
 }

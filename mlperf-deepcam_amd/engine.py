@@ -97,11 +97,6 @@ class LazyAct:
         self.N, self.H, self.W, self.C = y.N, y.H, y.W, y.C
         self._grad: Optional[Act] = None
         self.grad_init = False
-        # BatchNorm finalize inside the consumer (Engine.fuse_bn_finalize): `fin` = the finalize call's arguments (set by Engine._bn),
-        # `fin_consumer` = the consumer has taken the job (set by Engine._dw at build time), `fin_now` = it really does in this forward pass
-        self.fin: Optional[dict] = None
-        self.fin_consumer = False
-        self.fin_now = False
 
     @property
     def M(self) -> int:
@@ -178,14 +173,6 @@ class Engine:
         # the BatchNorm + ReLU in front of the classifier head (upsample.deconv3.1/.2) is applied by the head itself while it loads
         # (dc_head_fwd_loss_bnin / dc_head_bwd_bnin): the 256-channel 384 x 576 activation is never stored (at local batch 8: a 0.35 ms
         # dc_bn_apply pass and 1.8 GB of traffic less per step).  bf16 only (the fused head kernel).
-        # DC_FUSE_BN_FINALIZE=1: the finalize step of a BatchNorm whose output is never stored runs inside the depthwise kernel that consumes
-        # it (dc_dwconv_fwd_bnfin, csrc/bn_fin.h) instead of as a launch of its own.  Built because the finalize launches of the forward
-        # pass cost the chain 1.5 ms at local batch 8 (DC_DEBUG_SKIP_BN_FINALIZE=async); OFF because handing the coefficients from the
-        # leader workgroups to the others inside one kernel goes through the memory-side coherence point on an eight-XCD chip (write-through
-        # stores, a count, polls, agent-scope loads: about 12 us per layer) and that is no cheaper than the dispatch boundary it removes
-        # (38.86 vs 38.69 ms per step; scripts/bnfin_bench.py: 41.9 vs 36.6 us per layer alone).
-        self.fuse_bn_finalize = os.environ.get("DC_FUSE_BN_FINALIZE", "0") != "0"
-        self._fin_syncs: List[torch.Tensor] = []      # hand-over words of those layers; the last word of each counts waits that ran out
         self.fuse_bn_into_head = dtype == torch.bfloat16 and os.environ.get("DC_FUSE_BN_INTO_HEAD", "1") != "0"
         # depthwise weight gradient taken inside the depthwise data gradient (dc_dwconv_dgrad_bnstats_wgrad) where the layer's input is a
         # never-stored BatchNorm output: the separate dc_dwconv_wgrad launch (and its second read of dy and y) disappears
@@ -199,11 +186,13 @@ class Engine:
         wg = os.environ.get("DC_WGRAD_GROUP", "auto")
         self.wgrad_group = 3 if wg == "auto" else max(1, min(4, int(wg)))
         self._wg_recs: List[dict] = []
-        self.shift_side = os.environ.get("DC_SIDE_SCHEDULE", "eager") == "shift"   # complementary pairing of the two streams
-        self._side_deferred: List = []
+        # Weight-gradient partial sums stay in per-layer slabs and are folded by dc_fold_slabs (csrc/fold.hip): one fold per dense
+        # weight-gradient launch, which also takes the rows that the depthwise data-gradient kernels since the previous fold have left.
+        # _fold_seq lists, in execution order, ("dw", FoldEntry, name, ready-list) and ("dense", rec); _plan_folds() turns it into
+        # static per-launch tables once the backward program is resolved.
+        self._fold_seq: List[tuple] = []
+        self._final_fold = None                       # (FoldEntry array, count, names): rows produced after the last dense launch
         self.aspp_group = os.environ.get("DC_ASPP_GROUP", "1") != "0"      # atrous ASPP branches in one forward launch
-        self.par_branches = os.environ.get("DC_PAR_BRANCHES", "0") != "0"    # ASPP branches side by side on their own streams (measured +0.5 ms: off)
-        self._branch_streams: List[torch.cuda.Stream] = []
         self._deferred_names: List[str] = []
         self._ready_now: List[str] = []
 
@@ -297,65 +286,6 @@ class Engine:
         with torch.cuda.stream(self.side):
             fn(C.c_void_p(self.workspace2.data_ptr()))
 
-    def fin_waits_run_out(self) -> int:
-        """Workgroups (over all steps so far) whose wait for the in-kernel BatchNorm finalize ran out and that computed their coefficients
-        themselves (csrc/bn_fin.h): slower, same bits.  Zero in a healthy run; synchronises."""
-        return int(sum(int(s[-1]) for s in self._fin_syncs))
-
-    # ---- independent forward branches on their own streams -----------------------------------------------------------------
-    # The ASPP branches read the same encoder output and write disjoint channel slices of one buffer.  Each dilated 3x3 conv is
-    # 108 tiles of the 256-tile kernel (42 % of the CUs) with a 576-step K loop, so run one after the other they leave most of
-    # the chip idle; side by side the four convs and the latency-bound image-pool branch fill it.
-    def _par_begin(self) -> None:
-        self._par_marks = [(len(self.fwd_train), len(self.fwd_eval))]
-
-    def _par_branch(self) -> None:
-        self._par_marks.append((len(self.fwd_train), len(self.fwd_eval)))
-
-    def _par_end(self) -> None:
-        self._par_branch()
-        marks = self._par_marks
-        nb = len(marks) - 1
-        if not self.par_branches or nb < 2:
-            return
-        while len(self._branch_streams) < nb - 1:
-            self._branch_streams.append(torch.cuda.Stream(device=self.device))
-
-        def make(ops_list, col):
-            spans = [ops_list[marks[i][col]:marks[i + 1][col]] for i in range(nb)]
-
-            def run():
-                main = torch.cuda.current_stream()
-                fork = main.record_event()
-                for ops, st in zip(spans[1:], self._branch_streams):      # branch 0 stays on the calling stream
-                    st.wait_event(fork)
-                    with torch.cuda.stream(st):
-                        for op in ops:
-                            op()
-                for op in spans[0]:
-                    op()
-                for st in self._branch_streams[:nb - 1]:
-                    main.wait_stream(st)
-            return run
-
-        run_t, run_e = make(self.fwd_train, 0), make(self.fwd_eval, 1)
-        del self.fwd_train[marks[0][0]:]
-        del self.fwd_eval[marks[0][1]:]
-        self.fwd_train.append(run_t)
-        self.fwd_eval.append(run_e)
-
-    def _flush_deferred(self) -> None:
-        """Submit the deferred depthwise weight gradients to the side stream, ordered behind the main stream's current position.
-        Backward alternates HBM-bound kernels (BatchNorm backward, depthwise data gradient) and MFMA-bound ones (dense data
-        gradient) on the main stream; a weight gradient submitted the moment its operands exist meets a kernel of its OWN kind
-        there (pointwise weight gradient beside pointwise data gradient, depthwise beside depthwise) and the two take turns on the
-        same resource.  Deferred by half a unit they meet the other kind."""
-        if self._side_deferred:
-            pending, self._side_deferred = self._side_deferred, []
-            for fn, names in pending:
-                self._on_side(fn)
-                self._ready_now += names
-
     @staticmethod
     def _st():
         return L.stream_ptr()
@@ -384,8 +314,6 @@ class Engine:
         wb = torch.empty(nwb.value, dtype=tdtype, device=self.device) if need_dx else None
         rows = lib.dc_conv_stat_rows(C.byref(d), x.N, x.H, x.W) if stats else 0
         slab = self._f32(2 * rows * cout) if stats else None
-        wsb = lib.dc_conv_wgrad_workspace(C.byref(d), x.N, x.H, x.W)
-        self._need_ws(wsb)
         N, H, W = x.N, x.H, x.W
         pw, gw = self.pptr(wname), self.gptr(wname)
         pb = self.pptr(bias) if bias else None
@@ -417,38 +345,34 @@ class Engine:
                 self._need_ws(lib.dc_colsum_workspace(y.M, cout))
 
             # Weight gradients of consecutive layers of ONE geometry (the 728 -> 728 pointwise convs of the middle flow) are
-            # deferred and launched together (dc_conv_wgrad_group): _group_wgrads() fixes the roles once the program is resolved.
-            bsrc = getattr(x, "bn_src", None) if (sole_consumer and need_dx and self.fuse_bn_conv and not self.shift_side) else None
+            # deferred and launched together (one dc_conv_wgrad_partial call): _plan_folds() fixes the roles once the program is resolved.
+            bsrc = getattr(x, "bn_src", None) if (sole_consumer and need_dx and self.fuse_bn_conv) else None
             srows = lib.dc_conv_dgrad_bnstats_rows(C.byref(d), N, H, W) if (bsrc is not None and mode == 0 and x.parent is None) else 0
             if srows > 0:
                 sslab = self._f32(2 * srows * x.C)
                 x.fused_bwd = (sslab, srows)       # read by the BatchNorm's make_bwd, which runs after this one
                 by = bsrc["y"]
             rec = {"key": (dt, d.k, stride, pad, dil, d.transposed, x.C, cout, N, H, W, x.ld, dy.ld), "d": d, "x": x, "dy": dy,
-                   "gw": gw, "wname": wname, "ready": ready, "role": "solo", "group": None, "bias": bool(bias)}
+                   "gw": gw, "wname": wname, "ready": ready, "role": "solo", "launch": None, "fold": None, "bias": bool(bias)}
             self._wg_recs.append(rec)
+            self._fold_seq.append(("dense", rec))
 
             def wgrad():
                 if rec["role"] == "defer":
                     return
-                if rec["role"] == "solo":
-                    self._on_side(lambda ws: L.call("dc_conv_wgrad", C.byref(d), N, H, W, x.ptr, x.ld, dy.ptr, dy.ld, ws, wsb, gw, self._st()))
-                    return
-                cnt, xs, dys, gws, gbytes = rec["group"]
-                self._on_side(lambda ws: L.call("dc_conv_wgrad_group", C.byref(d), N, H, W, cnt, xs, x.ld, dys, dy.ld, ws, gbytes, gws, self._st()))
+                # partial sums of this layer (or of the group this layer closes) into their slabs, then ONE fold of those slabs and of the
+                # depthwise rows produced since the previous fold -- both behind a single fence on the weight-gradient stream
+                cnt, xs, dys, slabs, splits = rec["launch"]
+                ents, nent = rec["fold"]
+
+                def side(ws):
+                    L.call("dc_conv_wgrad_partial", C.byref(d), N, H, W, cnt, xs, x.ld, dys, dy.ld, slabs, splits, self._st())
+                    L.call("dc_fold_slabs", ents, nent, self._st())
+                self._on_side(side)
 
             def bwd():
                 if bias:
                     L.call("dc_colsum", dt, y.M, cout, dy.ptr, dy.ld, self.gptr(bias), self._wsptr(), self._st())
-                if self.shift_side:
-                    # complementary pairing (see _flush_deferred): the deferred depthwise weight gradients (HBM-bound) start beside
-                    # this MFMA-bound data gradient; this layer's own MFMA-bound weight gradient is submitted behind the data
-                    # gradient, so it runs beside the HBM-bound kernels that follow on the main stream
-                    self._flush_deferred()
-                    if need_dx:
-                        L.call("dc_conv_dgrad", C.byref(d), N, H, W, dy.ptr, dy.ld, L.dptr(wb), dx.ptr, dx.ld, mode, self._st())
-                    wgrad()
-                    return
                 wgrad()
                 if need_dx and srows > 0:
                     L.call("dc_conv_dgrad_bnstats", C.byref(d), N, H, W, dy.ptr, dy.ld, L.dptr(wb), dx.ptr, dx.ld, by.ptr, by.ld,
@@ -505,24 +429,6 @@ class Engine:
             L.call("dc_dwconv_fwd", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, pw, y.ptr, y.ld, ps, psh, prelu, self._st())
 
         fwd_train = fwd
-        words = lib.dc_dwconv_fwd_bnfin_sync_words(self.dt, Cc, stride, dil) if (lazy and self.fuse_bn_finalize and x.fin is not None) else 0
-        if words > 0:
-            # this kernel also runs the finalize step of the BatchNorm it reads through (dc_dwconv_fwd_bnfin)
-            x.fin_consumer = True
-            f = x.fin
-            sync = torch.zeros(words, dtype=torch.int32, device=self.device)
-            self._keep += [sync, f["slab"], f["mean"], f["invstd"]]
-            self._fin_syncs.append(sync)
-            vp = lambda v: v.value if isinstance(v, C.c_void_p) else v.data_ptr()
-            bn = L.BnFin(f["count"], vp(f["slab"]), f["rows"], vp(f["gamma"]), vp(f["beta"]), vp(f["rm"]), vp(f["rv"]), vp(f["nbt"]), BN_MOMENTUM,
-                         BN_EPS, vp(f["scale"]), vp(f["shift"]), vp(f["mean"]), vp(f["invstd"]), sync.data_ptr(), 0)
-
-            def fwd_train():
-                if not x.fin_now:
-                    return fwd()
-                L.call("dc_dwconv_fwd_bnfin", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, pw, y.ptr, y.ld, C.byref(bn), prelu, self._st())
-                bn.epoch += 1
-
         self.fwd_train.append(fwd_train)
         self.fwd_eval.append(fwd)
 
@@ -534,51 +440,42 @@ class Engine:
             # sums (sum g, sum g*xhat) on the way out of the data-gradient kernel instead of re-reading dx and y for them
             srows = lib.dc_dwconv_dgrad_bnstats_rows(self.dt, Cc, stride, dil, N, H, W) if (lazy and self.fuse_bn_reduce and mode == 0) else 0
             wrows = 0
-            if srows == 0 and self.fuse_dw_wgrad and not self.shift_side:
+            if srows == 0 and self.fuse_dw_wgrad:
                 # stored input (or a lazy one whose statistics are taken elsewhere): data gradient + weight-gradient rows in one kernel
                 wrows = lib.dc_dwconv_dgrad_wgrad_rows(self.dt, Cc, stride, dil, N, H, W)
-                if wrows > 0:
-                    wslab = self._f32(wrows * 9 * Cc)
             if srows > 0:
                 sslab = self._f32(2 * srows * Cc)
                 x.fused_bwd = (sslab, srows)
                 mean_p, invstd_p = L.dptr(x.mean), L.dptr(x.invstd)
-                if self.fuse_dw_wgrad and not self.shift_side:
+                if self.fuse_dw_wgrad:
                     wrows = lib.dc_dwconv_dgrad_wgrad_rows(self.dt, Cc, stride, dil, N, H, W)
-                if wrows > 0:
-                    wslab = self._f32(wrows * 9 * Cc)      # per layer: the reduction runs on the side stream, behind the next layers
+            ready = [wname]
+            if wrows > 0:
+                # the rows stay in this layer's own slab until the next dense weight-gradient launch folds them (dc_fold_slabs); the
+                # gradient is reported ready there (_plan_folds moves the name)
+                wslab = self._f32(wrows * 9 * Cc)
+                self._fold_seq.append(("dw", L.FoldEntry(wslab.data_ptr(), gw.value, L.DC_FOLD_DW, wrows, 9, Cc, 1), wname, ready))
 
             def dw_wgrad(ws):
                 L.call("dc_dwconv_wgrad", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, dy.ptr, dy.ld, ws, gw, ps, psh, prelu, self._st())
-
-            def dw_wreduce(ws):
-                L.call("dc_dwconv_wgrad_reduce", Cc, wrows, L.dptr(wslab), gw, self._st())
 
             def bwd():
                 if wrows > 0 and srows == 0:
                     L.call("dc_dwconv_dgrad_wgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
                            dx.ptr, dx.ld, src.ptr, src.ld, ps, psh, prelu, L.dptr(wslab), self._st())
-                    self._on_side(dw_wreduce)
                     return
                 if wrows > 0:
                     L.call("dc_dwconv_dgrad_bnstats_wgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr, dx.ld, src.ptr, src.ld,
                            mean_p, invstd_p, ps, psh, prelu, L.dptr(sslab), L.dptr(wslab), self._st())
-                    self._on_side(dw_wreduce)           # only the fixed-order fold of the rows is left for the side stream
                     return
-                if self.shift_side:
-                    self._side_deferred.append((dw_wgrad, [wname]))
-                else:
-                    self._on_side(dw_wgrad)
+                self._on_side(dw_wgrad)
                 if srows > 0:
                     L.call("dc_dwconv_dgrad_bnstats", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr, dx.ld, src.ptr, src.ld,
                            mean_p, invstd_p, ps, psh, prelu, L.dptr(sslab), self._st())
                 else:
                     L.call("dc_dwconv_dgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
                            dx.ptr, dx.ld, self._st())
-            if self.shift_side:
-                self._deferred_names.append(wname)
-                return bwd, []
-            return bwd, [wname]
+            return bwd, ready
 
         self.bwd.append(make_bwd)
         return y
@@ -606,11 +503,6 @@ class Engine:
         rld = residual.ld if residual is not None else 0
 
         def fwd_train():
-            if lz is not None:
-                # (a hipGraph capture keeps the two-launch form: the hand-over's launch counter is a kernel argument)
-                lz.fin_now = lz.fin_consumer and not torch.cuda.is_current_stream_capturing()
-                if lz.fin_now:
-                    return
             if self._debug_skip_finalize == "async":
                 # (timing experiment with realistic data: the finalize runs unordered on a stream of its own, the chain uses the previous
                 # step's coefficients)
@@ -633,8 +525,6 @@ class Engine:
         lz = LazyAct(y, scale, shift, relu, (name or bname) + ".lazy") if lazy else None
         if lz is not None:
             lz.mean, lz.invstd, lz.fused_bwd = mean, invstd, None
-            lz.fin = dict(count=M, slab=slab, rows=rows, gamma=gam, beta=bet, rm=rm, rv=rv, nbt=nbt, scale=scale, shift=shift, mean=mean,
-                          invstd=invstd)
         elif residual is None and out is None and (self.mask_from_y or not relu):
             # a stored BatchNorm(+ReLU) output whose ReLU mask is recomputed from y: a sole dense-conv consumer may take this
             # BatchNorm's backward sums in its data-gradient epilogue (_conv(..., sole_consumer=True), the classifier head)
@@ -788,7 +678,6 @@ class Engine:
         # image-pool branch first, so that in the backward program it is the LAST contributor to d(e)
         pooled = Act(self, "gap", B, 1, 1, 2048, dtype=torch.float32)     # this branch runs in fp32 (B values per channel)
         HW = h16 * w16
-        self._par_begin()
 
         def pool_fwd():
             L.call("dc_avgpool_fwd", self.dt, B, HW, 2048, e.ptr, e.ld, pooled.ptr, self._st())
@@ -828,11 +717,10 @@ class Engine:
 
         self.bwd.append(bc_bwd_make)
         # The atrous branches share ONE forward launch (dc_conv_fwd_dilated_group): each is 108 tiles of the 256-tile kernel at local
-        # batch 8 and 27 at batch 2, on 256 CUs.  (DC_ASPP_GROUP=0 or DC_PAR_BRANCHES=1: one launch per branch.)
-        group = [] if (self.aspp_group and not self.par_branches) else None
+        # batch 8 and 27 at batch 2, on 256 CUs.  (DC_ASPP_GROUP=0: one launch per branch.)
+        group = [] if self.aspp_group else None
         pending = []
         for i, rate in enumerate(S.ASPP_RATES, start=1):
-            self._par_branch()
             k, pad = (1, 0) if rate == 1 else (3, rate)
             y, slab, rows = self._conv(e, f"aspp{i}.atrous_convolution.weight", 256, k=k, pad=pad, dil=rate, name=f"aspp{i}.conv",
                                        fwd_group=group if rate != 1 else None)
@@ -844,7 +732,6 @@ class Engine:
             self._dilated_group_fwd(group)
             for y, slab, rows, i in pending:
                 self._bn(y, slab, rows, f"aspp{i}.bn", True, out=cat1.slice(f"aspp{i}", 256 * (i - 1), 256))
-        self._par_end()
         y, slab, rows = self._conv(cat1, "conv1.weight", 256, name="proj")
         p = self._bn(y, slab, rows, "bn1", True)
 
@@ -947,40 +834,69 @@ class Engine:
             fn, ready = mk()
             self.bwd.append(fn)
             self.grad_ready.append(ready)
-        self._group_wgrads()
+        self._plan_folds()
         seen = [n for r in self.grad_ready for n in r] + self._deferred_names
         assert sorted(seen) == sorted(self.layout.params), "every parameter must receive its gradient exactly once"
 
-    def _group_wgrads(self) -> None:
-        """Runs of consecutive dense-conv weight gradients with one geometry (in backward order) become groups of up to
-        `wgrad_group` layers: all but the last member defer, the last one launches the group and reports every member's
-        gradient as ready (on_grad_ready feeds the all-reduce buckets)."""
+    def _plan_folds(self) -> None:
+        """Fixes how every dense weight gradient is launched and folded (the backward program is static, so this runs once).
+        Runs of consecutive dense layers with one geometry (in backward order: the three 728 -> 728 pointwise convs of a middle-flow
+        Block) become groups of up to `wgrad_group` layers: all but the last member defer, the last one launches the group
+        (dc_conv_wgrad_partial) and reports every member's gradient as ready.  Every launch is followed, on the same stream, by one
+        dc_fold_slabs over its own slabs plus the rows left by the depthwise layers whose data-gradient kernels were enqueued since the
+        previous fold (their names move to this op's ready list: on_grad_ready feeds the all-reduce buckets)."""
         lib = L.load()
         G = self.wgrad_group
         recs = self._wg_recs            # make_bwd ran in backward order, so this list is in execution order
         i = 0
-        while G > 1 and i < len(recs):
+        while i < len(recs):
             j = i
-            while j + 1 < len(recs) and j + 1 - i < G and recs[j + 1]["key"] == recs[i]["key"] and not recs[j + 1]["bias"]:
-                j += 1
             r0 = recs[i]
-            if j > i and not r0["bias"] and self.dt == L.DC_BF16 and r0["key"][0] == L.DC_BF16:
-                members = recs[i:j + 1]
-                cnt = len(members)
-                d, x = r0["d"], r0["x"]
-                gbytes = lib.dc_conv_wgrad_group_workspace(C.byref(d), x.N, x.H, x.W, cnt)
-                self._need_ws(gbytes)
-                xs = (C.c_void_p * cnt)(*[m["x"].ptr.value for m in members])
-                dys = (C.c_void_p * cnt)(*[m["dy"].ptr.value for m in members])
-                gws = (C.c_void_p * cnt)(*[m["gw"].value for m in members])
-                last = members[-1]
-                for m in members[:-1]:
-                    m["role"] = "defer"
-                    m["ready"].remove(m["wname"])
-                    last["ready"].append(m["wname"])
-                last["role"] = "flush"
-                last["group"] = (cnt, xs, dys, gws, gbytes)
+            groupable = G > 1 and not r0["bias"] and self.dt == L.DC_BF16 and r0["key"][0] == L.DC_BF16
+            while groupable and j + 1 < len(recs) and j + 1 - i < G and recs[j + 1]["key"] == r0["key"] and not recs[j + 1]["bias"]:
+                j += 1
+            d, x = r0["d"], r0["x"]
+            splits, sbytes = C.c_int(), C.c_size_t()
+            if j > i and lib.dc_conv_wgrad_plan(C.byref(d), x.N, x.H, x.W, j + 1 - i, C.byref(splits), C.byref(sbytes)) != 0:
+                j = i                                   # the grouped launch does not serve this geometry: one launch per layer
+            members = recs[i:j + 1]
+            cnt = len(members)
+            L.call("dc_conv_wgrad_plan", C.byref(d), x.N, x.H, x.W, cnt, C.byref(splits), C.byref(sbytes))
+            slabs = [torch.empty(max(sbytes.value, 16), dtype=torch.uint8, device=self.device) for _ in members]
+            self._keep += slabs
+            last = members[-1]
+            for m in members[:-1]:
+                m["role"] = "defer"
+                m["ready"].remove(m["wname"])
+                last["ready"].append(m["wname"])
+            last["role"] = "flush" if cnt > 1 else "solo"
+            last["launch"] = (cnt, (C.c_void_p * cnt)(*[m["x"].ptr.value for m in members]),
+                              (C.c_void_p * cnt)(*[m["dy"].ptr.value for m in members]),
+                              (C.c_void_p * cnt)(*[t.data_ptr() for t in slabs]), splits.value)
+            kind = L.DC_FOLD_CONVT if d.transposed else L.DC_FOLD_CONV
+            last["own_entries"] = [L.FoldEntry(t.data_ptr(), m["gw"].value, kind, splits.value, d.k * d.k, d.cout, d.cin)
+                                   for m, t in zip(members, slabs)]
             i = j + 1
+        pending: List[tuple] = []
+        for item in self._fold_seq:
+            if item[0] == "dw":
+                pending.append(item)
+                continue
+            rec = item[1]
+            if rec["role"] == "defer":
+                continue
+            ents = [it[1] for it in pending] + rec["own_entries"]
+            rec["fold"] = ((L.FoldEntry * len(ents))(*ents), len(ents))
+            for _, _, name, ready in pending:
+                ready.remove(name)
+                rec["ready"].append(name)
+            pending = []
+        if pending:       # depthwise layers behind the last dense launch of the program (the entry flow's first separable convs)
+            ents = [it[1] for it in pending]
+            for _, _, name, ready in pending:
+                ready.remove(name)
+                self._deferred_names.append(name)
+            self._final_fold = ((L.FoldEntry * len(ents))(*ents), len(ents), [it[2] for it in pending])
 
     # ------------------------------------------------------------------------------------------------ execution
     def pack_weights(self) -> None:
@@ -1041,7 +957,10 @@ class Engine:
                 ready, self._ready_now = ready + self._ready_now, []
             if cb is not None and ready:
                 cb(ready)
-        self._flush_deferred()
+        if self._final_fold is not None:
+            ents, nent, names = self._final_fold
+            self._on_side(lambda ws: L.call("dc_fold_slabs", ents, nent, self._st()))
+            self._ready_now += names
         if self._ready_now:
             ready, self._ready_now = self._ready_now, []
             if cb is not None:

@@ -28,6 +28,15 @@ class PackEntry(C.Structure):
                 ("taps", C.c_int), ("kind", C.c_int)]
 
 
+class FoldEntry(C.Structure):
+    """dc_fold_entry (include/deepcam_hip.h): one layer's partial slabs and where their fixed-order sum goes."""
+    _fields_ = [("slab", C.c_void_p), ("grad", C.c_void_p), ("kind", C.c_int), ("splits", C.c_int), ("taps", C.c_int),
+                ("co", C.c_int), ("ci", C.c_int)]
+
+
+DC_FOLD_CONV, DC_FOLD_CONVT, DC_FOLD_DW = 0, 1, 2
+
+
 class BnFin(C.Structure):
     """dc_bn_fin (include/deepcam_hip.h): dc_bn_finalize's arguments as one block + the hand-over words of the in-kernel form."""
     _fields_ = [("count", C.c_long), ("slab", C.c_void_p), ("rows", C.c_int), ("gamma", C.c_void_p), ("beta", C.c_void_p),
@@ -63,6 +72,9 @@ _SIGS = {
     "dc_conv_wgrad": (I, [CD, I, I, I, P, I, P, I, P, SZ, P, P]),
     "dc_conv_wgrad_group_workspace": (SZ, [CD, I, I, I, I]),
     "dc_conv_wgrad_group": (I, [CD, I, I, I, I, P, I, P, I, P, SZ, P, P]),
+    "dc_conv_wgrad_plan": (I, [CD, I, I, I, I, C.POINTER(I), C.POINTER(C.c_size_t)]),
+    "dc_conv_wgrad_partial": (I, [CD, I, I, I, I, P, I, P, I, P, I, P]),
+    "dc_fold_slabs": (I, [P, I, P]),
     "dc_colsum": (I, [I, L, I, P, I, P, P, P]),
     "dc_colsum_workspace": (SZ, [L, I]),
     "dc_dwconv_pack_weights": (I, [I, P, P, P]),

@@ -8,7 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
 import os, sys, time, torch
-sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+ROOT = %r
+if os.environ.get("AB_ROOT"):          # another tree's package + library (scripts/snapshot_tree.sh)
+    ROOT = os.path.join(ROOT, os.environ["AB_ROOT"])
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from mlperf_deepcam_amd import nn as dnn
 B, steps, optn, dt = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
 dtype = torch.bfloat16 if dt == "bf16" else torch.float32
@@ -24,7 +27,7 @@ with ctx:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): step(x, y)
     torch.cuda.synchronize(); print("MS", (time.perf_counter() - t0) / steps * 1e3, step.loss())
-''' % (ROOT, ROOT)
+''' % (ROOT,)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8)

@@ -15,6 +15,7 @@ regenerated from seeds by the tests; expected outputs are stored here):
   model_small.json     G4  64x96 B=2: logits samples, loss, IoU, grad checksums, 3 steps Adam and AdamW, eval B=1
   model_full.json      G4  768x1152 B=2 (only with --full)
   model_full_b4.json   G4  768x1152 B=4, two Adam steps (only with --full or --only full_b4)
+  model_full_b8.json   G4  768x1152 B=8 (the benched local batch), two Adam steps (only with --only full_b8; ~50 GB resident)
   lr_schedule.json     G5  MultiStepLR sequences through the reference's get_lr_schedule
 """
 import argparse
@@ -253,6 +254,13 @@ def g4_model_full_b4():
     json.dump(out, open(os.path.join(HERE, "model_full_b4.json"), "w"), indent=0)
 
 
+def g4_model_full_b8():
+    """The benched local batch (BASELINE configs[4] per GPU, 8 samples) at full size: two Adam steps of the reference."""
+    out = {"recipe": "as model_small.json with B=8", "H": 768, "W": 1152, "B": 8}
+    out["adam_wd1e-6"], _ = run_model_steps(768, 1152, "Adam", 2, 1e-6, B=8)
+    json.dump(out, open(os.path.join(HERE, "model_full_b8.json"), "w"), indent=0)
+
+
 def g5_lr():
     out = {}
     arg = {"type": "multistep", "milestones": "3 6", "decay_rate": "0.1"}
@@ -298,4 +306,6 @@ if __name__ == "__main__":
         g4_model_full()
     if a.full or a.only == "full_b4":
         g4_model_full_b4()
+    if a.only == "full_b8":
+        g4_model_full_b8()
     print("golden fixtures written to", HERE)

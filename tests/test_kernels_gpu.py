@@ -656,6 +656,93 @@ def test_conv_wgrad_group(case, dtype):
         L.call("dc_conv_wgrad_group", C.byref(d), N, H, W, layers, pa(xs), cin + 16, pa(gys), cout, vptr(ws), 16, pa(gws), S())
 
 
+FOLD_CASES = [
+    # name, k, stride, pad, dil, transposed, cin, cout, N, H, W, layers
+    ("pw728_x3", 1, 1, 0, 1, 0, 728, 728, 2, 24, 20, 3),
+    ("dense3x3", 3, 1, 1, 1, 0, 256, 256, 2, 10, 12, 1),
+    ("tconv", 3, 2, 1, 1, 1, 64, 48, 2, 7, 9, 1),              # ConvTranspose2d: master layout [cin][cout][3][3]
+    ("thin_128tile", 1, 1, 0, 1, 0, 64, 48, 2, 9, 7, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", FOLD_CASES, ids=[c[0] for c in FOLD_CASES])
+def test_conv_wgrad_partial_and_fold(case, dtype):
+    """dc_conv_wgrad_partial + dc_fold_slabs (slabs of several layers and a depthwise layer's rows in ONE fold launch) give the bits of
+    the reducing calls dc_conv_wgrad / dc_conv_wgrad_group / dc_dwconv_wgrad_reduce."""
+    name, k, stride, pad, dil, tr, cin, cout, N, H, W, layers = case
+    if dtype == torch.float32 and layers > 1:
+        pytest.skip("the grouped launch is bf16 only")
+    d = desc(dtype, k, stride, pad, dil, tr, cin, cout)
+    wshape = (cin, cout, 3, 3) if tr else (cout, cin, k, k)
+    Ho, Wo = C.c_int(), C.c_int()
+    L.call("dc_conv_out_hw", C.byref(d), H, W, C.byref(Ho), C.byref(Wo))
+    Ho, Wo = Ho.value, Wo.value
+    xs, gys, keep = [], [], []
+    for l in range(layers):
+        xb, xv = to_nhwc(q(rnd(N, cin, H, W, seed=10 + l), dtype), dtype, ld=cin + 16, off=8)
+        gb, gyv = to_nhwc(q(rnd(N, cout, Ho, Wo, seed=20 + l), dtype), dtype)
+        keep += [xb, gb]
+        xs.append(xv)
+        gys.append(gyv)
+    lib = L.load()
+    pa = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    # reference: the reducing calls
+    ref = [torch.full(wshape, float("nan"), device=dev()) for _ in range(layers)]
+    wsb = lib.dc_conv_wgrad_group_workspace(C.byref(d), N, H, W, layers)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev())
+    L.call("dc_conv_wgrad_group", C.byref(d), N, H, W, layers, pa(xs), cin + 16, pa(gys), cout, vptr(ws), wsb, pa(ref), S())
+    # a depthwise layer's rows ride along in the same fold
+    Cd, rows = 72, 37
+    wslab = torch.randn(rows, 9, Cd, device=dev())
+    dref = torch.full((Cd, 1, 3, 3), float("nan"), device=dev())
+    L.call("dc_dwconv_wgrad_reduce", Cd, rows, vptr(wslab), vptr(dref), S())
+    # slab-only form
+    splits, sbytes = C.c_int(), C.c_size_t()
+    L.call("dc_conv_wgrad_plan", C.byref(d), N, H, W, layers, C.byref(splits), C.byref(sbytes))
+    assert sbytes.value == splits.value * wshape[0] * wshape[1] * wshape[2] * wshape[3] * 4
+    slabs = [torch.full((sbytes.value // 4,), float("nan"), device=dev()) for _ in range(layers)]
+    got = [torch.full(wshape, float("nan"), device=dev()) for _ in range(layers)]
+    dgot = torch.full((Cd, 1, 3, 3), float("nan"), device=dev())
+    L.call("dc_conv_wgrad_partial", C.byref(d), N, H, W, layers, pa(xs), cin + 16, pa(gys), cout, pa(slabs), splits.value, S())
+    kind = L.DC_FOLD_CONVT if tr else L.DC_FOLD_CONV
+    ents = [L.FoldEntry(wslab.data_ptr(), dgot.data_ptr(), L.DC_FOLD_DW, rows, 9, Cd, 1)]
+    ents += [L.FoldEntry(slabs[l].data_ptr(), got[l].data_ptr(), kind, splits.value, wshape[2] * wshape[3], cout, cin) for l in range(layers)]
+    L.call("dc_fold_slabs", (L.FoldEntry * len(ents))(*ents), len(ents), S())
+    torch.cuda.synchronize()
+    for l in range(layers):
+        assert torch.equal(got[l], ref[l]), name
+    assert torch.equal(dgot, dref)
+    with pytest.raises(L.DeepcamHipError, match="split plan"):
+        L.call("dc_conv_wgrad_partial", C.byref(d), N, H, W, layers, pa(xs), cin + 16, pa(gys), cout, pa(slabs), splits.value + 1, S())
+
+
+def test_fold_more_entries_than_one_launch_holds():
+    """dc_fold_slabs cuts long entry lists into launches of 24; 60 small layers of three kinds against a torch sum."""
+    torch.manual_seed(5)
+    ents, checks, keep = [], [], []
+    for i in range(60):
+        if i % 3 == 2:
+            Cd, rows = 8 * (1 + i % 5), 3 + i
+            slab = torch.randn(rows, 9, Cd, device=dev())
+            out = torch.full((Cd, 9), float("nan"), device=dev())
+            ents.append(L.FoldEntry(slab.data_ptr(), out.data_ptr(), L.DC_FOLD_DW, rows, 9, Cd, 1))
+            checks.append((out, slab.double().sum(0).t().float(), 1e-6))
+        else:
+            co, ci, taps, splits = 8 + i, 4 * (1 + i % 7), (1, 9)[i % 2], 1 + i % 11
+            slab = torch.randn(splits, taps, co, ci, device=dev())
+            trn = i % 3 == 1
+            out = torch.full((ci, co, taps) if trn else (co, ci, taps), float("nan"), device=dev())
+            ents.append(L.FoldEntry(slab.data_ptr(), out.data_ptr(), L.DC_FOLD_CONVT if trn else L.DC_FOLD_CONV, splits, taps, co, ci))
+            r = slab.double().sum(0)                          # [taps][co][ci]
+            checks.append((out, (r.permute(2, 1, 0) if trn else r.permute(1, 2, 0)).float(), 1e-5))
+        keep.append(slab)
+    L.call("dc_fold_slabs", (L.FoldEntry * len(ents))(*ents), len(ents), S())
+    torch.cuda.synchronize()
+    for out, want, tol in checks:
+        np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=tol, atol=tol)
+
+
 def test_conv_rejects_bad_arguments():
     d = desc(torch.bfloat16, 5, 1, 0, 1, 0, 64, 64)
     x = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device=dev())

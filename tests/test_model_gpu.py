@@ -222,31 +222,6 @@ def test_golden_full_size_step0(golden_dir, dtype, tol):
     assert torch.isfinite(eng.grads).all()
 
 
-def test_batchnorm_finalize_inside_the_consumer_same_bits(monkeypatch):
-    """DC_FUSE_BN_FINALIZE=1 (the depthwise kernels run the finalize step of the BatchNorm they read through; off by default, DESIGN
-    section 5) against the two-launch form: the same parameters, BatchNorm buffers and loss bit for bit after two steps, and no
-    workgroup's wait ran out."""
-    x, y = make_inputs(2, 96, 160)
-    res = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("DC_FUSE_BN_FINALIZE", flag)
-        net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=torch.bfloat16, seed=333)
-        net.materialize(2, 96, 160)
-        net.train()
-        opt = dnn.make_optimizer("LAMB", net, 1e-3, 1e-8, 1e-2)
-        step = dnn.TrainStep(net, opt, CW, 2, 96, 160)
-        for _ in range(2):
-            step(x.to(DEV), y.to(DEV))
-        torch.cuda.synchronize()
-        eng = net.engine
-        assert (len(eng._fin_syncs) > 30) == (flag == "1")          # 39 of the lazily applied BatchNorms feed a stride-1 depthwise kernel
-        assert eng.fin_waits_run_out() == 0
-        res.append((step.loss(), eng.params.clone(), eng.buffers.clone(), eng.nbt.clone()))
-    assert res[0][0] == res[1][0]
-    for a, b in zip(res[0][1:], res[1][1:]):
-        assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize("optname", ["LAMB", "AdamW"])
 def test_train_step_is_bit_reproducible(optname):
     """Two independently built models, the same batch, three steps (weight gradients on the side stream): no kernel that feeds
