@@ -471,6 +471,7 @@ extern "C" int dc_dw_set_option(const char* name, int value) {
   if (strcmp(name, "dw_tile") == 0) { g_dw_tile = value != 0; return 0; }
   if (strcmp(name, "dw_wgrad_tpb") == 0) { dw_tile_set_tpb(value); return 0; }
   if (strcmp(name, "dw_cg") == 0) { dw_tile_set_cg(value); return 0; }
+  if (strcmp(name, "dw_pipe") == 0) { dw_pipe_set(value); return 0; }
   if (strcmp(name, "dw_fin_fallback") == 0) { dw_tile_set_fin_fallback(value); return 0; }
   return -1;
 }
@@ -555,7 +556,10 @@ extern "C" int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int
 
 extern "C" int dc_dwconv_dgrad_bnstats_rows(int dtype, int C, int stride, int dil, int N, int Hi, int Wi) {
   if (!g_dw_tile || (dtype != DC_BF16 && dtype != DC_F32) || C <= 0 || N <= 0) return 0;
-  if (stride == 1 && (dil == 1 || dil == 2)) return dw_tile_rows(dtype, C, N, Hi, Wi);
+  if (stride == 1 && (dil == 1 || dil == 2)) {
+    const int pr = dw_pipe_rows(dtype, C, dil, N, Hi, Wi);    // persistent kernel (dwpipe.hip): one slab row per workgroup
+    return pr > 0 ? pr : dw_tile_rows(dtype, C, N, Hi, Wi);
+  }
   if (stride == 2 && dil == 1) return dw_tile_s2_dgrad_rows(dtype, C, N, Hi, Wi);
   return 0;
 }
@@ -586,6 +590,8 @@ extern "C" int dc_dwconv_dgrad_bnstats(int dtype, int C, int stride, int dil, in
 extern "C" int dc_dwconv_dgrad_wgrad_rows(int dtype, int C, int stride, int dil, int N, int Hi, int Wi) {
   if (stride != 1 || (dil != 1 && dil != 2) || !g_dw_tile) return 0;
   if (dc_dwconv_dgrad_bnstats_rows(dtype, C, stride, dil, N, Hi, Wi) <= 0) return 0;
+  const int pr = dw_pipe_rows(dtype, C, dil, N, Hi, Wi);
+  if (pr > 0) return pr;
   const int rows = dw_tile_rows(dtype, C, N, Hi, Wi);
   return rows <= DWT_MAX_ROWS ? rows : 0;
 }

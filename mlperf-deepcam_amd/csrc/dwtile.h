@@ -23,6 +23,14 @@ void dw_tile_set_tpb(int v);
 void dw_tile_set_cg(int v);
 int dw_tile_reduce(const float* slab, float* grad_w, int rows, int C, hipStream_t st);   // grad[c][t] = sum of slab rows (fp64, fixed order)
 
+// persistent pipelined kernel (dwpipe.hip): bf16, >= 128 channels, image extents multiples of 8.  dw_pipe_rows: workgroups per channel
+// block = slab rows of the sums that ride along with the data gradient; 0 = shape not served (or switched off: option "dw_pipe")
+int dw_pipe_rows(int dtype, int C, int dil, int N, int H, int W);
+int launch_dw_pipe(int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out, int ldout, int N,
+                   int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats* bnstats);
+void dw_pipe_set(int v);
+bool dw_pipe_forward();
+
 // stride-2 kernels (dwtile_s2.hip).  mode 0 forward, 1 data gradient (p1 = addend or null), 2 weight-gradient rows into the slab
 int launch_dw_tile_s2(int dtype, int mode, int N, int Hi, int Wi, int C, const void* p0, int ld0, const float* wp, const void* p1, int ld1,
                       void* out, int ldout, float* slab, int* rows_out, hipStream_t st, const float* pscale = nullptr,

@@ -477,6 +477,11 @@ int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, cons
                    void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu,
                    const DwBnStats* bnstats, const BnFinArgs* finp) {
   const int kpv = dtype == DC_BF16 ? 8 : 4;
+  // the persistent pipelined kernel serves the data gradients (52.0 -> 41.5 us with BatchNorm sums and weight gradient on the 728-channel
+  // layers at local batch 8); the forward pass stays here unless option "dw_pipe" = 2 (23.4 vs 24.1 us plain, 34.5 vs 31.7 us with the
+  // BatchNorm applied on load: its in-place transform pass costs eight waves more than it costs three co-resident workgroups)
+  if (finp == nullptr && (flip || dw_pipe_forward()) && (long)N * H * W < (1L << 31) && dw_pipe_rows(dtype, C, dil, N, H, W) > 0)
+    return launch_dw_pipe(dil, flip, in, ldin, wp, addend, ldadd, out, ldout, N, H, W, C, st, pscale, pshift, prelu, bnstats);
   const TileGrid t = tile_grid(C / kpv, N, H, W);
   DC_REQUIRE((long)t.ntiles * t.ncgb < (1L << 31) && (long)N * H * W < (1L << 31), "dc_dwconv: tensor too large for the tiled path");
   DwBnStats bs;

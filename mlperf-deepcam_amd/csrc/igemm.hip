@@ -938,7 +938,7 @@ static const struct { const char* name; int value; } kOptionDefaults[] = {
     {"igemm256k", 0}, {"igemm256_tile2d", 0}, {"thin_fwd", 1}, {"igemm256_rel", 0}, {"igemm_mix", 0}, {"pack_blocks", 2048},
     {"igemm256_epi", 0}, {"igemm256_phase_fast", 1}, {"igemm_mix_cus", 256}, {"igemm_mix_tail", 40}, {"wgrad_target_blocks", 768},
     {"wgrad_mode", 1}, {"wgrad_min_steps", 16}, {"wgrad256", 1}, {"thin_wgrad", 1}, {"wgrad256_slots", 192}, {"head_fused", 1},
-    {"head_dgrad_fused", 1}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_fin_fallback", 0}, {"bn_cgw", 32}, {"bn_rows", 32},
+    {"head_dgrad_fused", 1}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_fin_fallback", 0}, {"dw_pipe", 1}, {"bn_cgw", 32}, {"bn_rows", 32},
 };
 
 extern "C" int dc_reset_options(void) {

@@ -804,7 +804,9 @@ DW_CASES = [("s1", 728, 1, 1, 2, 12, 10), ("s2", 128, 2, 1, 2, 16, 12), ("d2", 1
             # stride-1 tiled path with thin layers (16 / 8 channel groups -> 16 / 32 pixel wide tiles), several tiles, ragged edges
             ("thin128", 128, 1, 1, 1, 17, 37), ("thin64", 64, 1, 1, 2, 9, 40), ("thin32d2", 32, 1, 2, 1, 11, 35),
             # stride-2 tiled path: several tiles, ragged edges, odd extents, all three channel-group widths
-            ("s2_728", 728, 2, 1, 1, 22, 34), ("s2_256", 256, 2, 1, 2, 13, 41), ("s2_64", 64, 2, 1, 1, 18, 70)]
+            ("s2_728", 728, 2, 1, 1, 22, 34), ("s2_256", 256, 2, 1, 2, 13, 41), ("s2_64", 64, 2, 1, 1, 18, 70),
+            # extents that are multiples of 8 with >= 128 channels: the persistent pipelined kernel (dwpipe.hip) in bf16
+            ("pipe728", 728, 1, 1, 2, 16, 24), ("pipe1024d2", 1024, 1, 2, 1, 16, 8), ("pipe128", 128, 1, 1, 3, 24, 40)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
@@ -942,6 +944,88 @@ def test_depthwise_tiled_matches_register_window_path():
         outs.append((yv.clone(), gv.clone()))
     L.call("dc_set_option", b"dw_tile", 1)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+PIPE_CASES = [("728", 728, 1, 2, 16, 24), ("728_b8", 728, 1, 8, 48, 72), ("1024d2", 1024, 2, 2, 16, 16), ("1536", 1536, 1, 1, 8, 8),
+              ("128", 128, 1, 1, 40, 64), ("256_one_tile_each", 256, 1, 1, 8, 16)]
+
+
+@pytest.mark.parametrize("case", PIPE_CASES, ids=[c[0] for c in PIPE_CASES])
+def test_depthwise_pipelined_kernel_matches_tiled(case):
+    """dwpipe.hip (persistent, LDS-DMA ring, sums kept in registers across a workgroup's tiles) against dwtile.hip (option dw_pipe = 0) on
+    every entry point it serves: outputs bit for bit (same taps, same order per pixel); BatchNorm sums and weight gradients after their
+    finalize / fold to the rounding of a different summation order (one slab row per workgroup instead of one per tile)."""
+    _, Cc, dil, N, H, W = case
+    dt = L.DC_BF16
+    lib = L.load()
+    x = q(rnd(N, Cc, H, W, seed=1), torch.bfloat16)
+    gy = q(rnd(N, Cc, H, W, seed=3), torch.bfloat16)
+    add = q(rnd(N, Cc, H, W, seed=4), torch.bfloat16)
+    wm = rnd(Cc, 1, 3, 3, seed=2, scale=1 / 3).to(dev())
+    wd = torch.empty(9 * Cc, device=dev())
+    L.call("dc_dwconv_pack_weights", Cc, vptr(wm), vptr(wd), S())
+    mean, invstd = rnd(Cc, seed=8, scale=0.2).to(dev()), (torch.rand(Cc) + 0.5).to(dev())
+    sc, sh = (torch.rand(Cc) + 0.5).to(dev()), rnd(Cc, seed=9, scale=0.3).to(dev())
+    ld = (Cc + 31) // 32 * 32
+    _, xv = to_nhwc(x, torch.bfloat16, ld=ld)
+    _, gyv = to_nhwc(gy, torch.bfloat16, ld=ld)
+    _, addv = to_nhwc(add, torch.bfloat16)
+    res = []
+    for mode in (2, 0):                                  # 2: the forward pass on the pipelined kernel too (default 1: data gradients only)
+        L.call("dc_set_option", b"dw_pipe", mode)
+        out = {}
+        for prelu, tag in ((None, "fwd"), (1, "fwd_bn_relu"), (0, "fwd_bn")):
+            _, yv = empty_nhwc(N, H, W, Cc, torch.bfloat16)
+            L.call("dc_dwconv_fwd", dt, Cc, 1, dil, N, H, W, vptr(xv), ld, vptr(wd), vptr(yv), Cc, vptr(sc) if prelu is not None else None,
+                   vptr(sh) if prelu is not None else None, prelu or 0, S())
+            out[tag] = yv
+        _, g1 = empty_nhwc(N, H, W, Cc, torch.bfloat16)
+        L.call("dc_dwconv_dgrad", dt, Cc, 1, dil, N, H, W, vptr(gyv), ld, vptr(wd), None, 0, vptr(g1), Cc, S())
+        _, g2 = empty_nhwc(N, H, W, Cc, torch.bfloat16)
+        L.call("dc_dwconv_dgrad", dt, Cc, 1, dil, N, H, W, vptr(gyv), ld, vptr(wd), vptr(addv), Cc, vptr(g2), Cc, S())
+        out["dgrad"], out["dgrad_add"] = g1, g2
+        for relu in (1, 0):
+            rows = lib.dc_dwconv_dgrad_bnstats_rows(dt, Cc, 1, dil, N, H, W)
+            wrows = lib.dc_dwconv_dgrad_wgrad_rows(dt, Cc, 1, dil, N, H, W)
+            assert rows > 0 and wrows > 0
+            _, g3 = empty_nhwc(N, H, W, Cc, torch.bfloat16)
+            slab = torch.full((2, rows, Cc), float("nan"), device=dev())
+            L.call("dc_dwconv_dgrad_bnstats", dt, Cc, 1, dil, N, H, W, vptr(gyv), ld, vptr(wd), vptr(g3), Cc, vptr(xv), ld, vptr(mean), vptr(invstd),
+                   vptr(sc), vptr(sh), relu, vptr(slab), S())
+            dgam, dbet = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
+            L.call("dc_bn_bwd_finalize", Cc, vptr(slab), rows, vptr(dgam), vptr(dbet), S())
+            _, g4 = empty_nhwc(N, H, W, Cc, torch.bfloat16)
+            slab2 = torch.full((2, rows, Cc), float("nan"), device=dev())
+            wslab = torch.full((wrows, 9, Cc), float("nan"), device=dev())
+            gw = torch.full((Cc, 1, 3, 3), float("nan"), device=dev())
+            L.call("dc_dwconv_dgrad_bnstats_wgrad", dt, Cc, 1, dil, N, H, W, vptr(gyv), ld, vptr(wd), vptr(g4), Cc, vptr(xv), ld, vptr(mean),
+                   vptr(invstd), vptr(sc), vptr(sh), relu, vptr(slab2), vptr(wslab), S())
+            L.call("dc_dwconv_wgrad_reduce", Cc, wrows, vptr(wslab), vptr(gw), S())
+            torch.cuda.synchronize()
+            assert torch.equal(slab, slab2) and torch.equal(g3, g4) and torch.equal(g3, g1)
+            out[f"stats{relu}"] = (dgam, dbet, gw)
+        # stored (or lazily affine) layer input, addend, no statistics
+        for aff in (0, 1):
+            _, g5 = empty_nhwc(N, H, W, Cc, torch.bfloat16)
+            wslab = torch.full((wrows, 9, Cc), float("nan"), device=dev())
+            gw = torch.full((Cc, 1, 3, 3), float("nan"), device=dev())
+            L.call("dc_dwconv_dgrad_wgrad", dt, Cc, 1, dil, N, H, W, vptr(gyv), ld, vptr(wd), vptr(addv), Cc, vptr(g5), Cc, vptr(xv), ld,
+                   vptr(sc) if aff else None, vptr(sh) if aff else None, aff, vptr(wslab), S())
+            L.call("dc_dwconv_wgrad_reduce", Cc, wrows, vptr(wslab), vptr(gw), S())
+            torch.cuda.synchronize()
+            assert torch.equal(g5, g2)
+            out[f"wg_add{aff}"] = gw
+        res.append(out)
+    L.call("dc_set_option", b"dw_pipe", 1)
+    a, b = res
+    for k in ("fwd", "fwd_bn_relu", "fwd_bn", "dgrad", "dgrad_add"):
+        assert torch.equal(a[k], b[k]), k
+    for relu in (1, 0):
+        for u, v in zip(a[f"stats{relu}"], b[f"stats{relu}"]):
+            np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=3e-5, atol=3e-5 * float(v.abs().max()))
+    for aff in (0, 1):
+        u, v = a[f"wg_add{aff}"], b[f"wg_add{aff}"]
+        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=3e-5, atol=3e-5 * float(v.abs().max()))
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
