@@ -225,6 +225,16 @@ int dc_dwconv_dgrad_bnstats_wgrad(int dtype, int C, int stride, int dil, int N, 
 int dc_dwconv_dgrad_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
                           const float* w_packed, const void* addend, int ldadd, void* dx, int lddx, const void* x, int ldx,
                           const float* pscale, const float* pshift, int prelu, float* wslab, void* stream);
+/* dc_dwconv_dgrad_wgrad where the stored input x is itself relu(bn(ybn) + residual), the output of the previous Xception block
+ * (deeplab_xception.py:99-122: `x += skip`, then the next block's in-place ReLU), and this data gradient is the LAST contribution to d(x):
+ * that BatchNorm's backward sums (sum g, sum g*xhat; g = the stored dx masked by x > 0 when relu) are taken on the way out into
+ * slab[2][rows][C], so dc_bn_bwd_reduce's pass over dx, ybn and x is not needed.  rows = dc_dwconv_dgrad_wgrad_bnres_rows (also the
+ * rows of wslab; 0: not served -- use dc_dwconv_dgrad_wgrad and dc_bn_bwd_reduce). */
+int dc_dwconv_dgrad_wgrad_bnres_rows(int dtype, int C, int stride, int dil, int N, int Hi, int Wi);
+int dc_dwconv_dgrad_wgrad_bnres(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                const float* w_packed, const void* addend, int ldadd, void* dx, int lddx, const void* x, int ldx,
+                                float* wslab, const void* ybn, int ldybn, const float* save_mean, const float* save_invstd, int relu,
+                                float* slab, void* stream);
 int dc_dwconv_wgrad_reduce(int C, int rows, const float* wslab, float* grad_w, void* stream);
 size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int stride);
 int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,

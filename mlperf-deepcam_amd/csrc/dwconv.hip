@@ -632,6 +632,36 @@ extern "C" int dc_dwconv_dgrad_wgrad(int dtype, int C, int stride, int dil, int 
   return launch_dw_tile(dtype, dil, true, dy, lddy, w, addend, ldadd, dx, lddx, N, Hi, Wi, C, (hipStream_t)stream, nullptr, nullptr, 0, &bs);
 }
 
+// dc_dwconv_dgrad_wgrad on a layer whose stored input x is a BatchNorm output with a residual, relu(bn(ybn) + r) -- the first separable conv
+// of an Xception block reading the previous block's output -- and whose data gradient is the LAST contribution to d(x): the kernel also
+// takes that BatchNorm's backward sums (g = dx masked by x > 0 when relu; slab[2][rows][C]), so dc_bn_bwd_reduce's pass over dx, ybn and x
+// disappears.  Served by the persistent kernel only (rows = 0: use dc_dwconv_dgrad_wgrad + dc_bn_bwd_reduce).
+extern "C" int dc_dwconv_dgrad_wgrad_bnres_rows(int dtype, int C, int stride, int dil, int N, int Hi, int Wi) {
+  if (stride != 1 || dil != 1 || !g_dw_tile) return 0;
+  return dw_pipe_rows(dtype, C, dil, N, Hi, Wi);
+}
+
+extern "C" int dc_dwconv_dgrad_wgrad_bnres(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                           const float* w, const void* addend, int ldadd, void* dx, int lddx, const void* x, int ldx,
+                                           float* wslab, const void* ybn, int ldybn, const float* save_mean, const float* save_invstd,
+                                           int relu, float* slab, void* stream) {
+  if (int e = dw_check(dtype, C, stride, dil, N, Hi, Wi)) return e;
+  if (int e = dc_check_view(dy, lddy, C, dtype, "dc_dwconv_dgrad_wgrad_bnres dy")) return e;
+  if (int e = dc_check_view(dx, lddx, C, dtype, "dc_dwconv_dgrad_wgrad_bnres dx")) return e;
+  if (int e = dc_check_view(x, ldx, C, dtype, "dc_dwconv_dgrad_wgrad_bnres x")) return e;
+  if (int e = dc_check_view(ybn, ldybn, C, dtype, "dc_dwconv_dgrad_wgrad_bnres ybn")) return e;
+  if (addend != nullptr)
+    if (int e = dc_check_view(addend, ldadd, C, dtype, "dc_dwconv_dgrad_wgrad_bnres addend")) return e;
+  DC_REQUIRE(w && wslab && save_mean && save_invstd && slab, "dc_dwconv_dgrad_wgrad_bnres: null argument");
+  DC_REQUIRE(dc_dwconv_dgrad_wgrad_bnres_rows(dtype, C, stride, dil, N, Hi, Wi) > 0, "dc_dwconv_dgrad_wgrad_bnres: shape not served");
+  DwBnStats bs;
+  bs.y = x; bs.ldy = ldx; bs.mean = bs.invstd = nullptr; bs.mscale = nullptr; bs.mshift = nullptr; bs.relu = 0;
+  bs.slab = nullptr; bs.rows = 0; bs.wslab = wslab;
+  DwResStats rs;
+  rs.y = ybn; rs.ldy = ldybn; rs.mean = save_mean; rs.invstd = save_invstd; rs.relu = relu ? 1 : 0; rs.slab = slab;
+  return launch_dw_pipe(dil, true, dy, lddy, w, addend, ldadd, dx, lddx, N, Hi, Wi, C, (hipStream_t)stream, nullptr, nullptr, 0, &bs, &rs);
+}
+
 extern "C" int dc_dwconv_wgrad_reduce(int C, int rows, const float* wslab, float* grad_w, void* stream) {
   DC_REQUIRE(C > 0 && rows > 0 && wslab && grad_w, "dc_dwconv_wgrad_reduce: bad argument");
   return dw_tile_reduce(wslab, grad_w, rows, C, (hipStream_t)stream);

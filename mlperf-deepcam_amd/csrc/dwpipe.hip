@@ -30,7 +30,10 @@ constexpr int P_TH = 8, P_TW = 8, P_CG = 16, P_THREADS = 512;
 constexpr int P_ROWB = P_CG * 16;   // bytes of one pixel's channel block in LDS
 constexpr int P_CH = P_CG * 8;      // channels of a block
 
-enum { PM_FLIP = 1, PM_STATS = 2, PM_WGRAD = 4, PM_ADD = 8, PM_XFORM = 16 };
+// PM_RES (with PM_WGRAD): the layer's stored input x is the output relu(bn(y2) + residual) of a BatchNorm whose backward sums (sum g, sum g*xhat
+// with g = dx masked by x > 0) this kernel takes as well -- dx is that BatchNorm's complete output gradient once this kernel, its last
+// writer, has added its share to the addend (the first separable conv of an Xception block, deeplab_xception.py:69-122)
+enum { PM_FLIP = 1, PM_STATS = 2, PM_WGRAD = 4, PM_ADD = 8, PM_XFORM = 16, PM_RES = 32 };
 
 template <int DIL>
 struct PCfg {
@@ -42,9 +45,10 @@ struct PCfg {
 
 template <int DIL, int MODE>
 struct PStage {
-  static constexpr bool Y = (MODE & (PM_STATS | PM_WGRAD)) != 0, A = (MODE & PM_ADD) != 0;
-  static constexpr int BYTES = PCfg<DIL>::HALO + (Y ? PCfg<DIL>::TILE : 0) + (A ? PCfg<DIL>::TILE : 0);
-  static constexpr int DMAS = PCfg<DIL>::HIT + (Y ? 2 : 0) + (A ? 2 : 0);
+  static constexpr bool Y = (MODE & (PM_STATS | PM_WGRAD)) != 0, A = (MODE & PM_ADD) != 0, Y2 = (MODE & PM_RES) != 0;
+  static constexpr int BYTES = PCfg<DIL>::HALO + ((Y ? 1 : 0) + (Y2 ? 1 : 0) + (A ? 1 : 0)) * PCfg<DIL>::TILE;
+  static constexpr int DMAS = PCfg<DIL>::HIT + 2 * ((Y ? 1 : 0) + (Y2 ? 1 : 0) + (A ? 1 : 0));
+  static constexpr int OFF_Y2 = PCfg<DIL>::HALO + (Y ? PCfg<DIL>::TILE : 0), OFF_A = OFF_Y2 + (Y2 ? PCfg<DIL>::TILE : 0);
   static constexpr int NS = (160 * 1024 / BYTES) > 4 ? 4 : (160 * 1024 / BYTES);
   static constexpr int STORES = DT_PX;    // per thread per tile
   static_assert(NS >= 2, "the ring needs two stages");
@@ -65,6 +69,12 @@ struct DwpArgs {
   const float* pshift;
   int prelu;
   DwBnStats st;         // data gradient: BatchNorm sums and / or this layer's weight-gradient rows; st.rows = workgroups per channel block
+  const bf16* y2;       // PM_RES: input of the BatchNorm whose (residual-added, ReLU'd) output is this layer's stored input st.y
+  int ldy2;
+  const float* mean2;
+  const float* invstd2;
+  int relu2;
+  float* slab2;         // [2][st.rows][C]
   const void* zero_page;
 };
 
@@ -85,7 +95,8 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
   typedef PCfg<DIL> K;
   typedef PStage<DIL, MODE> S;
   constexpr bool FLIP = (MODE & PM_FLIP) != 0, STATS = (MODE & PM_STATS) != 0, WGRAD = (MODE & PM_WGRAD) != 0, ADD = (MODE & PM_ADD) != 0,
-                 XFORM = (MODE & PM_XFORM) != 0;
+                 XFORM = (MODE & PM_XFORM) != 0, RES = (MODE & PM_RES) != 0;
+  static_assert(!RES || (WGRAD && !STATS), "PM_RES rides on the weight-gradient form");
   constexpr int WC = DT_PX + 2 * DIL, KH = 4, NS = S::NS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -116,6 +127,16 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
   for (int t9 = 0; t9 < (WGRAD ? 9 : 1); ++t9)
 #pragma unroll
     for (int e = 0; e < KH; ++e) dwa[t9][e] = 0.f;
+  float mu2[RES ? KH : 1], is2[RES ? KH : 1], ra[RES ? KH : 1], rb[RES ? KH : 1];
+  if constexpr (RES) {
+#pragma unroll
+    for (int e = 0; e < KH; ++e) {
+      mu2[e] = a.mean2[ch0 + e];
+      is2[e] = a.invstd2[ch0 + e];
+      ra[e] = rb[e] = 0.f;
+      asm volatile("" : "+v"(mu2[e]), "+v"(is2[e]));
+    }
+  }
   float xsc[8], xsh[8];   // XFORM: the coefficients of this lane's channel group (the transform pass walks the lane's DMA slots)
   if constexpr (XFORM) {
 #pragma unroll
@@ -174,7 +195,17 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
         const int p = (it * P_THREADS + tid) >> 4;
         const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
         const uintptr_t src = (live && gok) ? (uintptr_t)(ab + ((size_t)oy * W + ox) * a.ldadd) : zp;
-        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + K::HALO + (S::Y ? K::TILE : 0) + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + S::OFF_A + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
+      }
+    }
+    if constexpr (S::Y2) {
+      const bf16* yb = a.y2 + (size_t)n * H * W * a.ldy2 + goff;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int p = (it * P_THREADS + tid) >> 4;
+        const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
+        const uintptr_t src = (live && gok) ? (uintptr_t)(yb + ((size_t)oy * W + ox) * a.ldy2) : zp;
+        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + S::OFF_Y2 + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
       }
     }
   };
@@ -295,7 +326,7 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
     for (int j = 0; j < DT_PX; ++j) {
       if constexpr (ADD) {
         float av[KH];
-        unpack8(*reinterpret_cast<const vec8*>(sb + K::HALO + (S::Y ? K::TILE : 0) + (row * P_TW + xs + j) * P_ROWB + h * 8), av, bf16());
+        unpack8(*reinterpret_cast<const vec8*>(sb + S::OFF_A + (row * P_TW + xs + j) * P_ROWB + h * 8), av, bf16());
 #pragma unroll
         for (int e = 0; e < KH; ++e) acc[j][e] += av[e];
       }
@@ -307,6 +338,18 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
         float gs[KH];
         unpack8(v, gs, bf16());
         bn.add(gs, yf[j], a.st.relu);
+      }
+      if constexpr (RES) {
+        // g = the stored dx masked by the stored block output (yf = x here); xhat from the producing BatchNorm's input
+        float gs[KH], y2f[KH];
+        unpack8(v, gs, bf16());
+        unpack8(*reinterpret_cast<const vec8*>(sb + S::OFF_Y2 + (row * P_TW + xs + j) * P_ROWB + h * 8), y2f, bf16());
+#pragma unroll
+        for (int e = 0; e < KH; ++e) {
+          const float gm = (!a.relu2 || yf[j][e] > 0.f) ? gs[e] : 0.f;
+          ra[e] += gm;
+          rb[e] = fmaf(gm, (y2f[e] - mu2[e]) * is2[e], rb[e]);
+        }
       }
     }
     STAMP(tc);
@@ -340,6 +383,26 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) s += red[(q * 2 + which) * P_CH + cl];
         a.st.slab[((size_t)which * a.st.rows + wj) * a.C + c] = s;
+      }
+    }
+    __syncthreads();
+  }
+  if constexpr (RES) {
+    float* red = reinterpret_cast<float*>(smem);   // [16][2][P_CH]
+#pragma unroll
+    for (int e = 0; e < KH; ++e) {
+      red[(sl * 2 + 0) * P_CH + h * KH + e] = ra[e];
+      red[(sl * 2 + 1) * P_CH + h * KH + e] = rb[e];
+    }
+    __syncthreads();
+    if (tid < 2 * P_CH) {
+      const int which = tid / P_CH, cl = tid % P_CH;
+      const int c = cg0 * 8 + cl;
+      if (c < a.C) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[(q * 2 + which) * P_CH + cl];
+        a.slab2[((size_t)which * a.st.rows + wj) * a.C + c] = s;
       }
     }
     __syncthreads();
@@ -401,7 +464,8 @@ int dw_pipe_rows(int dtype, int C, int dil, int N, int H, int W) {
 }
 
 int launch_dw_pipe(int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out, int ldout, int N,
-                   int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats* bnstats) {
+                   int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats* bnstats,
+                   const DwResStats* res) {
   const int wc = dw_pipe_rows(DC_BF16, C, dil, N, H, W);
   DC_REQUIRE(wc > 0, "launch_dw_pipe: shape not served");
   static const void* zero_dev = nullptr;
@@ -420,11 +484,21 @@ int launch_dw_pipe(int dil, bool flip, const void* in, int ldin, const float* wp
   if (bnstats != nullptr) a.st = *bnstats;
   else { a.st.slab = nullptr; a.st.y = nullptr; a.st.ldy = 0; a.st.mean = a.st.invstd = a.st.mscale = a.st.mshift = nullptr; a.st.relu = 0; a.st.rows = 0; a.st.wslab = nullptr; }
   a.st.rows = wc;
+  a.y2 = nullptr; a.ldy2 = 0; a.mean2 = a.invstd2 = nullptr; a.relu2 = 0; a.slab2 = nullptr;
+  if (res != nullptr) {
+    a.y2 = (const bf16*)res->y; a.ldy2 = res->ldy; a.mean2 = res->mean; a.invstd2 = res->invstd; a.relu2 = res->relu; a.slab2 = res->slab;
+  }
   a.zero_page = zero_dev;
   const int grid = a.ncb * wc;
   const bool stats = flip && a.st.slab != nullptr, wg = flip && a.st.wslab != nullptr, add = flip && addend != nullptr;
   const bool xf = !flip && pscale != nullptr;
   DC_REQUIRE(!(stats || wg) || a.st.y != nullptr, "launch_dw_pipe: the sums need the BatchNorm input");
+  if (res != nullptr) {
+    DC_REQUIRE(wg && !stats && a.y2 && a.mean2 && a.invstd2 && a.slab2, "launch_dw_pipe: the residual BatchNorm's sums ride on the weight-gradient form");
+    DC_REQUIRE(dil == 1, "launch_dw_pipe: the residual form is built for dilation 1 (with dilation 2 its ring would hold a single stage)");
+    if (add) return launch1<1, PM_FLIP | PM_WGRAD | PM_ADD | PM_RES>(a, grid, st);
+    return launch1<1, PM_FLIP | PM_WGRAD | PM_RES>(a, grid, st);
+  }
 #define DWP(D, M) return launch1<D, M>(a, grid, st)
 #define DWP_MODES(D)                                                                                      \
   if (!flip) { if (xf) DWP(D, PM_XFORM); else DWP(D, 0); }                                               \

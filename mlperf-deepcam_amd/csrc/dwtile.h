@@ -6,6 +6,16 @@
 namespace dc {
 
 struct DwBnStats;   // dwtile_common.h
+// the BatchNorm whose stored output relu(bn(y) + residual) is a depthwise layer's input: its backward sums ride along with that layer's data
+// gradient (dwpipe.hip, PM_RES)
+struct DwResStats {
+  const void* y;
+  int ldy;
+  const float* mean;
+  const float* invstd;
+  int relu;
+  float* slab;
+};
 struct BnFinArgs;   // bn_fin.h
 
 constexpr int DWT_MAX_ROWS = 2048;   // most partial rows the weight-gradient slab may hold
@@ -27,7 +37,8 @@ int dw_tile_reduce(const float* slab, float* grad_w, int rows, int C, hipStream_
 // block = slab rows of the sums that ride along with the data gradient; 0 = shape not served (or switched off: option "dw_pipe")
 int dw_pipe_rows(int dtype, int C, int dil, int N, int H, int W);
 int launch_dw_pipe(int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out, int ldout, int N,
-                   int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats* bnstats);
+                   int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats* bnstats,
+                   const DwResStats* res = nullptr);
 void dw_pipe_set(int v);
 bool dw_pipe_forward();
 

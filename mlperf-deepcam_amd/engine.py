@@ -52,6 +52,7 @@ class Act:
             self.off = parent.off + off
         self._grad: Optional[Act] = None
         self.grad_init = False      # set while the backward program is built: has some op written the gradient yet?
+        self.grad_takes = 0         # consumers that have registered their contribution to the gradient so far (execution order)
 
     @property
     def M(self) -> int:
@@ -85,6 +86,7 @@ class Act:
             init = init or a.grad_init
             a = a.parent
         self.grad_init = True
+        self.grad_takes += 1
         return 1 if init else 0
 
 
@@ -179,6 +181,9 @@ class Engine:
         # (local batch 8: 39.97 -> 39.74 ms/step; batch 4 / 2: +0.25 / +0.15 ms -- the fused kernel holds 232 registers, two workgroups
         # per CU instead of three, which the few tiles of a small batch do not hide: on from batch 8)
         self.fuse_dw_wgrad = os.environ.get("DC_FUSE_DW_WGRAD", "1" if batch >= 8 else "0") != "0"
+        # the backward sums of a block-output BatchNorm (relu(bn(y) + residual)) taken by the next block's first depthwise data gradient,
+        # the last writer of that output's gradient (dc_dwconv_dgrad_wgrad_bnres) instead of a dc_bn_bwd_reduce pass over three tensors
+        self.fuse_bn_res = os.environ.get("DC_FUSE_BN_RES", "1") != "0"
         # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
         # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 40.31 -> 40.10 (round 3; 1 / 2 / 3 / 4 layers:
         # 40.31 / 40.28 / 40.10 / 40.18) -- the fp32 split slabs (256 KiB per workgroup whatever the batch) are a third of a 728-channel
@@ -449,6 +454,14 @@ class Engine:
                 mean_p, invstd_p = L.dptr(x.mean), L.dptr(x.invstd)
                 if self.fuse_dw_wgrad:
                     wrows = lib.dc_dwconv_dgrad_wgrad_rows(self.dt, Cc, stride, dil, N, H, W)
+            # the stored input is a block output relu(bn(y) + residual) and this data gradient completes d(x): that BatchNorm's sums ride along
+            res = getattr(x, "bn_res", None) if (not lazy and wrows > 0 and srows == 0 and self.fuse_bn_res) else None
+            if res is not None and getattr(x, "fused_bwd", 1) is None and x.parent is None and \
+                    lib.dc_dwconv_dgrad_wgrad_bnres_rows(self.dt, Cc, stride, dil, N, H, W) == wrows:
+                rslab2 = self._f32(2 * wrows * Cc)
+                x.fused_bwd = (rslab2, wrows, x.grad_takes)       # (this layer's take_grad_mode call above was the last one so far)
+            else:
+                res = None
             ready = [wname]
             if wrows > 0:
                 # the rows stay in this layer's own slab until the next dense weight-gradient launch folds them (dc_fold_slabs); the
@@ -460,6 +473,11 @@ class Engine:
                 L.call("dc_dwconv_wgrad", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, dy.ptr, dy.ld, ws, gw, ps, psh, prelu, self._st())
 
             def bwd():
+                if res is not None:
+                    L.call("dc_dwconv_dgrad_wgrad_bnres", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
+                           dx.ptr, dx.ld, src.ptr, src.ld, L.dptr(wslab), res["y"].ptr, res["y"].ld, L.dptr(res["mean"]), L.dptr(res["invstd"]),
+                           res["relu"], L.dptr(rslab2), self._st())
+                    return
                 if wrows > 0 and srows == 0:
                     L.call("dc_dwconv_dgrad_wgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
                            dx.ptr, dx.ld, src.ptr, src.ld, ps, psh, prelu, L.dptr(wslab), self._st())
@@ -530,6 +548,11 @@ class Engine:
             # BatchNorm's backward sums in its data-gradient epilogue (_conv(..., sole_consumer=True), the classifier head)
             o.bn_src = {"y": y, "scale": scale, "shift": shift, "mean": mean, "invstd": invstd, "relu": relu_i}
             o.fused_bwd = None
+        elif not lazy and residual is not None and out is None:
+            # a block output relu(bn(y) + residual): the depthwise conv that reads it first (the next block's) is the last writer of its
+            # gradient and may take this BatchNorm's backward sums on the way (_dw: dc_dwconv_dgrad_wgrad_bnres)
+            o.bn_res = {"y": y, "mean": mean, "invstd": invstd, "relu": relu_i}
+            o.fused_bwd = None
 
         self.fwd_train.append(fwd_train)
         self.fwd_eval.append(fwd_eval)
@@ -554,6 +577,8 @@ class Engine:
 
             # set by the consumer (a depthwise conv for a lazy output, a dense conv / the head for a stored one): its make_bwd ran first
             fused = lz.fused_bwd if lazy else getattr(o, "fused_bwd", None)
+            if fused is not None and len(fused) > 2:
+                assert o.grad_takes == fused[2], f"{bname}: the consumer that takes the sums must be the last writer of the gradient"
             rslab, rrows = (fused[0], fused[1]) if fused is not None else (bslab, brows)
 
             def bwd():

@@ -1028,6 +1028,54 @@ def test_depthwise_pipelined_kernel_matches_tiled(case):
         np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=3e-5, atol=3e-5 * float(v.abs().max()))
 
 
+@pytest.mark.parametrize("relu", [1, 0])
+@pytest.mark.parametrize("with_addend", [True, False])
+@pytest.mark.parametrize("case", [c for c in PIPE_CASES if c[2] == 1], ids=lambda c: c[0])
+def test_depthwise_dgrad_takes_the_residual_batchnorm_sums(case, with_addend, relu):
+    """dc_dwconv_dgrad_wgrad_bnres = dc_dwconv_dgrad_wgrad (same dx and weight-gradient rows, bit for bit) + the sums dc_bn_bwd_reduce
+    (mask from the stored output) would take from that dx, the BatchNorm input and the stored block output."""
+    _, Cc, dil, N, H, W = case
+    dt, lib = L.DC_BF16, L.load()
+    rows = lib.dc_dwconv_dgrad_wgrad_bnres_rows(dt, Cc, 1, dil, N, H, W)
+    assert rows > 0 and rows == lib.dc_dwconv_dgrad_wgrad_rows(dt, Cc, 1, dil, N, H, W)
+    xo = q(rnd(N, Cc, H, W, seed=1), torch.bfloat16)            # stored block output (its sign is the ReLU mask)
+    ybn = q(rnd(N, Cc, H, W, seed=7), torch.bfloat16)           # input of the BatchNorm that produced it
+    gy = q(rnd(N, Cc, H, W, seed=3), torch.bfloat16)
+    add = q(rnd(N, Cc, H, W, seed=4), torch.bfloat16)
+    wm = rnd(Cc, 1, 3, 3, seed=2, scale=1 / 3).to(dev())
+    wd = torch.empty(9 * Cc, device=dev())
+    L.call("dc_dwconv_pack_weights", Cc, vptr(wm), vptr(wd), S())
+    mean, invstd = rnd(Cc, seed=8, scale=0.2).to(dev()), (torch.rand(Cc) + 0.5).to(dev())
+    ld = (Cc + 31) // 32 * 32
+    _, xv = to_nhwc(xo, torch.bfloat16, ld=ld)
+    _, yv = to_nhwc(ybn, torch.bfloat16, ld=ld)
+    _, gyv = to_nhwc(gy, torch.bfloat16)
+    res = []
+    for fused in (True, False):
+        _, dx = to_nhwc(add, torch.bfloat16)                     # dx starts as the other consumers' contribution
+        ap, al = (vptr(dx), Cc) if with_addend else (None, 0)
+        wslab = torch.full((rows, 9, Cc), float("nan"), device=dev())
+        slab = torch.full((2, rows, Cc), float("nan"), device=dev())
+        if fused:
+            L.call("dc_dwconv_dgrad_wgrad_bnres", dt, Cc, 1, dil, N, H, W, vptr(gyv), Cc, vptr(wd), ap, al, vptr(dx), Cc, vptr(xv), ld, vptr(wslab),
+                   vptr(yv), ld, vptr(mean), vptr(invstd), relu, vptr(slab), S())
+            srows = rows
+        else:
+            L.call("dc_dwconv_dgrad_wgrad", dt, Cc, 1, dil, N, H, W, vptr(gyv), Cc, vptr(wd), ap, al, vptr(dx), Cc, vptr(xv), ld, None, None, 0,
+                   vptr(wslab), S())
+            M = N * H * W
+            srows = lib.dc_bn_stat_rows(M)
+            slab = torch.empty((2, srows, Cc), device=dev())
+            L.call("dc_bn_bwd_reduce", dt, M, Cc, vptr(dx), Cc, vptr(yv), ld, vptr(xv), ld, relu, vptr(mean), vptr(invstd), vptr(slab), None, None, S())
+        dgam, dbet = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
+        L.call("dc_bn_bwd_finalize", Cc, vptr(slab), srows, vptr(dgam), vptr(dbet), S())
+        torch.cuda.synchronize()
+        res.append((dx.clone(), wslab.clone(), dgam, dbet))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for u, v in zip(res[0][2:], res[1][2:]):
+        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=3e-5, atol=3e-5 * float(v.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", [c for c in DW_CASES if c[0] in ("s1", "d2", "thin64", "s2_728", "s2_64", "odd")], ids=lambda c: c[0])
 @pytest.mark.parametrize("relu", [1, 0])
