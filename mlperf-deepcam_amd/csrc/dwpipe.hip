@@ -40,6 +40,7 @@ struct PCfg {
   static constexpr int HH = P_TH + 2 * DIL, HW = P_TW + 2 * DIL, HP = HH * HW;
   static constexpr int HIT = (HP * P_CG + P_THREADS - 1) / P_THREADS;   // LDS-DMA instructions per wave for the halo tile
   static constexpr int HALO = HIT * P_THREADS * 16;
+  static constexpr int LASTW = (HP * P_CG - (HIT - 1) * P_THREADS + 63) / 64;   // waves with real slots in the last halo instruction (the others skip it)
   static constexpr int TILE = P_TH * P_TW * P_ROWB;                     // own-pixel tile (BatchNorm input / addend): 16 KiB, 2 instructions per wave
 };
 
@@ -117,6 +118,62 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
   const size_t goff = (size_t)(cg0 + g) * 8;
   const uintptr_t zp = (uintptr_t)a.zero_page;
 
+  auto issue = [&](int t, int stage) {
+    char* sb = smem + stage * S::BYTES;
+    const bool live = t < t1;
+    const int tt = live ? t : t0;
+    const int tx = tt % a.ntx;
+    const int r = tt / a.ntx;
+    const int ty = r % a.nty, n = r / a.nty;
+    const int y0 = ty * P_TH, x0 = tx * P_TW;
+    const bf16* base = a.in + (size_t)n * H * W * a.ldin + goff;
+#pragma unroll
+    for (int it = 0; it < K::HIT; ++it) {
+      if (it == K::HIT - 1 && wv >= K::LASTW) break;      // wave-uniform: this wave's slots of the last instruction lie past the halo tile
+      const int hp = (it * P_THREADS + tid) >> 4;
+      const int hy = hp / K::HW, hx = hp - hy * K::HW;
+      const int iy = y0 - DIL + hy, ix = x0 - DIL + hx;
+      const bool ok = live && gok && hp < K::HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const uintptr_t src = ok ? (uintptr_t)(base + ((size_t)iy * W + ix) * a.ldin) : zp;
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
+    }
+    if constexpr (S::Y) {
+      const bf16* yb = reinterpret_cast<const bf16*>(a.st.y) + (size_t)n * H * W * a.st.ldy + goff;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int p = (it * P_THREADS + tid) >> 4;
+        const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
+        const uintptr_t src = (live && gok) ? (uintptr_t)(yb + ((size_t)oy * W + ox) * a.st.ldy) : zp;
+        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + K::HALO + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
+      }
+    }
+    if constexpr (S::A) {
+      const bf16* ab = a.addend + (size_t)n * H * W * a.ldadd + goff;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int p = (it * P_THREADS + tid) >> 4;
+        const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
+        const uintptr_t src = (live && gok) ? (uintptr_t)(ab + ((size_t)oy * W + ox) * a.ldadd) : zp;
+        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + S::OFF_A + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
+      }
+    }
+    if constexpr (S::Y2) {
+      const bf16* yb = a.y2 + (size_t)n * H * W * a.ldy2 + goff;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int p = (it * P_THREADS + tid) >> 4;
+        const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
+        const uintptr_t src = (live && gok) ? (uintptr_t)(yb + ((size_t)oy * W + ox) * a.ldy2) : zp;
+        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + S::OFF_Y2 + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- prologue: tiles 0 .. NS-2 requested FIRST, so that the taps and coefficients below travel beside them (the compiler's wait for
+  // those loads then covers the first tiles as well: one exposed round trip per launch instead of two)
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(t0 + s, s);
+
   float wk[9][KH];
   load_taps<KH>(a.wp, ch0, a.C, FLIP, wk);
   BnAcc<KH> bn;
@@ -160,59 +217,7 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
     for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(xsc[e]), "+v"(xsh[e]));
   }
 
-  auto issue = [&](int t, int stage) {
-    char* sb = smem + stage * S::BYTES;
-    const bool live = t < t1;
-    const int tt = live ? t : t0;
-    const int tx = tt % a.ntx;
-    const int r = tt / a.ntx;
-    const int ty = r % a.nty, n = r / a.nty;
-    const int y0 = ty * P_TH, x0 = tx * P_TW;
-    const bf16* base = a.in + (size_t)n * H * W * a.ldin + goff;
-#pragma unroll
-    for (int it = 0; it < K::HIT; ++it) {
-      const int hp = (it * P_THREADS + tid) >> 4;
-      const int hy = hp / K::HW, hx = hp - hy * K::HW;
-      const int iy = y0 - DIL + hy, ix = x0 - DIL + hx;
-      const bool ok = live && gok && hp < K::HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const uintptr_t src = ok ? (uintptr_t)(base + ((size_t)iy * W + ix) * a.ldin) : zp;
-      __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
-    }
-    if constexpr (S::Y) {
-      const bf16* yb = reinterpret_cast<const bf16*>(a.st.y) + (size_t)n * H * W * a.st.ldy + goff;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int p = (it * P_THREADS + tid) >> 4;
-        const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
-        const uintptr_t src = (live && gok) ? (uintptr_t)(yb + ((size_t)oy * W + ox) * a.st.ldy) : zp;
-        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + K::HALO + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
-      }
-    }
-    if constexpr (S::A) {
-      const bf16* ab = a.addend + (size_t)n * H * W * a.ldadd + goff;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int p = (it * P_THREADS + tid) >> 4;
-        const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
-        const uintptr_t src = (live && gok) ? (uintptr_t)(ab + ((size_t)oy * W + ox) * a.ldadd) : zp;
-        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + S::OFF_A + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
-      }
-    }
-    if constexpr (S::Y2) {
-      const bf16* yb = a.y2 + (size_t)n * H * W * a.ldy2 + goff;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int p = (it * P_THREADS + tid) >> 4;
-        const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
-        const uintptr_t src = (live && gok) ? (uintptr_t)(yb + ((size_t)oy * W + ox) * a.ldy2) : zp;
-        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + S::OFF_Y2 + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
-      }
-    }
-  };
 
-  // ---- prologue: tiles 0 .. NS-2 requested
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s) issue(t0 + s, s);
 
 #ifdef DWP_STAMPS
   unsigned long long tw = 0, ti = 0, tx_ = 0, tc = 0, tprev = __builtin_amdgcn_s_memtime();
@@ -223,10 +228,17 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
   int stage = 0;
   for (int i = 0; i < nt; ++i) {
     // tile i has landed once all but the youngest [stores of the last min(i, NS-1) tiles + DMAs of tiles i+1 .. i+NS-2] are done
-    if (i >= NS - 1) wait_vm<(NS - 1) * S::STORES + (NS - 2) * S::DMAS>();
-    else if (i == 0) wait_vm<(NS - 2) * S::DMAS>();
-    else if (i == 1) wait_vm<S::STORES + (NS - 2) * S::DMAS>();
-    else wait_vm<2 * S::STORES + (NS - 2) * S::DMAS>();
+    if (wv < K::LASTW) {
+      if (i >= NS - 1) wait_vm<(NS - 1) * S::STORES + (NS - 2) * S::DMAS>();
+      else if (i == 0) wait_vm<(NS - 2) * S::DMAS>();
+      else if (i == 1) wait_vm<S::STORES + (NS - 2) * S::DMAS>();
+      else wait_vm<2 * S::STORES + (NS - 2) * S::DMAS>();
+    } else {          // one LDS-DMA fewer per tile
+      if (i >= NS - 1) wait_vm<(NS - 1) * S::STORES + (NS - 2) * (S::DMAS - 1)>();
+      else if (i == 0) wait_vm<(NS - 2) * (S::DMAS - 1)>();
+      else if (i == 1) wait_vm<S::STORES + (NS - 2) * (S::DMAS - 1)>();
+      else wait_vm<2 * S::STORES + (NS - 2) * (S::DMAS - 1)>();
+    }
     __builtin_amdgcn_s_barrier();     // everybody's pieces of tile i have landed; everybody is done with the stage tile i-1 used
     STAMP(tw);
     {
@@ -245,6 +257,7 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
       // v = act(x * scale + shift) in place, once per staged element; the zero padding (out of the image) stays zero
 #pragma unroll
       for (int it = 0; it < K::HIT; ++it) {
+        if (it == K::HIT - 1 && wv >= K::LASTW) break;
         const int hp = (it * P_THREADS + tid) >> 4;
         const int hy = hp / K::HW, hx = hp - hy * K::HW;
         const int iy = y0 - DIL + hy, ix = x0 - DIL + hx;

@@ -455,6 +455,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 static int g_wgrad_mode = 1;               // 1 = LDS-DMA 3-stage kernel, 0 = register-staged kernel
 static int g_thin_wgrad = 1;               // one-pass kernel for the two thin stem convolutions (thinconv.hip)
+static int g_wgrad256_pad = 115;           // tuning switch "wgrad256_pad"
 static int g_wgrad256 = 1;                 // 0: 128-tile kernel only, 1: planner, 2: 256-tile kernel wherever eligible (bf16)
 static int g_wgrad_target_blocks = 768;    // resident capacity: 256 CUs x 3 workgroups (48 KiB LDS, 146 registers)
 
@@ -502,6 +503,11 @@ extern "C" int dc_wgrad_set_slots(int n) {
   return 0;
 }
 
+extern "C" int dc_wgrad_set_pad(int pct) {
+  g_wgrad256_pad = pct < 100 ? 100 : pct;
+  return 0;
+}
+
 extern "C" int dc_wgrad_set_thin(int m) {
   g_thin_wgrad = m ? 1 : 0;
   return 0;
@@ -513,7 +519,7 @@ static bool wgrad256_wins(const GatherGeom& g) {
   if (g_wgrad256 == 0) return false;
   const long pad256 = (long)cdiv(g.Cin, 256) * 256 * cdiv(g.Cout, 256) * 256;
   const long pad128 = (long)cdiv(g.Cin, 128) * 128 * cdiv(g.Cout, 128) * 128;
-  return pad256 * 100 <= pad128 * 115;   // at most 15 % more padded work than the small tile
+  return pad256 * 100 <= pad128 * g_wgrad256_pad;   // at most (g_wgrad256_pad - 100) % more padded work than the small tile
 }
 
 static int launch_wgrad_reduce(const float* slab, float* grad_w, int splits, const GatherGeom& g, int transposed, hipStream_t st) {

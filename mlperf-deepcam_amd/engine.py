@@ -169,18 +169,19 @@ class Engine:
         self.mask_from_y = os.environ.get("DC_MASK_FROM_Y", "1") != "0"
         # BatchNorm backward sums taken in the epilogue of the consuming dense conv's data gradient (dc_conv_dgrad_bnstats /
         # dc_head_bwd_bnstats) instead of a dc_bn_bwd_reduce pass over the gradient and the BatchNorm input
-        # (time-neutral at local batch 8 and 4, where it saves 2.8 GB of reads per step; +0.08 ms at batch 2: off there)
-        self.fuse_bn_conv = os.environ.get("DC_FUSE_BN_CONV", "1" if batch >= 4 else "0") != "0"
-        self.fuse_bn_head = os.environ.get("DC_FUSE_BN_HEAD", "1" if batch >= 4 else "0") != "0"
+        # (time-neutral at local batch 8 and 4, where it saves 2.8 GB of reads per step; round 4, one job at local batch 2: 13.99 -> 13.95 ms)
+        self.fuse_bn_conv = os.environ.get("DC_FUSE_BN_CONV", "1") != "0"
+        self.fuse_bn_head = os.environ.get("DC_FUSE_BN_HEAD", "1") != "0"
         # the BatchNorm + ReLU in front of the classifier head (upsample.deconv3.1/.2) is applied by the head itself while it loads
         # (dc_head_fwd_loss_bnin / dc_head_bwd_bnin): the 256-channel 384 x 576 activation is never stored (at local batch 8: a 0.35 ms
         # dc_bn_apply pass and 1.8 GB of traffic less per step).  bf16 only (the fused head kernel).
         self.fuse_bn_into_head = dtype == torch.bfloat16 and os.environ.get("DC_FUSE_BN_INTO_HEAD", "1") != "0"
         # depthwise weight gradient taken inside the depthwise data gradient (dc_dwconv_dgrad_bnstats_wgrad) where the layer's input is a
-        # never-stored BatchNorm output: the separate dc_dwconv_wgrad launch (and its second read of dy and y) disappears
-        # (local batch 8: 39.97 -> 39.74 ms/step; batch 4 / 2: +0.25 / +0.15 ms -- the fused kernel holds 232 registers, two workgroups
-        # per CU instead of three, which the few tiles of a small batch do not hide: on from batch 8)
-        self.fuse_dw_wgrad = os.environ.get("DC_FUSE_DW_WGRAD", "1" if batch >= 8 else "0") != "0"
+        # never-stored BatchNorm output: the separate dc_dwconv_wgrad launch (and its second read of dy and y) disappears.  On the tiled
+        # kernel the fusion held 232 registers (two workgroups per CU instead of three) and paid from local batch 8 only; on the persistent
+        # pipelined kernel (csrc/dwpipe.hip, one workgroup per CU by design) it pays everywhere: one job in round 4, local batch 2
+        # 14.36 -> 13.99 ms, batch 4 21.92 -> 21.42 ms
+        self.fuse_dw_wgrad = os.environ.get("DC_FUSE_DW_WGRAD", "1") != "0"
         # the backward sums of a block-output BatchNorm (relu(bn(y) + residual)) taken by the next block's first depthwise data gradient,
         # the last writer of that output's gradient (dc_dwconv_dgrad_wgrad_bnres) instead of a dc_bn_bwd_reduce pass over three tensors
         self.fuse_bn_res = os.environ.get("DC_FUSE_BN_RES", "1") != "0"
