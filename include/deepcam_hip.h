@@ -65,27 +65,6 @@ typedef struct {
   int cout;
 } dc_conv_desc;
 
-/* dc_bn_finalize's arguments as one block, for the calls that run the finalize step INSIDE the kernel that consumes scale / shift
- * (dc_dwconv_fwd_bnfin): at local batch 8 the 77 finalize launches of a forward pass cost the chain 1.5 ms, mostly dispatch boundaries. */
-typedef struct dc_bn_fin {
-  long count;               /* values per channel (N*H*W) */
-  const float* slab;        /* [2][rows][C] */
-  int rows;
-  const float* gamma;
-  const float* beta;
-  float* running_mean;      /* may be NULL */
-  float* running_var;
-  int64_t* num_batches_tracked;
-  float momentum, eps;
-  float* scale;
-  float* shift;
-  float* save_mean;         /* may be NULL */
-  float* save_invstd;
-  unsigned* sync;           /* dc_dwconv_fwd_bnfin_sync_words() words owned by this layer, zeroed once; the LAST word counts the
-                             * workgroups whose wait for the leaders ran out (they then compute their coefficients themselves: slower,
-                             * same bits) -- zero in a healthy run */
-  unsigned epoch;           /* how many in-kernel finalize launches of this layer have been issued before this one (0, 1, 2, ...) */
-} dc_bn_fin;
 
 /* Output extent of the forward op for an Hi x Wi input. */
 int dc_conv_out_hw(const dc_conv_desc* d, int Hi, int Wi, int* Ho, int* Wo);
@@ -191,13 +170,6 @@ int dc_dwconv_pack_weights(int C, const float* master, float* packed, void* stre
 int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
                   const float* wp, void* y, int ldy, const float* pscale, const float* pshift, int prelu, void* stream);
 /* dx = dw_backward_data(dy) [+ addend]  (addend: same shape as dx, e.g. the residual branch's gradient) */
-/* dc_bn_finalize(bn) + dc_dwconv_fwd(x, bn->scale, bn->shift, prelu) in one launch (SeparableConv2d_same's depthwise conv on the
- * BatchNorm + ReLU in front of it, deeplab_xception.py:62-66 after :105-117): the first workgroups of the depthwise grid run the
- * finalize blocks and publish them, the others wait for them while their halo tiles load.  Same bits as the two calls.  Shapes the
- * tiled stride-1 kernels do not serve (sync_words == 0) run as the two calls. */
-int dc_dwconv_fwd_bnfin_sync_words(int dtype, int C, int stride, int dil);
-int dc_dwconv_fwd_bnfin(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx, const float* w,
-                        void* y, int ldy, const dc_bn_fin* bn, int prelu, void* stream);
 int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
                     const float* wp, const void* addend, int ldadd, void* dx, int lddx, void* stream);
 /* Data gradient that also takes the backward statistics of the BatchNorm(+ReLU) whose (never materialised) output fed this

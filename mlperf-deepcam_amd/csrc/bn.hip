@@ -347,7 +347,6 @@ extern "C" int dc_bn_finalize(int C, long count, const float* slab, int rows, co
   a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
   a.nbt = reinterpret_cast<long long*>(num_batches_tracked); a.momentum = momentum; a.eps = eps;
   a.scale = scale; a.shift = shift; a.save_mean = save_mean; a.save_invstd = save_invstd;
-  a.sync = nullptr; a.epoch = 0;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, (hipStream_t)stream, a);
   DC_CHECK_LAUNCH();
   return 0;

@@ -6,7 +6,6 @@
 
 #include "common.h"
 #include "dwtile.h"
-#include "bn_fin.h"
 #include "dwtile_common.h"
 
 namespace dc {
@@ -440,9 +439,8 @@ static int launch_dw(const void* in, int ldin, const float* w, const void* adden
 
 static int launch_dw_s1(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
                         void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale = nullptr,
-                        const float* pshift = nullptr, int prelu = 0, const BnFinArgs* fin = nullptr) {
-  if (g_dw_tile) return launch_dw_tile(dtype, dil, flip, in, ldin, wp, addend, ldadd, out, ldout, N, H, W, C, st, pscale, pshift, prelu, nullptr, fin);
-  DC_REQUIRE(fin == nullptr, "dc_dwconv_fwd_bnfin: the in-kernel finalize belongs to the tiled kernels");
+                        const float* pshift = nullptr, int prelu = 0) {
+  if (g_dw_tile) return launch_dw_tile(dtype, dil, flip, in, ldin, wp, addend, ldadd, out, ldout, N, H, W, C, st, pscale, pshift, prelu, nullptr);
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   const long total = (long)N * H * ((W + DW_PX - 1) / DW_PX) * (C / kpv);
   DC_REQUIRE(total < (1L << 31), "dc_dwconv: tensor too large for the stride-1 fast path");
@@ -472,7 +470,6 @@ extern "C" int dc_dw_set_option(const char* name, int value) {
   if (strcmp(name, "dw_wgrad_tpb") == 0) { dw_tile_set_tpb(value); return 0; }
   if (strcmp(name, "dw_cg") == 0) { dw_tile_set_cg(value); return 0; }
   if (strcmp(name, "dw_pipe") == 0) { dw_pipe_set(value); return 0; }
-  if (strcmp(name, "dw_fin_fallback") == 0) { dw_tile_set_fin_fallback(value); return 0; }
   return -1;
 }
 
@@ -499,41 +496,6 @@ extern "C" int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int H
     return launch_dw_tile_s2(dtype, 0, N, Hi, Wi, C, x, ldx, w, nullptr, 0, y, ldy, nullptr, nullptr, st, pscale, pshift, prelu);
   return dtype == DC_BF16 ? launch_dw<bf16, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st, pscale, pshift, prelu)
                           : launch_dw<float, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st, pscale, pshift, prelu);
-}
-
-extern "C" int dc_bn_finalize(int C, long count, const float* slab, int rows, const float* gamma, const float* beta,
-                              float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                              float eps, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
-
-// Words of dc_bn_fin::sync a depthwise layer of C channels needs (0: this shape is not served in-kernel; dc_dwconv_fwd_bnfin then
-// launches dc_bn_finalize itself and ignores sync / epoch)
-extern "C" int dc_dwconv_fwd_bnfin_sync_words(int dtype, int C, int stride, int dil) {
-  if (!g_dw_tile || stride != 1 || (dil != 1 && dil != 2) || (dtype != DC_BF16 && dtype != DC_F32) || C <= 0) return 0;
-  return dw_tile_channel_blocks(dtype, C) + 1;      // one counter per channel block of the grid + the count of waits that ran out
-}
-
-// dc_bn_finalize(bn) followed by dc_dwconv_fwd(x, pscale = bn->scale, pshift = bn->shift, prelu), in ONE launch where the tiled stride-1
-// kernels serve the shape (bn_fin.h): same outputs and same BatchNorm vectors bit for bit.
-extern "C" int dc_dwconv_fwd_bnfin(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
-                                   const float* w, void* y, int ldy, const dc_bn_fin* bn, int prelu, void* stream) {
-  DC_REQUIRE(bn != nullptr && bn->slab && bn->gamma && bn->beta && bn->scale && bn->shift && bn->rows > 0, "dc_dwconv_fwd_bnfin: bad BatchNorm block");
-  if (bn->count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
-  if (dc_dwconv_fwd_bnfin_sync_words(dtype, C, stride, dil) == 0 || bn->sync == nullptr) {
-    if (int e = dc_bn_finalize(C, bn->count, bn->slab, bn->rows, bn->gamma, bn->beta, bn->running_mean, bn->running_var, bn->num_batches_tracked,
-                               bn->momentum, bn->eps, bn->scale, bn->shift, bn->save_mean, bn->save_invstd, stream)) return e;
-    return dc_dwconv_fwd(dtype, C, stride, dil, N, Hi, Wi, x, ldx, w, y, ldy, bn->scale, bn->shift, prelu, stream);
-  }
-  if (int e = dw_check(dtype, C, stride, dil, N, Hi, Wi)) return e;
-  if (int e = dc_check_view(x, ldx, C, dtype, "dc_dwconv_fwd_bnfin x")) return e;
-  if (int e = dc_check_view(y, ldy, C, dtype, "dc_dwconv_fwd_bnfin y")) return e;
-  DC_REQUIRE(w != nullptr, "dc_dwconv_fwd_bnfin: null weights");
-  BnFinArgs a;
-  a.slab = bn->slab; a.rows = bn->rows; a.C = C; a.inv_count = 1.0 / (double)bn->count; a.unbias = (double)bn->count / (double)(bn->count - 1);
-  a.gamma = bn->gamma; a.beta = bn->beta; a.running_mean = bn->running_mean; a.running_var = bn->running_var;
-  a.nbt = reinterpret_cast<long long*>(bn->num_batches_tracked); a.momentum = bn->momentum; a.eps = bn->eps;
-  a.scale = bn->scale; a.shift = bn->shift; a.save_mean = bn->save_mean; a.save_invstd = bn->save_invstd;
-  a.sync = bn->sync; a.epoch = bn->epoch;
-  return launch_dw_s1(dtype, dil, false, x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, C, (hipStream_t)stream, bn->scale, bn->shift, prelu, &a);
 }
 
 extern "C" int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,

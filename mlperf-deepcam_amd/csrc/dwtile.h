@@ -16,15 +16,12 @@ struct DwResStats {
   int relu;
   float* slab;
 };
-struct BnFinArgs;   // bn_fin.h
 
 constexpr int DWT_MAX_ROWS = 2048;   // most partial rows the weight-gradient slab may hold
 
 int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
                    void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale = nullptr,
-                   const float* pshift = nullptr, int prelu = 0, const DwBnStats* bnstats = nullptr, const BnFinArgs* fin = nullptr);
-int dw_tile_channel_blocks(int dtype, int C);
-void dw_tile_set_fin_fallback(int v);
+                   const float* pshift = nullptr, int prelu = 0, const DwBnStats* bnstats = nullptr);
 int dw_tile_rows(int dtype, int C, int N, int H, int W);   // pixel tiles of the stride-1 kernels = slab rows of the fused BN statistics
 int launch_dw_tile_wgrad(int dtype, int dil, const void* x, int ldx, const void* dy, int lddy, float* slab, float* grad_w, int N,
                          int H, int W, int C, hipStream_t st, const float* pscale = nullptr, const float* pshift = nullptr, int prelu = 0);

@@ -15,7 +15,6 @@
 #include "common.h"
 #include "dwtile.h"
 #include "dwtile_common.h"
-#include "bn_fin.h"
 
 namespace dc {
 
@@ -69,8 +68,7 @@ template <typename T, int DIL, bool FLIP, int CG, bool WG = false>
 __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int ldin, const float* __restrict__ wp,
                                                   const T* __restrict__ addend, int ldadd, T* __restrict__ out, int ldout, int H, int W,
                                                   int C, int ncgb, int ntx, int nty, const float* __restrict__ pscale,
-                                                  const float* __restrict__ pshift, int prelu, const DwBnStats st, const BnFinArgs fin,
-                                                  int fin_fallback) {
+                                                  const float* __restrict__ pshift, int prelu, const DwBnStats st) {
   typedef TileCfg<DIL, CG> K;
   constexpr int KPV = Elem<T>::kPerVec, KH = KPV / 2;
   constexpr int WC = DT_PX + 2 * DIL;
@@ -84,17 +82,6 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
   const int ty = r % nty, n = r / nty;
   const int ngroups = C / KPV;
   const int cg0 = cgb * CG, y0 = ty * K::TH, x0 = tx * K::TW;
-  // forward on a BatchNorm output whose finalize step has not run (bn_fin.h): the first workgroups of every channel block do it, before
-  // their halo tile is requested (the LDS is their scratch); pscale / pshift are fin.scale / fin.shift
-  const bool do_fin = !FLIP && fin.slab != nullptr;
-  const int fin_lo = cg0 * KPV, fin_hi = min(C, (cg0 + CG) * KPV);
-  if (do_fin) {
-    const int nlead = bn_fin_leaders(ncgb, CG * KPV, (int)gridDim.x);
-    if ((int)blockIdx.x < nlead) {
-      static_assert(K::LDS_BYTES >= (int)sizeof(double) * 2 * FIN_RL * FIN_CH, "the tile buffer doubles as the finalize scratch");
-      bn_fin_lead(fin, ncgb, CG * KPV, (int)blockIdx.x, nlead, *reinterpret_cast<double (*)[2][FIN_RL][FIN_CH]>(smem));
-    }
-  }
   stage_halo<T, DIL, CG>(smem, in, ldin, n, y0, x0, cg0, ngroups, H, W);
 
   const int h = threadIdx.x % (2 * CG), sl = threadIdx.x / (2 * CG);   // half-group, strip lane
@@ -102,10 +89,9 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
   const int ch0 = cok ? cg0 * KPV + h * KH : 0;                          // first of this thread's channels
   float wk[9][KH];
   load_taps<KH>(wp, ch0, C, FLIP, wk);
-  if (do_fin) bn_fin_wait(fin, ncgb, cgb, fin_lo, fin_hi, fin_fallback);   // the halo tile travels meanwhile
   __syncthreads();   // vmcnt(0) + barrier: the whole halo tile has landed
   if (!FLIP && pscale != nullptr) {   // fused BatchNorm(+ReLU) of the producer, applied once per staged element
-    bn_transform_tile<T, K::HH, K::HW, CG>(smem, y0 - DIL, x0 - DIL, H, W, pscale, pshift, prelu, cg0, ngroups, do_fin);
+    bn_transform_tile<T, K::HH, K::HW, CG>(smem, y0 - DIL, x0 - DIL, H, W, pscale, pshift, prelu, cg0, ngroups);
     __syncthreads();
   }
   const bool stats = FLIP && st.slab != nullptr;
@@ -395,16 +381,9 @@ int dw_tile_reduce(const float* slab, float* grad_w, int rows, int C, hipStream_
 static int g_dw_tpb = 0;   // tiles per workgroup of the weight gradient; 0 = planner
 void dw_tile_set_tpb(int v) { g_dw_tpb = v < 0 ? 0 : v; }
 
-static int g_dw_fin_fallback = 0;   // test switch "dw_fin_fallback": every workgroup computes its coefficients itself (the path of a wait that ran out)
-void dw_tile_set_fin_fallback(int v) { g_dw_fin_fallback = v ? 1 : 0; }
 static int g_dw_cg = 0;   // 0: by channel count; 8 / 16 / 32: force the channel-group width of a workgroup (tuning switch)
 void dw_tile_set_cg(int v) { g_dw_cg = (v == 8 || v == 16 || v == 32) ? v : 0; }
 static int pick_cg(int ngroups) { return g_dw_cg ? g_dw_cg : ngroups <= 8 ? 8 : ngroups <= 16 ? 16 : 32; }
-// channel blocks of the tiled kernels' grid (= words of BnFinArgs::sync a layer needs)
-int dw_tile_channel_blocks(int dtype, int C) {
-  const int ngroups = C / (dtype == DC_BF16 ? 8 : 4);
-  return cdiv(ngroups, pick_cg(ngroups));
-}
 
 struct TileGrid {
   int cg, ncgb, ntx, nty, ntiles;
@@ -446,53 +425,46 @@ size_t dw_tile_wgrad_workspace(int C, int N, int H, int W) {
 
 template <typename T, int DIL, bool FLIP, int CG>
 static void launch_fwd1(const TileGrid& t, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out,
-                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats& bs,
-                        const BnFinArgs& fin, int fin_fallback) {
+                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats& bs) {
   if constexpr (FLIP) {
     if (bs.wslab != nullptr) {          // data gradient + BatchNorm sums + this layer's weight-gradient rows
       constexpr int FOLD = TileCfg<DIL, CG>::NSL * 9 * CG * Elem<T>::kPerVec * (int)sizeof(float);
       constexpr int LDSW = TileCfg<DIL, CG>::LDS_BYTES > FOLD ? TileCfg<DIL, CG>::LDS_BYTES : FOLD;
       DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, true, CG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW));
       hipLaunchKernelGGL((dwt_kernel<T, DIL, true, CG, true>), dim3(t.ntiles * t.ncgb), dim3(256), LDSW, st, (const T*)in, ldin, wp,
-                         (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs, fin, fin_fallback);
+                         (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs);
       return;
     }
   }
   constexpr int LDS = TileCfg<DIL, CG>::LDS_BYTES;
   DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, FLIP, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   hipLaunchKernelGGL((dwt_kernel<T, DIL, FLIP, CG>), dim3(t.ntiles * t.ncgb), dim3(256), LDS, st, (const T*)in, ldin, wp,
-                     (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs, fin, fin_fallback);
+                     (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs);
 }
 
 template <typename T, int DIL, bool FLIP>
 static void launch_fwd2(const TileGrid& t, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out,
-                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats& bs,
-                        const BnFinArgs& fin, int fin_fallback) {
-  if (t.cg == 32) launch_fwd1<T, DIL, FLIP, 32>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs, fin, fin_fallback);
-  else if (t.cg == 16) launch_fwd1<T, DIL, FLIP, 16>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs, fin, fin_fallback);
-  else launch_fwd1<T, DIL, FLIP, 8>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs, fin, fin_fallback);
+                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats& bs) {
+  if (t.cg == 32) launch_fwd1<T, DIL, FLIP, 32>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs);
+  else if (t.cg == 16) launch_fwd1<T, DIL, FLIP, 16>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs);
+  else launch_fwd1<T, DIL, FLIP, 8>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs);
 }
 
 int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
                    void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu,
-                   const DwBnStats* bnstats, const BnFinArgs* finp) {
+                   const DwBnStats* bnstats) {
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   // the persistent pipelined kernel serves the data gradients (52.0 -> 41.5 us with BatchNorm sums and weight gradient on the 728-channel
   // layers at local batch 8); the forward pass stays here unless option "dw_pipe" = 2 (23.4 vs 24.1 us plain, 34.5 vs 31.7 us with the
   // BatchNorm applied on load: its in-place transform pass costs eight waves more than it costs three co-resident workgroups)
-  if (finp == nullptr && (flip || dw_pipe_forward()) && (long)N * H * W < (1L << 31) && dw_pipe_rows(dtype, C, dil, N, H, W) > 0)
+  if ((flip || dw_pipe_forward()) && (long)N * H * W < (1L << 31) && dw_pipe_rows(dtype, C, dil, N, H, W) > 0)
     return launch_dw_pipe(dil, flip, in, ldin, wp, addend, ldadd, out, ldout, N, H, W, C, st, pscale, pshift, prelu, bnstats);
   const TileGrid t = tile_grid(C / kpv, N, H, W);
   DC_REQUIRE((long)t.ntiles * t.ncgb < (1L << 31) && (long)N * H * W < (1L << 31), "dc_dwconv: tensor too large for the tiled path");
   DwBnStats bs;
   if (bnstats != nullptr) bs = *bnstats; else { bs.slab = nullptr; bs.y = nullptr; bs.ldy = 0; bs.mean = bs.invstd = bs.mscale = bs.mshift = nullptr; bs.relu = 0; bs.rows = 0; bs.wslab = nullptr; }
   if (bs.slab != nullptr) bs.rows = t.ntiles;
-  BnFinArgs fin{};          // slab == nullptr: off
-  if (finp != nullptr) fin = *finp;
-  DC_REQUIRE(fin.slab == nullptr || (!flip && fin.sync != nullptr && pscale == fin.scale && pshift == fin.shift),
-             "dc_dwconv_fwd_bnfin: the finalize hand-over belongs to the forward kernel and writes the scale / shift it reads");
-  const int fin_fallback = g_dw_fin_fallback;
-#define DWT(TT, D, F) launch_fwd2<TT, D, F>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs, fin, fin_fallback)
+#define DWT(TT, D, F) launch_fwd2<TT, D, F>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs)
   if (dtype == DC_BF16) {
     if (dil == 1) { if (flip) DWT(bf16, 1, true); else DWT(bf16, 1, false); }
     else          { if (flip) DWT(bf16, 2, true); else DWT(bf16, 2, false); }

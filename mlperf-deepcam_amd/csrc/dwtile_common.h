@@ -136,26 +136,17 @@ __device__ inline void bn_acc_store(float* red, const float (&a)[KH], const floa
 // where the register-window kernels recomputed it per window position); a thread's channel group is fixed, so its 8 (4)
 // coefficients live in registers.  Call between two workgroup barriers.
 template <typename T, int HH, int HW, int CG>
-// coherent: the coefficients were written by other workgroups of THIS kernel (bn_fin.h) and are read at agent scope
 __device__ inline void bn_transform_tile(char* smem, int iy0, int ix0, int H, int W, const float* __restrict__ pscale,
-                                         const float* __restrict__ pshift, int prelu, int cg0, int ngroups, bool coherent = false) {
+                                         const float* __restrict__ pshift, int prelu, int cg0, int ngroups) {
   constexpr int KPV = Elem<T>::kPerVec;
   constexpr int HP = HH * HW, ITER = (HP * CG + 255) / 256;
   const int tid = threadIdx.x, g = tid % CG;
   if (cg0 + g >= ngroups) return;
   float sc[KPV], sh[KPV];
-  if (coherent) {
 #pragma unroll
-    for (int e = 0; e < KPV; ++e) {
-      sc[e] = __hip_atomic_load(pscale + (cg0 + g) * KPV + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sh[e] = __hip_atomic_load(pshift + (cg0 + g) * KPV + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < KPV; ++e) {
-      sc[e] = pscale[(cg0 + g) * KPV + e];
-      sh[e] = pshift[(cg0 + g) * KPV + e];
-    }
+  for (int e = 0; e < KPV; ++e) {
+    sc[e] = pscale[(cg0 + g) * KPV + e];
+    sh[e] = pshift[(cg0 + g) * KPV + e];
   }
 #pragma unroll 2
   for (int it = 0; it < ITER; ++it) {

@@ -56,9 +56,6 @@ int igemm256_phase_fast_enabled();
 // igemm256p.hip: persistent form (one workgroup per CU walks its tiles; the ring never drains between tiles)
 bool igemm256p_eligible(const IgemmParams& p);
 int launch_igemm256p(const IgemmParams& p, int workgroups, hipStream_t st);
-// igemm256k.hip: the persistent form with 128-byte K rows (stride-1 geometries)
-bool igemm256k_eligible(const IgemmParams& p);
-int launch_igemm256k(const IgemmParams& p, int workgroups, hipStream_t st);
 // workgroups the 256-tile kernel would launch for this problem
 inline long igemm256_tiles(const IgemmParams& p) {
   return (long)((p.g.Cout + 255) / 256) * ((p.M - p.m_beg + 255) / 256) * p.g.os * p.g.os * (p.ngroup > 1 ? p.ngroup : 1);

@@ -529,9 +529,6 @@ static int launch_igemm(const IgemmParams& p, hipStream_t st) {
 // (>= 64 steps of 32), about the same at 20-60 steps (the 728-channel layers) and 1.1-1.2 when it is short (its prologue and
 // 132 KiB epilogue are not hidden by a co-resident workgroup) -- for 4/3 of the work per round.  When both fit one round the
 // small tile (finer tail, three workgroups hiding each other's latencies) keeps the layer unless the K loop is long.
-static int g_igemm_mix = 0;        // mixed 256-tile / 128-tile plan (off: bit-equal and +6 % alone on 1536 -> 2048, but +1.5 ms per step beside the weight-gradient stream)
-static int g_mix_cus = 256;        // workgroup slots of a 256-tile round (tuning / test switch: a small value cuts small problems)
-static int g_mix_tail_pct = 40;    // largest fill of the last round (percent) that is handed to the 128-tile kernel
 static int g_rel256 = 0;   // 0: model below; otherwise cost of a 256-tile round in percent of a 128-tile round (tuning switch)
 // Pointwise layers on the one-wave-per-SIMD kernel (igemm384.hip).  0: never, 1: where the round model below expects it to win,
 // 2 / 3: whenever eligible with 256- / 128-pixel tiles (tests and A/B runs).  Costs are in rounds of 256 x 256 tiles: a
@@ -539,7 +536,6 @@ static int g_rel256 = 0;   // 0: model below; otherwise cost of a 256-tile round
 // the K depths in question (see igemm256_wins).  The layer must also fill most of the chip with its one workgroup per CU.
 static int g_igemm256p = 1;          // persistent 256-tile kernel for multi-round launches (A/B switch "igemm256p")
 static int g_igemm256p_wgs = 0;      // its workgroups ("igemm256p_wgs"); 0: fewest that keep the number of rounds
-static int g_igemm256k = 0;          // 128-byte-row form of the persistent kernel for stride-1 geometries ("igemm256k"): measured 0 - 3 % slower, off
 static int g_igemm256p_min = 257;    // fewest tiles it is used for ("igemm256p_min")
 static int g_pw384 = 1;
 static int g_pw384_k64 = 1;         // 256 x 384 tiles with 128-byte K rows where the planner picks that tile ("pw384_k64")
@@ -623,30 +619,7 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   }
   if (d->dtype == DC_BF16 && !out32 && g_igemm256 != 0) {
     if (g_igemm256 == 2 || igemm256_wins(p)) {
-      // Mixed plan.  The 256-tile kernel holds one workgroup per CU, so a layer of r.f rounds pays for r+1 (the 728 -> 728
-      // pointwise layers at B = 8: 324 tiles on 256 CUs).  When the last round is mostly empty the pixel range is cut at a
-      // 256-pixel boundary: whole rounds of 256-tiles, then the rest on the 128-tile kernel, whose workgroups are a quarter
-      // of the work, three to a CU, and all resident at once.  Same arithmetic per output element in both kernels (bit-equal
-      // outputs, scripts/gemm256_bench.py), and both write the statistics slab by 128-pixel row, so the cut is invisible.
-      const long ntn = cdiv(p.g.Cout, 256), phases = (long)p.g.os * p.g.os;
-      const long t256 = igemm256_tiles(p);
-      const long full = t256 / g_mix_cus, tail = t256 % g_mix_cus;
-      // (single-tap layers only: the two kernels add the taps of a multi-tap layer in different orders, so a cut would show in the bits)
-      if (g_igemm_mix && p.g.ntaps == 1 && full >= 1 && tail > 0 && tail * 100 <= (long)g_mix_cus * g_mix_tail_pct) {
-        const long rows_a = full * g_mix_cus / (ntn * phases);          // 256-pixel row tiles that fit the whole rounds
-        const long m_cut = rows_a * 256;
-        const long small = (long)cdiv(p.g.Cout, BN) * cdiv(M - m_cut, BM) * phases;
-        if (rows_a >= 1 && m_cut < M && small <= 3L * g_mix_cus) {
-          IgemmParams a = p, b = p;
-          a.M = (int)m_cut;
-          b.m_beg = (int)m_cut;
-          if (int e = launch_igemm256(a, st)) return e;
-          return launch_igemm<bf16, false>(b, st);
-        }
-      }
       // several rounds of tiles: the persistent form keeps the operand ring full across tiles (igemm256p.hip)
-      // ... with 128-byte K rows where the geometry allows (igemm256k.hip)
-      if (g_igemm256k && g_igemm256p && bst == nullptr && igemm256k_eligible(p) && igemm256_tiles(p) >= (long)g_igemm256p_min) return launch_igemm256k(p, g_igemm256p_wgs, st);
       if (g_igemm256p && bst == nullptr && igemm256p_eligible(p) && igemm256_tiles(p) >= (long)g_igemm256p_min) return launch_igemm256p(p, g_igemm256p_wgs, st);
       return launch_igemm256(p, st);
     }
@@ -903,21 +876,13 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm256p") == 0) { g_igemm256p = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256p_wgs") == 0) { g_igemm256p_wgs = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256p_min") == 0) { g_igemm256p_min = value; return 0; }
-  if (name != nullptr && strcmp(name, "igemm256k") == 0) { g_igemm256k = value; return 0; }
   if (name != nullptr && strcmp(name, "pw384_k64") == 0) { g_pw384_k64 = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_tile2d") == 0) { igemm256_set_tile2d(value); return 0; }
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }
-  if (name != nullptr && strcmp(name, "igemm_mix") == 0) { g_igemm_mix = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "pack_blocks") == 0 && value > 0) { g_pack_blocks = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_epi") == 0) { igemm256_set_epilogue(value); return 0; }
   if (name != nullptr && strcmp(name, "igemm256_phase_fast") == 0) { igemm256_set_phase_fast(value); return 0; }
-  if (name != nullptr && strcmp(name, "igemm_mix_cus") == 0) {
-    if (value < 1) return dc_fail("dc_set_option: igemm_mix_cus must be positive", __FILE__, __LINE__);
-    g_mix_cus = value;
-    return 0;
-  }
-  if (name != nullptr && strcmp(name, "igemm_mix_tail") == 0) { g_mix_tail_pct = value; return 0; }
   if (name != nullptr && strcmp(name, "wgrad_target_blocks") == 0) return dc_wgrad_set_target_blocks(value);
   if (name != nullptr && strcmp(name, "wgrad_mode") == 0) return dc_wgrad_set_mode(value);
   if (name != nullptr && strcmp(name, "wgrad_min_steps") == 0) return dc_wgrad_set_min_steps(value);
@@ -937,10 +902,10 @@ extern "C" int dc_set_option(const char* name, int value) {
 // tests on an experimental kernel), and the library applies the same table when it is loaded, so the table IS the default.
 static const struct { const char* name; int value; } kOptionDefaults[] = {
     {"igemm_mode", 2}, {"igemm256", 1}, {"pw384", 1}, {"pw384_k64", 1}, {"igemm256p", 1}, {"igemm256p_wgs", 0}, {"igemm256p_min", 257},
-    {"igemm256k", 0}, {"igemm256_tile2d", 0}, {"thin_fwd", 1}, {"igemm256_rel", 0}, {"igemm_mix", 0}, {"pack_blocks", 2048},
-    {"igemm256_epi", 0}, {"igemm256_phase_fast", 1}, {"igemm_mix_cus", 256}, {"igemm_mix_tail", 40}, {"wgrad_target_blocks", 768},
+    {"igemm256_tile2d", 0}, {"thin_fwd", 1}, {"igemm256_rel", 0}, {"pack_blocks", 2048},
+    {"igemm256_epi", 0}, {"igemm256_phase_fast", 1}, {"wgrad_target_blocks", 768},
     {"wgrad_mode", 1}, {"wgrad_min_steps", 16}, {"wgrad256", 1}, {"wgrad256_pad", 115}, {"thin_wgrad", 1}, {"wgrad256_slots", 192}, {"head_fused", 1},
-    {"head_dgrad_fused", 1}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_fin_fallback", 0}, {"dw_pipe", 1}, {"bn_cgw", 32}, {"bn_rows", 32},
+    {"head_dgrad_fused", 1}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_pipe", 1}, {"bn_cgw", 32}, {"bn_rows", 32},
 };
 
 extern "C" int dc_reset_options(void) {

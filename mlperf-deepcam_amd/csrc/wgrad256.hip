@@ -31,7 +31,7 @@ constexpr int WSTAGE = 2 * WOPER;
 constexpr int WNST = DC_WG256_STAGES;   // ring stages of 32 KiB (5 = the CU's whole LDS)
 __device__ inline int ring(int s) { return (WNST & (WNST - 1)) == 0 ? (s & (WNST - 1)) : s % WNST; }
 #ifndef DC_WG256_PROBE
-#define DC_WG256_PROBE 0     // diagnostic builds only (scripts/wgrad256_probe.py): 1 = no LDS-DMA, 2 = no LDS fragment reads, 8 = no slab stores
+#define DC_WG256_PROBE 0     // diagnostic builds only (scripts/wgrad256_probe.py): 1 = no LDS-DMA, 2 = no LDS fragment reads, 4 = L2-resident operands, 8 = no slab stores
 #endif
 
 static __device__ __attribute__((aligned(256))) unsigned char wg256_zero_page[256];
@@ -187,6 +187,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_)
       const bool ok = (m < mend) & cp_ok[i] & ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
       if (!(DC_WG256_PROBE & 1)) __builtin_amdgcn_global_load_lds(pick(ok, xg + offp[i]), (lds_ptr)(x_ + j * 1024), 16, 0, 0);
       // advance this row by one stage
+      if (DC_WG256_PROBE & 4) continue;   // diagnostic: every stage re-reads the first stage's (then L2-resident) rows
       rqx[i] += WBP;
       if (rqx[i] < g.Qw) {
         offq[i] += stepq;

@@ -370,6 +370,9 @@ class Engine:
                 # depthwise rows produced since the previous fold -- both behind a single fence on the weight-gradient stream
                 cnt, xs, dys, slabs, splits = rec["launch"]
                 ents, nent = rec["fold"]
+                for i, m in enumerate(rec["members"]):      # (an activation's buffer may be swapped between steps: the input pipeline's slots)
+                    xs[i] = m["x"].ptr.value
+                    dys[i] = m["dy"].ptr.value
 
                 def side(ws):
                     L.call("dc_conv_wgrad_partial", C.byref(d), N, H, W, cnt, xs, x.ld, dys, dy.ld, slabs, splits, self._st())
@@ -896,6 +899,7 @@ class Engine:
                 m["ready"].remove(m["wname"])
                 last["ready"].append(m["wname"])
             last["role"] = "flush" if cnt > 1 else "solo"
+            last["members"] = members
             last["launch"] = (cnt, (C.c_void_p * cnt)(*[m["x"].ptr.value for m in members]),
                               (C.c_void_p * cnt)(*[m["dy"].ptr.value for m in members]),
                               (C.c_void_p * cnt)(*[t.data_ptr() for t in slabs]), splits.value)

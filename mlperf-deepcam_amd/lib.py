@@ -37,14 +37,6 @@ class FoldEntry(C.Structure):
 DC_FOLD_CONV, DC_FOLD_CONVT, DC_FOLD_DW = 0, 1, 2
 
 
-class BnFin(C.Structure):
-    """dc_bn_fin (include/deepcam_hip.h): dc_bn_finalize's arguments as one block + the hand-over words of the in-kernel form."""
-    _fields_ = [("count", C.c_long), ("slab", C.c_void_p), ("rows", C.c_int), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
-                ("momentum", C.c_float), ("eps", C.c_float), ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p),
-                ("save_invstd", C.c_void_p), ("sync", C.c_void_p), ("epoch", C.c_uint)]
-
-
 P, I, L, F, SZ = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 CD = C.POINTER(ConvDesc)
 
@@ -107,8 +99,6 @@ _SIGS = {
     "dc_head_fwd_loss": (I, [I, I, I, I, I, P, I, P, P, P, P, I, P, F, P, P, P, P, P]),
     "dc_head_bwd": (I, [I, I, I, I, I, P, I, P, P, P, I, P, P, P]),
     "dc_head_bwd_bnstats": (I, [I, I, I, I, I, P, I, P, P, P, I, P, P, P, I, P, P, P, P, I, P, P]),
-    "dc_dwconv_fwd_bnfin_sync_words": (I, [I, I, I, I]),
-    "dc_dwconv_fwd_bnfin": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P]),
     "dc_head_fwd_bnin": (I, [I, I, I, I, I, P, I, P, P, I, P, P, P, P]),
     "dc_head_fwd_loss_bnin": (I, [I, I, I, I, I, P, I, P, P, I, P, P, P, P, I, P, F, P, P, P, P, P]),
     "dc_head_bwd_bnin": (I, [I, I, I, I, I, P, I, P, P, I, P, P, P, I, P, P, P, P, P, I, P]),

@@ -24,14 +24,9 @@ for (k, s, p, d, tr, cin, cout, N, H, W) in shapes:
     wf = (torch.randn(kk * cout * r32(cin), device=dev) * 0.05).to(dt)
     rows = lib.dc_conv_stat_rows(C.byref(desc), N, H, W)
     outs, res = [], []
-    for mode in [0] + WGS + ["k"]:
-        if mode == "k":      # the 128-byte-row form (igemm256k.hip) with the library's workgroup count
-            L.call("dc_set_option", b"igemm256k", 1); L.call("dc_set_option", b"igemm256p", 1); L.call("dc_set_option", b"igemm256p_wgs", 0)
-            mode = -2
-        else:
-            L.call("dc_set_option", b"igemm256k", 0)
+    for mode in [0] + WGS:
         L.call("dc_set_option", b"igemm256p", 1 if mode else 0)
-        if mode and mode != -2: L.call("dc_set_option", b"igemm256p_wgs", max(mode, 0))
+        if mode: L.call("dc_set_option", b"igemm256p_wgs", max(mode, 0))
         y = torch.zeros(N, Ho, Wo, r32(cout), device=dev, dtype=dt); slab = torch.zeros(2 * rows * cout, device=dev)
         once = lambda: L.call("dc_conv_fwd", C.byref(desc), N, H, W, L.dptr(x), r32(cin), L.dptr(wf), None, L.dptr(y), r32(cout), L.dptr(slab), 0, L.stream_ptr())
         for _ in range(3): once()

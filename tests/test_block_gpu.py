@@ -76,9 +76,7 @@ def test_block_matches_reference_block(golden_dir, case):
     # backward from the reference's upstream gradient
     out.grad.buf.zero_()
     out.grad.view().copy_(_nhwc(torch.from_numpy(z[case + "_go"])).to(DEV))
-    for op in eng.bwd:
-        op()
-    torch.cuda.current_stream().wait_stream(eng.side)
+    eng.backward()                  # the launch list, the folds of the weight-gradient slabs and the join with the weight-gradient stream
     torch.cuda.synchronize()
     gx = made["xin"].grad.view().permute(0, 3, 1, 2).cpu()
     if kw["start_with_relu"]:

@@ -294,9 +294,8 @@ def test_conv_persistent_tiles_same_bits(case):
         L.call("dc_set_option", b"igemm256", 2)
         L.call("dc_set_option", b"igemm256p_min", 1)
         L.call("dc_set_option", b"igemm256p_wgs", wgs)
-        for persistent in (0, 1, 2):          # 2: the 128-byte-row form where the geometry allows (else the same kernel as 1)
-            L.call("dc_set_option", b"igemm256p", 1 if persistent else 0)
-            L.call("dc_set_option", b"igemm256k", 1 if persistent == 2 else 0)
+        for persistent in (0, 1):
+            L.call("dc_set_option", b"igemm256p", persistent)
             ybuf, yv = empty_nhwc(N, Ho, Wo, cout, dtype, ld=cout + 24, off=16)
             slab = torch.full((2, rows, cout), float("nan"), device=dev())
             L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, vptr(slab), 0, S())
@@ -312,11 +311,10 @@ def test_conv_persistent_tiles_same_bits(case):
     finally:
         L.call("dc_set_option", b"igemm256", 1)
         L.call("dc_set_option", b"igemm256p", 1)
-        L.call("dc_set_option", b"igemm256k", 0)
         L.call("dc_set_option", b"igemm256p_min", 257)          # the library's defaults
         L.call("dc_set_option", b"igemm256p_wgs", 0)
     assert_close(got[0][0], conv_ref(x, q(w, dtype), None, k, stride, pad, dil, tr), dtype)
-    for v in (1, 2):
+    for v in (1,):
         for i in range(3):
             assert torch.equal(got[0][i], got[v][i]), f"variant {v}: output {i} differs"
         a, b = got[0][3], got[v][3]
@@ -542,67 +540,6 @@ def test_dilated_group_is_bit_identical_to_single_launches(shape, dtype):
     assert all(torch.equal(ys[b], singles[b][0]) for b in range(3))
     with pytest.raises(L.DeepcamHipError):
         L.call("dc_conv_fwd_dilated_group", C.byref(d0), N, H, W, 5, (C.c_int * 5)(1, 2, 3, 4, 5), vptr(xv), cin + 32, None, None, cout, None, S())
-
-
-MIX_CASES = [
-    # name, k, stride, pad, dil, transposed, cin, cout, N, H, W, cus, tail_pct
-    ("pw_3_tiles_on_2", 1, 1, 0, 1, 0, 64, 256, 2, 20, 16, 2, 60),          # 640 px: 512 on the 256-tile kernel, 128 on the small one
-    ("pw728_ragged", 1, 1, 0, 1, 0, 728, 728, 3, 19, 17, 4, 80),            # 969 px x 3 channel tiles = 12 tiles on 4 "CUs" + ragged rest
-    ("dense3x3", 3, 1, 1, 1, 0, 96, 256, 2, 24, 20, 3, 70),                 # halo taps across the cut
-    ("convT_phases", 3, 2, 1, 1, 1, 256, 256, 2, 16, 12, 3, 70),            # four sub-pixel phases, each cut at the same pixel
-]
-
-
-@pytest.mark.parametrize("case", MIX_CASES, ids=[c[0] for c in MIX_CASES])
-def test_conv_mixed_tile_plan_is_invisible(case):
-    """run_gather's mixed plan (whole rounds on the 256-tile kernel, the rest on the 128-tile kernel) gives the same bits as the
-    single-kernel launch: outputs, BatchNorm statistics slab, data gradient, also in accumulate mode."""
-    name, k, stride, pad, dil, tr, cin, cout, N, H, W, cus, pct = case
-    dtype = torch.bfloat16
-    d = desc(dtype, k, stride, pad, dil, tr, cin, cout)
-    kk = 3 if tr else k
-    wshape = (cin, cout, kk, kk) if tr else (cout, cin, kk, kk)
-    x = q(rnd(N, cin, H, W, seed=1), dtype)
-    w = rnd(*wshape, seed=2, scale=(cin * kk * kk) ** -0.5)
-    Ho, Wo = C.c_int(), C.c_int()
-    L.call("dc_conv_out_hw", C.byref(d), H, W, C.byref(Ho), C.byref(Wo))
-    Ho, Wo = Ho.value, Wo.value
-    yref = conv_ref(x, q(w, dtype), None, k, stride, pad, dil, tr)
-    gy = q(rnd(N, cout, Ho, Wo, seed=3), dtype)
-    nwf, nwb = C.c_size_t(), C.c_size_t()
-    L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
-    wf = torch.empty(nwf.value, dtype=dtype, device=dev())
-    wb = torch.empty(nwb.value, dtype=dtype, device=dev())
-    L.call("dc_conv_pack_weights", C.byref(d), vptr(w.to(dev())), vptr(wf), vptr(wb), S())
-    _, xv = to_nhwc(x, dtype, ld=cin + 16, off=8)
-    _, gyv = to_nhwc(gy, dtype)
-    rows = L.load().dc_conv_stat_rows(C.byref(d), N, H, W)
-    got = []
-    try:
-        L.call("dc_set_option", b"igemm256", 2)
-        L.call("dc_set_option", b"igemm_mix_cus", cus)
-        L.call("dc_set_option", b"igemm_mix_tail", pct)
-        for mix in (0, 1):
-            L.call("dc_set_option", b"igemm_mix", mix)
-            ybuf, yv = empty_nhwc(N, Ho, Wo, cout, dtype, ld=cout + 24, off=16)
-            slab = torch.full((2, rows, cout), float("nan"), device=dev())
-            L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, vptr(slab), 0, S())
-            L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, None, 1, S())
-            _, gxv = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
-            L.call("dc_conv_dgrad", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(gxv), cin + 8, 0, S())
-            torch.cuda.synchronize()
-            assert torch.isnan(ybuf[..., :16].float()).all() and torch.isnan(ybuf[..., 16 + cout:].float()).all()
-            got.append((from_nhwc(yv), slab.cpu(), from_nhwc(gxv)))
-    finally:
-        L.call("dc_set_option", b"igemm256", 1)
-        L.call("dc_set_option", b"igemm_mix", 0)          # the library's default
-        L.call("dc_set_option", b"igemm_mix_cus", 256)
-        L.call("dc_set_option", b"igemm_mix_tail", 40)
-    assert_close(got[1][0], 2 * yref, dtype, bf16=4e-2)
-    assert not torch.isnan(got[1][1]).any()
-    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][2], got[1][2])       # outputs and data gradient: same bits
-    # the statistics rows past the cut come from the other kernel, which adds the same stored values in another order
-    np.testing.assert_allclose(got[0][1].numpy(), got[1][1].numpy(), rtol=2e-5, atol=1e-4)
 
 
 GROUP_CASES = [
@@ -1446,58 +1383,6 @@ BNFIN_CASES = [
     ("dilated", 256, 2, 1, 16, 24, 70),               # more rows than the 64 row lanes of a finalize block
     ("thin", 128, 1, 2, 40, 24, 600),                 # 16-group workgroups; a slab longer than one eight-row sweep per lane
 ]
-
-
-@pytest.mark.parametrize("fallback", [0, 1], ids=["leaders", "wait_ran_out"])
-@pytest.mark.parametrize("case", BNFIN_CASES, ids=[c[0] for c in BNFIN_CASES])
-def test_depthwise_forward_with_batchnorm_finalize_inside(case, fallback):
-    """dc_dwconv_fwd_bnfin (the first workgroups of the depthwise grid run the BatchNorm finalize blocks, the others wait for them)
-    against dc_bn_finalize followed by dc_dwconv_fwd: output, scale / shift, saved mean / invstd, running statistics and
-    num_batches_tracked bit for bit, over three launches (the hand-over counter runs on) -- also on the path a workgroup takes when its
-    wait runs out (forced by the test switch: every workgroup computes its coefficients itself, serially, in the same order)."""
-    name, Cc, dil, N, H, W, rows = case
-    dtype = torch.bfloat16
-    dt = L.dtype_code(dtype)
-    M = N * H * W
-    x = q(rnd(N, Cc, H, W, seed=1), dtype)
-    _, xv = to_nhwc(x, dtype, ld=Cc + 8)
-    wm = rnd(Cc, 1, 3, 3, seed=2, scale=0.3).to(dev())
-    wp = torch.empty(9 * Cc, device=dev())
-    L.call("dc_dwconv_pack_weights", Cc, vptr(wm), vptr(wp), S())
-    gam, bet = (rnd(Cc, seed=3).abs() + 0.5).to(dev()), rnd(Cc, seed=4, scale=0.3).to(dev())
-    words = L.load().dc_dwconv_fwd_bnfin_sync_words(dt, Cc, 1, dil)
-    assert words == ((Cc // 8 + 31) // 32 if Cc // 8 > 16 else 1) + 1
-
-    def state():
-        return dict(rm=torch.zeros(Cc, device=dev()), rv=torch.ones(Cc, device=dev()), nbt=torch.zeros(1, dtype=torch.int64, device=dev()),
-                    scale=torch.full((Cc,), float("nan"), device=dev()), shift=torch.full((Cc,), float("nan"), device=dev()),
-                    mean=torch.full((Cc,), float("nan"), device=dev()), invstd=torch.full((Cc,), float("nan"), device=dev()))
-
-    ref, got = state(), state()
-    sync = torch.zeros(max(words, 1), dtype=torch.int32, device=dev())
-    try:
-        L.call("dc_set_option", b"dw_fin_fallback", fallback)
-        for epoch in range(3):
-            slab = (rnd(2, rows, Cc, seed=10 + epoch).abs() * (M / rows)).to(dev())          # "sums" and "sums of squares" of about M values
-            slab[1] += slab[0] ** 2 / (M / rows) * 1.5
-            _, y0 = empty_nhwc(N, H, W, Cc, dtype)
-            L.call("dc_bn_finalize", Cc, M, vptr(slab), rows, vptr(gam), vptr(bet), vptr(ref["rm"]), vptr(ref["rv"]), vptr(ref["nbt"]), 0.1, 1e-5,
-                   vptr(ref["scale"]), vptr(ref["shift"]), vptr(ref["mean"]), vptr(ref["invstd"]), S())
-            L.call("dc_dwconv_fwd", dt, Cc, 1, dil, N, H, W, vptr(xv), Cc + 8, vptr(wp), vptr(y0), Cc, vptr(ref["scale"]), vptr(ref["shift"]), 1, S())
-            _, y1 = empty_nhwc(N, H, W, Cc, dtype)
-            bn = L.BnFin(M, slab.data_ptr(), rows, gam.data_ptr(), bet.data_ptr(), got["rm"].data_ptr(), got["rv"].data_ptr(), got["nbt"].data_ptr(),
-                         0.1, 1e-5, got["scale"].data_ptr(), got["shift"].data_ptr(), got["mean"].data_ptr(), got["invstd"].data_ptr(),
-                         sync.data_ptr(), epoch)
-            L.call("dc_dwconv_fwd_bnfin", dt, Cc, 1, dil, N, H, W, vptr(xv), Cc + 8, vptr(wp), vptr(y1), Cc, C.byref(bn), 1, S())
-            torch.cuda.synchronize()
-            assert torch.equal(from_nhwc(y1), from_nhwc(y0)), f"launch {epoch}: output"
-            for k in ref:
-                assert torch.equal(got[k], ref[k]), f"launch {epoch}: {k}"
-        # every finalize block counted once per launch; no wait ran out (the leaders are the first workgroups the dispatcher starts)
-        assert int(sync[:-1].sum()) == 3 * ((Cc + 3) // 4), sync.tolist()
-        assert int(sync[-1]) == 0, f"{int(sync[-1])} workgroups waited in vain"
-    finally:
-        L.call("dc_set_option", b"dw_fin_fallback", 0)
 
 
 @pytest.mark.parametrize("relu", [1, 0], ids=["relu", "affine"])
