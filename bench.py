@@ -197,6 +197,20 @@ def main():
         reducer.broadcast_parameters()
         step.attach_reducer(reducer)
     x, y = synthetic_batch(B, H, W, 1234 + rank, dev)
+    # N > 1: what the collective backend saw and how long the step waited for it.  The wait of reducer.finish() (the compute stream
+    # stalls until the outstanding bucket all-reduces are done, then the optimizer runs) is bracketed by two events on that stream in
+    # every timed step: with no kernel between them their distance IS the exposed communication time.
+    comm_events = []
+    if reducer is not None:
+        inner_finish = step.after_backward
+
+        def timed_finish():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            inner_finish()
+            e1.record()
+            comm_events.append((e0, e1))
+        step.after_backward = timed_finish
     graphed = False
     if world == 1 and a.graph:
         step(x, y)
@@ -211,6 +225,7 @@ def main():
     for _ in range(a.warmup):
         step(x, y)
     barrier()
+    comm_events.clear()
     # per-step HIP events on the launch stream (SURVEY 8d asks for the median of per-step times beside the mean): recording an event
     # costs no synchronisation, the timed region stays K steps between two barriers
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
@@ -232,6 +247,16 @@ def main():
         dt = float(t.item())
     loss = step.loss()
     sps = a.steps * B * world / dt
+    comm = None
+    if reducer is not None:
+        waits = sorted(e0.elapsed_time(e1) for e0, e1 in comm_events[:a.steps])
+        step.after_backward = inner_finish               # the roofline passes below run without the brackets
+        comm = {"backend": dist.get_backend(), "world": dist.get_world_size(), "payload": reducer.payload,
+                "buckets": len(reducer.buckets), "bytes_per_step_per_rank": int(net.engine.layout.n_params * (2 if reducer.payload == "bf16" else 4)),
+                "buckets_launched_per_step": reducer.launched_last if hasattr(reducer, "launched_last") else None,
+                "exposed_wait_ms": {"median": round(waits[len(waits) // 2], 3), "max": round(waits[-1], 3)} if waits else None,
+                "what": "exposed_wait_ms = rank 0's compute stream stalled in reducer.finish() (bucket all-reduces still running when "
+                        "backward had finished), HIP events around the wait, per timed step"}
 
     # ---- roofline of the dominant kernel family, timed per launch with HIP events on the launch stream ----------------
     roof = None
@@ -332,6 +357,8 @@ def main():
                           "local_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": a.optimizer,
                           "hip_graph": graphed, "switches": switches},
                "loss_last_step": round(loss, 6), "roofline": roof}
+        if comm is not None:
+            out["comm"] = comm
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(H, W)

@@ -39,32 +39,17 @@ struct GatherGeom {
   Tap taps[9];     // sorted by phase
   int phase_beg[5];     // taps of phase ph: [phase_beg[ph], phase_beg[ph+1])
   FastDiv div_hw, div_w;   // by Qh*Qw and by Qw
-  // 256-tile kernel, multi-tap layers whose phase grid is a multiple of 16 x 16: a workgroup's 256 pixels are a 16 x 16 block of
-  // the grid instead of 256 consecutive pixels of one row, so the halo rows its 3 x 3 taps gather are its OWN block's rows plus a
-  // one-pixel frame (18 x 18 / 256 = 1.27 x the block) instead of three full rows per row (3 x): the fabric-side traffic of the
-  // 192 x 288 decoder convolutions was 2.1 x their tensors (profiles/r03_roofline_table.md).  tile2d = 0: linear pixel order.
-  int tile2d;
-  FastDiv div_tw, div_timg;   // by Qw/16 (tiles per grid row) and by (Qh/16)*(Qw/16) (tiles per image)
   int Hin, Win, Cin;    // gathered tensor extents
   int Hout, Wout, Cout; // produced tensor extents
   int Qh, Qw;           // phase grid extents (Hout/os, Wout/os)
 };
 
-// pixel index m of the phase grid (0 <= m < N*Qh*Qw) -> image n, grid position (qy, qx); in tile2d order m = tile * 256 + ly * 16 + lx
+// pixel index m of the phase grid (0 <= m < N*Qh*Qw) -> image n, grid position (qy, qx)
 __device__ inline void grid_pixel(const GatherGeom& g, int m, int& n, int& qy, int& qx) {
-  if (g.tile2d) {
-    const int t = m >> 8, l = m & 255;
-    n = fast_div(t, g.div_timg);
-    const int r = t - n * g.div_timg.d;
-    const int ty = fast_div(r, g.div_tw), tx = r - ty * g.div_tw.d;
-    qy = ty * 16 + (l >> 4);
-    qx = tx * 16 + (l & 15);
-  } else {
-    n = fast_div(m, g.div_hw);
-    const int rem = m - n * (g.Qh * g.Qw);
-    qy = fast_div(rem, g.div_w);
-    qx = rem - qy * g.Qw;
-  }
+  n = fast_div(m, g.div_hw);
+  const int rem = m - n * (g.Qh * g.Qw);
+  qy = fast_div(rem, g.div_w);
+  qx = rem - qy * g.Qw;
 }
 
 enum GatherMode { kFwd = 0, kDgrad = 1 };
@@ -125,9 +110,6 @@ inline bool build_geom(const dc_conv_desc& d, int Hi, int Wi, GatherMode mode, G
   }
   g->div_hw = make_fastdiv(g->Qh * g->Qw);
   g->div_w = make_fastdiv(g->Qw);
-  g->tile2d = 0;
-  g->div_tw = make_fastdiv(g->Qw / 16 > 0 ? g->Qw / 16 : 1);
-  g->div_timg = make_fastdiv((g->Qh / 16) * (g->Qw / 16) > 0 ? (g->Qh / 16) * (g->Qw / 16) : 1);
   return true;
 }
 

@@ -32,7 +32,6 @@ struct IgemmParams {
   int mtiles;  // 128-pixel tiles per phase of the WHOLE layer (= rows per phase of the statistics slab)
   int accumulate;
   const void* zero_page;   // 256 zero bytes in device memory (set by the 256-tile launcher)
-  int reg_epilogue;        // 256-tile kernel: epilogue from the accumulator registers (set by its launcher)
   int phase_fast;          // 256-tile kernel: consecutive tiles walk the sub-pixel phases of one pixel tile (set by its launcher)
   // 256-tile kernel, grouped launch (dc_conv_fwd_dilated_group): `ngroup` "same" dilated 3x3 convolutions of ONE input share the
   // launch.  g holds the unit-dilation tap table (dy, dx in {-1,0,1}); member b gathers at dy*gdil[b], dx*gdil[b], multiplies
@@ -49,9 +48,7 @@ struct IgemmParams {
 
 // 256 x 256 tile kernel (bf16 only).  Returns 0 after launching.
 int launch_igemm256(const IgemmParams& p, hipStream_t st);
-void igemm256_set_epilogue(int v);
 void igemm256_set_phase_fast(int v);
-void igemm256_set_tile2d(int v);
 int igemm256_phase_fast_enabled();
 // igemm256p.hip: persistent form (one workgroup per CU walks its tiles; the ring never drains between tiles)
 bool igemm256p_eligible(const IgemmParams& p);

@@ -592,7 +592,6 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   DC_REQUIRE(M < (1L << 31) - BM, "dc_conv: too many pixels for 32-bit indexing");
   p.M = (int)M;
   p.m_beg = 0;
-  p.reg_epilogue = 0;
   p.phase_fast = 0;
   p.zero_page = nullptr;
   p.ngroup = 0;
@@ -877,11 +876,9 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm256p_wgs") == 0) { g_igemm256p_wgs = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256p_min") == 0) { g_igemm256p_min = value; return 0; }
   if (name != nullptr && strcmp(name, "pw384_k64") == 0) { g_pw384_k64 = value; return 0; }
-  if (name != nullptr && strcmp(name, "igemm256_tile2d") == 0) { igemm256_set_tile2d(value); return 0; }
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }
   if (name != nullptr && strcmp(name, "pack_blocks") == 0 && value > 0) { g_pack_blocks = value; return 0; }
-  if (name != nullptr && strcmp(name, "igemm256_epi") == 0) { igemm256_set_epilogue(value); return 0; }
   if (name != nullptr && strcmp(name, "igemm256_phase_fast") == 0) { igemm256_set_phase_fast(value); return 0; }
   if (name != nullptr && strcmp(name, "wgrad_target_blocks") == 0) return dc_wgrad_set_target_blocks(value);
   if (name != nullptr && strcmp(name, "wgrad_mode") == 0) return dc_wgrad_set_mode(value);
@@ -902,8 +899,8 @@ extern "C" int dc_set_option(const char* name, int value) {
 // tests on an experimental kernel), and the library applies the same table when it is loaded, so the table IS the default.
 static const struct { const char* name; int value; } kOptionDefaults[] = {
     {"igemm_mode", 2}, {"igemm256", 1}, {"pw384", 1}, {"pw384_k64", 1}, {"igemm256p", 1}, {"igemm256p_wgs", 0}, {"igemm256p_min", 257},
-    {"igemm256_tile2d", 0}, {"thin_fwd", 1}, {"igemm256_rel", 0}, {"pack_blocks", 2048},
-    {"igemm256_epi", 0}, {"igemm256_phase_fast", 1}, {"wgrad_target_blocks", 768},
+    {"thin_fwd", 1}, {"igemm256_rel", 0}, {"pack_blocks", 2048},
+    {"igemm256_phase_fast", 1}, {"wgrad_target_blocks", 768},
     {"wgrad_mode", 1}, {"wgrad_min_steps", 16}, {"wgrad256", 1}, {"wgrad256_pad", 115}, {"thin_wgrad", 1}, {"wgrad256_slots", 192}, {"head_fused", 1},
     {"head_dgrad_fused", 1}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_pipe", 1}, {"bn_cgw", 32}, {"bn_rows", 32},
 };
@@ -975,7 +972,7 @@ extern "C" int dc_conv_fwd_dilated_group(const dc_conv_desc* d, int N, int Hi, i
   p.bst = BnBwdEpi{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
   p.N = N; p.ldx = ldx; p.ldy = ldy;
   p.ldw = (p.g.Cin + 31) / 32 * 32;
-  p.M = (int)M; p.m_beg = 0; p.reg_epilogue = 0; p.phase_fast = 0; p.zero_page = nullptr;
+  p.M = (int)M; p.m_beg = 0; p.phase_fast = 0; p.zero_page = nullptr;
   p.mtiles = cdiv(M, BM);
   p.accumulate = 0;
   p.ngroup = count;

@@ -326,107 +326,6 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
     o[7] = (unsigned long long)steps;
   }
 #endif
-  if (p.reg_epilogue) {
-    // ---- epilogue from the accumulator registers (no LDS, no workgroup barrier) -------------------------------------------
-    // A lane holds, per MFMA tile (i, j), channels fg*4 .. +3 of channel block i for pixel fr of pixel block j: 8 bytes.  Lanes
-    // l and l ^ 16 (fg and fg ^ 1) trade halves so that the even-fg lane keeps 8 consecutive channels of block i and the odd-fg
-    // lane 8 consecutive channels of block i + 1: 16-byte stores, 64 contiguous bytes per pixel and store instruction (the
-    // LDS epilogue stores whole 512-byte rows but costs 13 k of a 63 k-cycle 23-stage tile: scripts/igemm_stamps.py).
-    // BatchNorm sums of the STORED values: over the lane's 8 pixels in registers, over the 16 pixel lanes by DPP; the wave's
-    // 128 pixels x 64 channels are exactly its segment of one slab row.
-    const bool odd = fg & 1;
-    bf16* __restrict__ yg = reinterpret_cast<bf16*>(ysel);
-    const bool do_stats = slabsel != nullptr;
-    size_t opix[8];
-    bool pok[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = m0 + grp * 128 + j * 16 + fr;
-      pok[j] = m < p.M;
-      opix[j] = (size_t)m;
-      if (g.os != 1 || g.tile2d) {
-        const int mm = pok[j] ? m : 0;
-        int n, qy, qx;
-        grid_pixel(g, mm, n, qy, qx);
-        opix[j] = (size_t)(n * g.Hout + qy * g.os + py) * g.Wout + qx * g.os + px;
-      }
-    }
-    float st[2][2][8];   // [channel-block pair][sum, sum of squares][channel]
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-      const int i0 = 2 * pr;
-      const int chl = wc * 64 + (i0 + (odd ? 1 : 0)) * 16 + (fg >> 1) * 8;   // first of this lane's 8 channels after the trade
-      const int ch0 = n0 + chl;
-      const bool chok = ch0 < g.Cout;                                        // Cout is a multiple of 8: all or nothing
-      float ba[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};      // bias of the channels this lane COMPUTED
-      if (p.bias != nullptr) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ca = n0 + wc * 64 + i0 * 16 + fg * 4 + r, cb = ca + 16;
-          if (ca < g.Cout) ba[r] = p.bias[ca];
-          if (cb < g.Cout) bb[r] = p.bias[cb];
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) st[pr][0][e] = st[pr][1][e] = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        uint32_t a0 = pack2_bf16(acc[i0][j][0] + ba[0], acc[i0][j][1] + ba[1]);
-        uint32_t a1 = pack2_bf16(acc[i0][j][2] + ba[2], acc[i0][j][3] + ba[3]);
-        uint32_t b0 = pack2_bf16(acc[i0 + 1][j][0] + bb[0], acc[i0 + 1][j][1] + bb[1]);
-        uint32_t b1 = pack2_bf16(acc[i0 + 1][j][2] + bb[2], acc[i0 + 1][j][3] + bb[3]);
-        const uint32_t r0 = swap_rows16(odd ? a0 : b0), r1 = swap_rows16(odd ? a1 : b1);
-        vec16 v;
-        v.w[0] = odd ? r0 : a0;
-        v.w[1] = odd ? r1 : a1;
-        v.w[2] = odd ? b0 : r0;
-        v.w[3] = odd ? b1 : r1;
-        if (pok[j] && chok) {
-          bf16* dst = yg + opix[j] * p.ldy + ch0;
-          float f[8];
-          unpack(v, f, bf16());
-          if (p.accumulate) {
-            float o[8];
-            unpack(ldg16(dst), o, bf16());
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += o[e];
-            pack(v, f, bf16());
-            unpack(v, f, bf16());
-          }
-          stg16(dst, v);
-          if (do_stats) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              st[pr][0][e] += f[e];
-              st[pr][1][e] = fmaf(f[e], f[e], st[pr][1][e]);
-            }
-          }
-        }
-      }
-    }
-    if (do_stats) {
-      const int rows = p.mtiles * g.os * g.os;
-      const int mt128 = (m0 >> 7) + grp;
-      // value idx = pr*16 + which*8 + e; lane fr of a row writes idx = fr and idx = fr + 16 (i.e. pair 0 and pair 1)
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        float mine = 0.f;
-#pragma unroll
-        for (int w = 0; w < 2; ++w)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float t = row_sum16(st[pr][w][e]);
-            if (fr == w * 8 + e) mine = t;
-          }
-        const int which = fr >> 3, e = fr & 7;
-        const int c = n0 + wc * 64 + (2 * pr + (odd ? 1 : 0)) * 16 + (fg >> 1) * 8 + e;
-        if (c < g.Cout && mt128 < p.mtiles)
-          slabsel[((size_t)which * rows + phase * p.mtiles + mt128) * g.Cout + c] = mine;
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // LDS-DMA fills of the last slots must land before the LDS is released
-    return;
-  }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the zero-page fills of the last three slots
   __builtin_amdgcn_s_barrier();
 
@@ -478,7 +377,7 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
     bmh[e] = (ok && p.bst.relu) ? p.bst.mshift[ch0 + e] : 0.f;
   }
   auto out_pixel = [&](int m) -> size_t {
-    if (g.os == 1 && !g.tile2d) return (size_t)m;
+    if (g.os == 1) return (size_t)m;
     int n, qy, qx;
     grid_pixel(g, m, n, qy, qx);
     return (size_t)(n * g.Hout + qy * g.os + py) * g.Wout + qx * g.os + px;
@@ -587,17 +486,6 @@ extern "C" int dc_debug_stamp_buf256(void* buf) {
 }
 #endif
 
-// 0: epilogue through an LDS C tile (512-byte rows), 1: from the accumulator registers (A/B switch "igemm256_epi").  Measured
-// the same per step (41.0 vs 41.1 ms) and per layer within +-4 % (worse by 13 % on the HBM-bound 256 -> 256 pointwise layer at
-// 192 x 288): the 13 k cycles the stamps show for the epilogue of a 23-stage tile are the write burst of 256 workgroups
-// finishing together (32 MB at HBM speed), not LDS or instruction time.
-static int g_reg_epilogue = 0;
-void igemm256_set_epilogue(int v) { g_reg_epilogue = v ? 1 : 0; }
-// 16 x 16 pixel blocks per workgroup on multi-tap layers (A/B switch "igemm256_tile2d").  Off: once the K order keeps the tap sweeps in
-// L2 the blocks fetch the same bytes as 256 consecutive pixels (264 MB per launch either way) and run 5 % slower (494 vs 471 us on the
-// 192 x 288 3 x 3 layer, 877 vs 825 us on the transposed one): sixteen short row segments per tile instead of one long one.
-static int g_tile2d = 0;
-void igemm256_set_tile2d(int v) { g_tile2d = v ? 1 : 0; }
 static int g_phase_fast = 1;     // tile order of multi-phase (transposed / strided) launches: phase fastest (A/B switch "igemm256_phase_fast")
 void igemm256_set_phase_fast(int v) { g_phase_fast = v ? 1 : 0; }
 int igemm256_phase_fast_enabled() { return g_phase_fast; }
@@ -615,9 +503,6 @@ int launch_igemm256(const IgemmParams& p_in, hipStream_t st) {
   if (init_err != hipSuccess) return dc_set_error(init_err, __FILE__, __LINE__);
   IgemmParams p = p_in;
   p.zero_page = zero_dev;
-  // 16 x 16 pixel blocks for multi-tap layers on grids that divide (the 3 x 3 and transposed convolutions of the decoder)
-  p.g.tile2d = (g_tile2d && p.g.ntaps > 1 && p.m_beg == 0 && p.g.Qh % 16 == 0 && p.g.Qw % 16 == 0) ? 1 : 0;
-  p.reg_epilogue = p.bst.y != nullptr ? 0 : g_reg_epilogue;      // the BatchNorm-backward sums live in the LDS epilogue
   p.phase_fast = g_phase_fast;
   hipLaunchKernelGGL(igemm256_kernel, dim3((unsigned)igemm256_tiles(p)), dim3(512), lds, st, p);
   DC_CHECK_LAUNCH();

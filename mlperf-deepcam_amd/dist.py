@@ -125,6 +125,10 @@ class GradReducer:
         if self.payload == "bf16":
             # one send buffer for the whole arena (bucket b uses [lo, hi) of it, so buckets in flight never alias)
             self._send = torch.empty(lay.n_params, dtype=torch.bfloat16, device=engine.grads.device)
+            # dc_grad_pack_bf16 / dc_grad_unpack_bf16 move 16-byte vectors of both arenas: every bucket must start on an 8-element boundary
+            bad = [b.lo for b in self.buckets if b.lo % 8]
+            if bad:
+                raise ValueError(f"bf16 gradient payload needs bucket offsets that are multiples of 8 elements, got {bad[:4]}")
         self.engines = []
         self.hook(engine)
         self.launched = 0
@@ -142,6 +146,7 @@ class GradReducer:
         for b in self.buckets:
             b.remaining = len(b.names)
             b.work = None
+        self.launched_last = self.launched       # buckets the step that has just finished sent to the collective (bench.py's comm block)
         self.launched = 0
 
     def _reduce(self, b: Bucket):

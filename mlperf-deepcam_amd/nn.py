@@ -139,7 +139,9 @@ class _NetFn(torch.autograd.Function):
         red = ctx.module._ddp_reducer
         if red is not None:
             # under dist.DistributedDataParallel: wait for the bucketed all-reduces launched during backward, re-arm the
-            # buckets and leave the AVERAGED gradient in the arena (train_hdf5_ddp.py:227,363)
+            # buckets and leave the AVERAGED gradient in the arena (train_hdf5_ddp.py:227,363).  A reducer that a fused TrainStep
+            # has taken over averages inside the optimizer kernel: finish(average=True) refuses (the gradients would otherwise be
+            # scaled twice, or -- had the reference been dropped -- the buckets launched by this backward would never be waited for)
             red.finish(average=True)
         ctx.module._attach_grads()
         return None, None, None
@@ -499,8 +501,8 @@ class TrainStep:
         # one averaging mechanism per module: the autograd path (DistributedDataParallel -> finish(average=True)) is switched off
         reducer.averaging_in_optimizer = True
         reducer.hook(self.eng)
-        if getattr(self.net, "_ddp_reducer", None) is reducer:
-            self.net._ddp_reducer = None
+        # (net._ddp_reducer stays set: a loss.backward() through the wrapped module after this point reaches finish(average=True), which
+        # raises on a reducer whose averaging lives in the optimizer, instead of silently leaving launched buckets un-waited)
 
     def launch(self, x: torch.Tensor, labels: torch.Tensor) -> None:
         eng = self.eng

@@ -12,6 +12,12 @@ addressed by integer handles (they own device buffers and a compiled launch prog
     deepcam::wce_fused(...) -> ()                                                  fp_loss + its gradient + argmax + IoU counts (losses.py:28-52)
     deepcam::confusion_counts(Tensor pred, Tensor gt, Tensor(a!) counts) -> ()      compute_score's tp / fp / fn (utils.py:32-60)
     deepcam::optimizer_step(int optimizer) -> ()                                    optimizer.step() (:364)
+
+EAGER ONLY.  The schemas name the operators, not their memory effects: net_forward returns the engine's persistent logits buffer (the
+same storage every call; a fused TrainStep does not even write it), net_backward and optimizer_step mutate the engine's arenas behind a
+`-> ()` signature.  That is what an eager training loop needs and all this package does with them; under opcheck, functionalization or
+torch.compile such operators could be reordered or dropped, so do not trace through them.  The drop-in boundary for another host is the
+C ABI (include/deepcam_hip.h), not this registration.
 """
 from __future__ import annotations
 

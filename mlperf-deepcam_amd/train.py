@@ -247,14 +247,17 @@ def main(pargs):
                 scheduler.step()
             if step % pargs.logging_frequency == 0:
                 loss_now = train_step.loss()
-                if not math.isfinite(loss_now):
-                    # the fused loss kernel turns a label outside [0, 3) into NaN (the reference's CrossEntropyLoss raises on it,
-                    # losses.py:50); one such step poisons every weight, so stop here instead of training on NaNs
-                    raise RuntimeError(f"non-finite training loss {loss_now} at step {step}: corrupt label or diverged run")
-                vals = torch.tensor([loss_now, train_step.iou()], dtype=torch.float32, device=device)
+                # the fused loss kernel turns a label outside [0, 3) into NaN (the reference's CrossEntropyLoss raises on it,
+                # losses.py:50); one such step poisons every weight, so stop instead of training on NaNs.  The decision is
+                # collective: only the rank that saw the corrupt label has a NaN at this step, and a rank that raised alone would leave
+                # the others blocked in the reduction below.
+                vals = torch.tensor([loss_now, train_step.iou(), 0.0 if math.isfinite(loss_now) else 1.0], dtype=torch.float32, device=device)
                 if size > 1:
-                    dist.reduce(vals, dst=0, op=dist.ReduceOp.SUM)
-                loss_avg_train, iou_avg_train = (vals / float(size)).tolist()
+                    dist.all_reduce(vals, op=dist.ReduceOp.SUM)
+                if float(vals[2]) > 0 or not bool(torch.isfinite(vals[0])):
+                    raise RuntimeError(f"non-finite training loss at step {step} on {int(vals[2])} rank(s) (local value {loss_now}): "
+                                       "corrupt label or diverged run")
+                loss_avg_train, iou_avg_train = (vals[:2] / float(size)).tolist()
                 md = {"epoch_num": epoch + 1, "step_num": step}
                 logger.log_event(key="learning_rate", value=current_lr, metadata=md)
                 logger.log_event(key="train_accuracy", value=iou_avg_train, metadata=md)
@@ -289,6 +292,13 @@ def main(pargs):
             if pargs.save_frequency > 0 and step % pargs.save_frequency == 0:
                 md = {"epoch_num": epoch + 1, "step_num": step}
                 logger.log_start(key="save_start", metadata=md, sync=True)
+                # never write a checkpoint of poisoned weights (the loss check above runs every logging_frequency steps only): same
+                # collective decision, on this step's loss
+                bad = torch.tensor([0.0 if math.isfinite(train_step.loss()) else 1.0], dtype=torch.float32, device=device)
+                if size > 1:
+                    dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+                if float(bad[0]) > 0:
+                    raise RuntimeError(f"non-finite training loss at step {step} on {int(bad[0])} rank(s): checkpoint not written")
                 if rank == 0:
                     checkpoint = {"step": step, "epoch": epoch, "model": ddp.state_dict(), "optimizer": optimizer.state_dict(),
                                   "amp": amp_state_dict(pargs.amp_opt_level)}

@@ -96,19 +96,6 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_256_tile_kernel_register_epilogue(case):
-    """The 256-tile kernel with the epilogue from the accumulator registers (lane-pair exchange, 16-byte stores, BatchNorm sums
-    by DPP row reductions), an A/B switch: same outputs, statistics equal up to the order of the additions."""
-    L.call("dc_set_option", b"igemm256", 2)
-    L.call("dc_set_option", b"igemm256_epi", 1)
-    try:
-        test_conv_fwd_dgrad_wgrad(case, torch.bfloat16)
-    finally:
-        L.call("dc_set_option", b"igemm256", 1)
-        L.call("dc_set_option", b"igemm256_epi", 0)
-
-
-@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv_256_tile_kernel(case):
     """The eight-wave 256 x 256 tile kernel (forced on every eligible call) passes the same checks as the 128 x 128 one."""
     L.call("dc_set_option", b"igemm256", 2)
@@ -185,71 +172,6 @@ def test_conv_pointwise_384_tile_kernel_same_bits(shape):
         assert torch.equal(got[0][0], other[0]) and torch.equal(got[0][1], other[1]) and torch.equal(got[0][3], other[3])
         assert not torch.isnan(other[2]).any()
         np.testing.assert_allclose(got[0][2].numpy(), other[2].numpy(), rtol=2e-5, atol=1e-4)
-
-
-TILE2D_CASES = [
-    # name, k, stride, pad, dil, transposed, cin, cout, N, H, W      (grids that are multiples of 16 x 16 in forward AND backward)
-    ("dense3x3", 3, 1, 1, 1, 0, 72, 264, 2, 32, 48),
-    ("atrous6", 3, 1, 6, 6, 0, 64, 256, 1, 48, 32),
-    ("convT", 3, 2, 1, 1, 1, 256, 256, 2, 16, 32),
-]
-
-
-@pytest.mark.parametrize("case", TILE2D_CASES, ids=[c[0] for c in TILE2D_CASES])
-def test_conv_2d_pixel_tiles_same_bits(case):
-    """The 256-tile kernel with 16 x 16 pixel blocks per workgroup (multi-tap layers on grids that divide): the same outputs and data
-    gradients bit for bit as with 256 consecutive pixels per workgroup, the same BatchNorm sums up to the order of the additions, and
-    the fused BatchNorm-backward epilogue agrees too."""
-    name, k, stride, pad, dil, tr, cin, cout, N, H, W = case
-    dtype = torch.bfloat16
-    d = desc(dtype, k, stride, pad, dil, tr, cin, cout)
-    kk = 3 if tr else k
-    wshape = (cin, cout, kk, kk) if tr else (cout, cin, kk, kk)
-    x = q(rnd(N, cin, H, W, seed=1), dtype)
-    w = rnd(*wshape, seed=2, scale=(cin * kk * kk) ** -0.5)
-    Ho, Wo = C.c_int(), C.c_int()
-    L.call("dc_conv_out_hw", C.byref(d), H, W, C.byref(Ho), C.byref(Wo))
-    Ho, Wo = Ho.value, Wo.value
-    gy = q(rnd(N, cout, Ho, Wo, seed=3), dtype)
-    ybn = q(rnd(N, cin, H, W, seed=5), dtype)
-    mean, invstd = rnd(cin, seed=6, scale=0.3).to(dev()), (rnd(cin, seed=7).abs() + 0.5).to(dev())
-    mscale, mshift = rnd(cin, seed=8).to(dev()), rnd(cin, seed=9, scale=0.5).to(dev())
-    nwf, nwb = C.c_size_t(), C.c_size_t()
-    L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
-    wf = torch.empty(nwf.value, dtype=dtype, device=dev())
-    wb = torch.empty(nwb.value, dtype=dtype, device=dev())
-    L.call("dc_conv_pack_weights", C.byref(d), vptr(w.to(dev())), vptr(wf), vptr(wb), S())
-    _, xv = to_nhwc(x, dtype, ld=cin + 16, off=8)
-    _, gyv = to_nhwc(gy, dtype)
-    _, ybv = to_nhwc(ybn, dtype)
-    rows = L.load().dc_conv_stat_rows(C.byref(d), N, H, W)
-    brows = L.load().dc_conv_dgrad_bnstats_rows(C.byref(d), N, H, W)
-    got = []
-    try:
-        L.call("dc_set_option", b"igemm256", 2)
-        for t2 in (0, 1):
-            L.call("dc_set_option", b"igemm256_tile2d", t2)
-            ybuf, yv = empty_nhwc(N, Ho, Wo, cout, dtype, ld=cout + 24, off=16)
-            slab = torch.full((2, rows, cout), float("nan"), device=dev())
-            L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, vptr(slab), 0, S())
-            _, gxv = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
-            L.call("dc_conv_dgrad", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(gxv), cin + 8, 0, S())
-            _, gxv2 = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
-            bslab = torch.full((2, brows, cin), float("nan"), device=dev())
-            L.call("dc_conv_dgrad_bnstats", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(gxv2), cin + 8, vptr(ybv), cin,
-                   vptr(mean), vptr(invstd), vptr(mscale), vptr(mshift), 1, vptr(bslab), S())
-            torch.cuda.synchronize()
-            assert torch.isnan(ybuf[..., :16].float()).all() and torch.isnan(ybuf[..., 16 + cout:].float()).all()
-            got.append((from_nhwc(yv), slab.double().sum(1).cpu(), from_nhwc(gxv), from_nhwc(gxv2), bslab.double().sum(1).cpu()))
-    finally:
-        L.call("dc_set_option", b"igemm256", 1)
-        L.call("dc_set_option", b"igemm256_tile2d", 0)          # the library's default
-    assert_close(got[0][0], conv_ref(x, q(w, dtype), None, k, stride, pad, dil, tr), dtype)
-    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][2], got[1][2]) and torch.equal(got[0][3], got[1][3])
-    assert torch.equal(got[1][2], got[1][3])
-    for a, b in ((got[0][1], got[1][1]), (got[0][4], got[1][4])):
-        assert not torch.isnan(b).any()
-        assert (a - b).abs().max().item() <= 2e-5 * (a.abs().max().item() + 1e-12) + 1e-6
 
 
 PERSIST_CASES = [
