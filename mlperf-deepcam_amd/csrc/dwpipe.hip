@@ -225,36 +225,20 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
 #else
 #define STAMP(acc) do {} while (0)
 #endif
-  int stage = 0;
-  for (int i = 0; i < nt; ++i) {
-    // tile i has landed once all but the youngest [stores of the last min(i, NS-1) tiles + DMAs of tiles i+1 .. i+NS-2] are done
-    if (wv < K::LASTW) {
-      if (i >= NS - 1) wait_vm<(NS - 1) * S::STORES + (NS - 2) * S::DMAS>();
-      else if (i == 0) wait_vm<(NS - 2) * S::DMAS>();
-      else if (i == 1) wait_vm<S::STORES + (NS - 2) * S::DMAS>();
-      else wait_vm<2 * S::STORES + (NS - 2) * S::DMAS>();
-    } else {          // one LDS-DMA fewer per tile
-      if (i >= NS - 1) wait_vm<(NS - 1) * S::STORES + (NS - 2) * (S::DMAS - 1)>();
-      else if (i == 0) wait_vm<(NS - 2) * (S::DMAS - 1)>();
-      else if (i == 1) wait_vm<S::STORES + (NS - 2) * (S::DMAS - 1)>();
-      else wait_vm<2 * S::STORES + (NS - 2) * (S::DMAS - 1)>();
-    }
-    __builtin_amdgcn_s_barrier();     // everybody's pieces of tile i have landed; everybody is done with the stage tile i-1 used
-    STAMP(tw);
-    {
-      int ns = stage + NS - 1;
-      if (ns >= NS) ns -= NS;
-      issue(t0 + i + NS - 1, ns);     // into the stage tile i-1 has just left
-    }
-    STAMP(ti);
-    char* sb = smem + stage * S::BYTES;
-    const int t = t0 + i;
+  auto decode = [&](int t, int& n, int& y0, int& x0) {
     const int tx = t % a.ntx;
     const int r = t / a.ntx;
-    const int ty = r % a.nty, n = r / a.nty;
-    const int y0 = ty * P_TH, x0 = tx * P_TW;
-    if constexpr (XFORM) {
-      // v = act(x * scale + shift) in place, once per staged element; the zero padding (out of the image) stays zero
+    const int ty = r % a.nty;
+    n = r / a.nty;
+    y0 = ty * P_TH;
+    x0 = tx * P_TW;
+  };
+  // v = act(x * scale + shift) in place on a landed halo tile, once per staged element; the zero padding (out of the image) stays zero
+  auto xform_tile = [&](int t, int stg) {
+    char* sb = smem + stg * S::BYTES;
+    int n, y0, x0;
+    decode(t, n, y0, x0);
+    (void)n;
 #pragma unroll
       for (int it = 0; it < K::HIT; ++it) {
         if (it == K::HIT - 1 && wv >= K::LASTW) break;
@@ -281,10 +265,11 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
           asm volatile("ds_write_b128 %0, %1" ::"v"(qa), "v"(ov) : "memory");
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    STAMP(tx_);
+  };
+  auto compute_tile = [&](int t, int stg) {
+    char* sb = smem + stg * S::BYTES;
+    int n, y0, x0;
+    decode(t, n, y0, x0);
     // ---- one strip: output row `row`, columns xs .. xs+3
     const char* tile = sb + h * 8;
     const int oy = y0 + row;
@@ -365,15 +350,74 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
         }
       }
     }
-    STAMP(tc);
-    if (++stage == NS) stage = 0;
+  };
+  int stage = 0;
+  if constexpr (!XFORM) {
+    for (int i = 0; i < nt; ++i) {
+      // tile i has landed once all but the youngest [stores of the last min(i, NS-1) tiles + DMAs of tiles i+1 .. i+NS-2] are done
+      if (wv < K::LASTW) {
+        if (i >= NS - 1) wait_vm<(NS - 1) * S::STORES + (NS - 2) * S::DMAS>();
+        else if (i == 0) wait_vm<(NS - 2) * S::DMAS>();
+        else if (i == 1) wait_vm<S::STORES + (NS - 2) * S::DMAS>();
+        else wait_vm<2 * S::STORES + (NS - 2) * S::DMAS>();
+      } else {          // one LDS-DMA fewer per tile
+        if (i >= NS - 1) wait_vm<(NS - 1) * S::STORES + (NS - 2) * (S::DMAS - 1)>();
+        else if (i == 0) wait_vm<(NS - 2) * (S::DMAS - 1)>();
+        else if (i == 1) wait_vm<S::STORES + (NS - 2) * (S::DMAS - 1)>();
+        else wait_vm<2 * S::STORES + (NS - 2) * (S::DMAS - 1)>();
+      }
+      __builtin_amdgcn_s_barrier();     // everybody's pieces of tile i have landed; everybody is done with the stage tile i-1 used
+      STAMP(tw);
+      {
+        int ns = stage + NS - 1;
+        if (ns >= NS) ns -= NS;
+        issue(t0 + i + NS - 1, ns);     // into the stage tile i-1 has just left
+      }
+      STAMP(ti);
+      compute_tile(t0 + i, stage);
+      STAMP(tc);
+      if (++stage == NS) stage = 0;
+    }
+  } else {
+    // Forward on a lazily applied BatchNorm: the in-place transform of tile i+1 runs in the same barrier interval as the stencil of tile i
+    // (different stages), so a tile costs ONE workgroup barrier and the transform's LDS round trips hide among the stencil's.  Tile i+1
+    // must therefore have landed at the top of iteration i: all but the youngest [stores of the last min(i, NS-2) tiles + DMAs of tiles
+    // i+2 .. i+NS-2].
+    static_assert(!XFORM || NS >= 3, "the transform one tile ahead needs three stages");
+    constexpr int D0 = S::DMAS, D1 = S::DMAS - 1;
+    if (wv < K::LASTW) wait_vm<(NS - 2) * D0>(); else wait_vm<(NS - 2) * D1>();     // tile 0
+    __builtin_amdgcn_s_barrier();
+    xform_tile(t0, 0);
+    for (int i = 0; i < nt; ++i) {
+      if (wv < K::LASTW) {
+        if (i >= NS - 2) wait_vm<(NS - 2) * S::STORES + (NS - 3) * D0>();
+        else if (i == 0) wait_vm<(NS - 3) * D0>();
+        else wait_vm<S::STORES + (NS - 3) * D0>();
+      } else {
+        if (i >= NS - 2) wait_vm<(NS - 2) * S::STORES + (NS - 3) * D1>();
+        else if (i == 0) wait_vm<(NS - 3) * D1>();
+        else wait_vm<S::STORES + (NS - 3) * D1>();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this thread's transform stores of tile i
+      __builtin_amdgcn_s_barrier();     // tile i is transformed, tile i+1 has landed, everybody is done with the stage tile i-1 used
+      STAMP(tw);
+      {
+        int ns = stage + NS - 1;
+        if (ns >= NS) ns -= NS;
+        issue(t0 + i + NS - 1, ns);
+      }
+      STAMP(ti);
+      if (i + 1 < nt) {
+        int s1 = stage + 1;
+        if (s1 == NS) s1 = 0;
+        xform_tile(t0 + i + 1, s1);
+      }
+      STAMP(tx_);
+      compute_tile(t0 + i, stage);
+      STAMP(tc);
+      if (++stage == NS) stage = 0;
+    }
   }
-#ifdef DWP_STAMPS
-  if ((tid & 63) == 0) {   // diagnostic builds only: cycles per phase, summed over this wave's tiles
-    unsigned long long* dbg = dwp_stamp_buf + 4 * ((blockIdx.x & 255) * 8 + wv);
-    dbg[0] = tw; dbg[1] = ti; dbg[2] = tx_; dbg[3] = tc;
-  }
-#endif
   // the ring drains (dummy requests past the last tile included) before its memory becomes the fold's scratch
   wait_vm<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -9,10 +9,12 @@ as read; both counters are in KiB.
 """
 import csv, glob, json, os, sys
 
-FAMILIES = {"igemm": ("igemm_kernel", "igemm256_kernel", "pw384_kernel", "tiny_gemm_kernel"),
-            "wgrad": ("wgrad_dma_kernel", "wgrad256_kernel", "wgrad_kernel", "wgrad_reduce_kernel")}
-# launches of the C-ABI entry point = launches of the main kernel (the reduce kernel rides along with each wgrad call)
-MAIN = {"igemm": ("igemm_kernel", "igemm256_kernel", "pw384_kernel", "tiny_gemm_kernel"), "wgrad": ("wgrad_dma_kernel", "wgrad256_kernel", "wgrad_kernel")}
+FAMILIES = {"igemm": ("igemm_kernel", "igemm256_kernel", "igemm256p_kernel", "pw384_kernel", "tiny_gemm_kernel"),
+            "wgrad": ("wgrad_dma_kernel", "wgrad256_kernel", "wgrad_kernel", "wgrad_reduce_kernel", "fold_kernel")}
+# launches of the C-ABI entry point = launches of the main kernel (the fold of the slabs rides along with each weight-gradient launch; since
+# round 4 it also folds the depthwise layers' rows, a few MB per launch)
+MAIN = {"igemm": ("igemm_kernel", "igemm256_kernel", "igemm256p_kernel", "pw384_kernel", "tiny_gemm_kernel"),
+        "wgrad": ("wgrad_dma_kernel", "wgrad256_kernel", "wgrad_kernel")}
 
 
 def collect(d, counter):
@@ -38,7 +40,8 @@ def collect(d, counter):
 
 fetch, calls_f, pk_f = collect(sys.argv[1], "FETCH_SIZE")
 write, calls_w, pk_w = collect(sys.argv[2], "WRITE_SIZE")
-out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline",
+cfg = {"local_batch": int(sys.argv[4]) if len(sys.argv) > 4 else 8, "dtype": "bf16", "height": 768, "width": 1152}
+out = {"config": cfg, "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline",
        "correction": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as read; KiB -> bytes; "
                      "per launch = per C-ABI call of the family (dc_conv_fwd + dc_conv_dgrad / dc_conv_wgrad incl. its slab reduction)",
        "kernels": {}, "per_kernel": {}}

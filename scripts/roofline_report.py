@@ -93,8 +93,9 @@ for r in rows:
 steps = max(n.get(k, 0) for k in n if "pack_all" in k) if any("pack_all" in k for k in n) else 1
 tot_gb = sum(r["gb"] for r in rows)
 out.append("")
-out.append(f"**Fabric-side traffic of the whole step: {tot_gb / steps:.1f} GB per step = {tot_gb / steps / 8:.2f} GB per sample** "
-           f"({steps} profiled steps of local batch 8; MFMA kernels {sum(r['gb'] for r in rows if r['tf'] > 0) / steps:.1f} GB, the others "
+LB = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+out.append(f"**Fabric-side traffic of the whole step: {tot_gb / steps:.1f} GB per step = {tot_gb / steps / LB:.2f} GB per sample** "
+           f"({steps} profiled steps of local batch {LB}; MFMA kernels {sum(r['gb'] for r in rows if r['tf'] > 0) / steps:.1f} GB, the others "
            f"{sum(r['gb'] for r in rows if r['tf'] <= 0) / steps:.1f} GB).  At the 6.29 TB/s a copy reaches that alone is "
            f"{tot_gb / steps / 6.29:.1f} ms per step.")
 out.append("")
