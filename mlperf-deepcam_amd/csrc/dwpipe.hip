@@ -517,6 +517,10 @@ int dw_pipe_rows(int dtype, int C, int dil, int N, int H, int W) {
   long wc = 256 / ncb;               // one workgroup per CU
   if (wc < 1) wc = 1;
   if (wc > ptiles) wc = ptiles;
+  // the launch takes as long as its busiest workgroup: keep that number of tiles and use the fewest workgroups that reach it (432 tiles on
+  // 42 workgroups are 11 rounds; so are 40 workgroups, and the other CUs stay free for the weight-gradient stream)
+  const long rounds = (ptiles + wc - 1) / wc;
+  wc = (ptiles + rounds - 1) / rounds;
   return (int)wc;
 }
 
