@@ -221,8 +221,10 @@ int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi
 int dc_bn_stat_rows(long M);
 int dc_bn_stats(int dtype, long M, int C, const void* x, int ldx, float* slab, void* stream);
 /* slab[2][rows][C] -> batch mean / biased var -> scale = gamma*rsqrt(var+eps), shift = beta - mean*scale;
- * running_mean/var (momentum, unbiased var) and num_batches_tracked (int64) are updated when non-NULL. */
-int dc_bn_finalize(int C, long count, const float* slab, int rows, const float* gamma, const float* beta,
+ * running_mean/var (momentum, unbiased var) and num_batches_tracked (int64) are updated when non-NULL.
+ * The slab is CONSUMED: above 4096 rows it is folded in two stages and the first stage leaves its fp64 results in the slab itself
+ * (same for dc_bn_bwd_finalize). */
+int dc_bn_finalize(int C, long count, float* slab, int rows, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                    float eps, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
 /* eval mode: scale/shift from the running statistics */
@@ -238,7 +240,7 @@ int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int lddo, const
                      const void* out, int ldout, int relu, const float* save_mean, const float* save_invstd,
                      float* slab, const float* mscale, const float* mshift, void* stream);
 /* step 2: dgamma, dbeta (fp32, written to the gradient arena) */
-int dc_bn_bwd_finalize(int C, const float* slab, int rows, float* dgamma, float* dbeta, void* stream);
+int dc_bn_bwd_finalize(int C, float* slab, int rows, float* dgamma, float* dbeta, void* stream);
 /* step 3: dy = gamma*invstd*(g - dbeta/count - xhat*dgamma/count);  g is also stored when g_out != NULL */
 int dc_bn_bwd_apply(int dtype, long M, int C, long count, const void* dout, int lddo, const void* y, int ldy,
                     const void* out, int ldout, int relu, const float* gamma, const float* save_mean,

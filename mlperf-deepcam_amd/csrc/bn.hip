@@ -18,11 +18,17 @@ inline int red_rows(long M) {
   r = (r + 31) / 32 * 32;
   return (int)(r < RED_ROWS_MIN ? RED_ROWS_MIN : r);
 }
-constexpr int RED_CG = 32;     // channel groups per block: 512 contiguous bytes per row (256-byte runs measured 25 % slower)
-constexpr int RED_RL = 256 / RED_CG;   // row lanes
+// channel groups per block: 32 = 512 contiguous bytes per row (256-byte runs measured 25 % slower); tensors with fewer channel groups
+// (the 32 / 64 / 128-channel layers) get a block as narrow as the tensor, so that no lane idles on channels that do not exist
+constexpr int RED_CG_MAX = 32;
+inline int narrow_cg(int ngroups, int widest) {
+  int cg = 4;
+  while (cg < widest && cg < ngroups) cg *= 2;
+  return cg;
+}
 
 // Generic two-value column reduction.  F(row vectors...) -> (a[e], b[e]) accumulated per channel element.
-template <typename T, int MODE>
+template <typename T, int MODE, int RED_CG>
 __global__ __launch_bounds__(256) void colred_kernel(long M, int C, int RED_ROWS, const T* __restrict__ p0, int ld0,
                                                      const T* __restrict__ p1, int ld1, const T* __restrict__ p2,
                                                      int ld2, int relu, const float* __restrict__ mean,
@@ -35,6 +41,7 @@ __global__ __launch_bounds__(256) void colred_kernel(long M, int C, int RED_ROWS
   //         recomputed as y*mscale + mshift > 0, the very expression the consumer evaluated
   // MODE 2: column sum of p0       -> (sum x, 0)
   constexpr int KPV = Elem<T>::kPerVec;
+  constexpr int RED_RL = 256 / RED_CG;   // row lanes
   constexpr int CW = RED_CG * KPV;   // channels per block
   __shared__ __attribute__((aligned(16))) float red[2][RED_RL][CW];   // first the per-channel vectors, then the partial sums
   const int cgl = threadIdx.x % RED_CG, rl = threadIdx.x / RED_CG;
@@ -133,6 +140,11 @@ __global__ __launch_bounds__(256) void colred_kernel(long M, int C, int RED_ROWS
   }
 }
 
+__global__ __launch_bounds__(256) void slab_fold_kernel(float* slab, int rows, int C) {
+  __shared__ double red[2][FIN_RL][FIN_CH];
+  slab_fold_block(slab, rows, C, red);
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinArgs a) {
   __shared__ double red[2][FIN_RL][FIN_CH];
   bn_finalize_block(a, blockIdx.x, red);
@@ -179,12 +191,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(long M, int C, const T* _
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, const float* __restrict__ slab, int rows, float* dgamma,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, const float* __restrict__ slab, int rows, int parts, float* dgamma,
                                                               float* dbeta) {
   __shared__ double red[2][FIN_RL][FIN_CH];
   const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
   double s, q;
-  slab_colsum2(slab, slab + (size_t)rows * C, rows, C, c, c < C, red, s, q);
+  slab_colsum2(SlabLoad{slab, slab + (size_t)rows * C, C, c, parts}, parts ? parts : rows, c < C, red, s, q);
   if (threadIdx.x >= FIN_CH || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
@@ -291,11 +303,20 @@ static int launch_colred(long M, int C, const void* p0, int ld0, const void* p1,
                          int relu, const float* mean, const float* invstd, float* slab, hipStream_t st,
                          const float* mscale = nullptr, const float* mshift = nullptr) {
   const int RED_ROWS = red_rows(M);
-  dim3 grid(cdiv(C / Elem<T>::kPerVec, RED_CG), cdiv(M, red_rows(M)));
-  hipLaunchKernelGGL((colred_kernel<T, MODE>), grid, dim3(256), 0, st, M, C, RED_ROWS, (const T*)p0, ld0, (const T*)p1, ld1,
-                     (const T*)p2, ld2, relu, mean, invstd, slab, mscale, mshift);
+  const int ngroups = C / Elem<T>::kPerVec, cg = narrow_cg(ngroups, RED_CG_MAX);
+  dim3 grid(cdiv(ngroups, cg), cdiv(M, red_rows(M)));
+#define DC_COLRED(W) hipLaunchKernelGGL((colred_kernel<T, MODE, W>), grid, dim3(256), 0, st, M, C, RED_ROWS, (const T*)p0, ld0, (const T*)p1, ld1, (const T*)p2, ld2, relu, mean, invstd, slab, mscale, mshift)
+  if (cg == 32) DC_COLRED(32); else if (cg == 16) DC_COLRED(16); else if (cg == 8) DC_COLRED(8); else DC_COLRED(4);
+#undef DC_COLRED
   DC_CHECK_LAUNCH();
   return 0;
+}
+
+// stage one of the two-stage fold of a large slab (bn_fin.h); returns the number of parts stage two reads (0: the slab is read as it is)
+static int fold_large_slab(float* slab, int rows, int C, hipStream_t st) {
+  const int parts = fin_parts(rows);
+  if (parts > 0) hipLaunchKernelGGL(slab_fold_kernel, dim3(cdiv(C, FIN_CH), parts), dim3(256), 0, st, slab, rows, C);
+  return parts;
 }
 
 }  // namespace dc
@@ -330,20 +351,21 @@ extern "C" int dc_colsum(int dtype, long M, int C, const void* dy, int lddy, flo
   if (e) return e;
   // reuse the BN backward finalize: "dbeta" = column sum; the second output goes to the slab's own tail
   const int rows = cdiv(M, red_rows(M));
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, st, C, (const float*)slab, rows,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, st, C, (const float*)slab, rows, 0,
                      slab + (size_t)rows * C, out);
   DC_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int dc_bn_finalize(int C, long count, const float* slab, int rows, const float* gamma, const float* beta,
+extern "C" int dc_bn_finalize(int C, long count, float* slab, int rows, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                               float eps, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
   DC_REQUIRE(C > 0 && rows > 0 && slab && gamma && beta && scale && shift, "dc_bn_finalize: bad argument");
   if (count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
   const double unbias = (double)count / (double)(count - 1);
   BnFinArgs a;
-  a.slab = slab; a.rows = rows; a.C = C; a.inv_count = 1.0 / (double)count; a.unbias = unbias;
+  const int parts = fold_large_slab(slab, rows, C, (hipStream_t)stream);
+  a.slab = slab; a.rows = rows; a.C = C; a.parts = parts; a.inv_count = 1.0 / (double)count; a.unbias = unbias;
   a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
   a.nbt = reinterpret_cast<long long*>(num_batches_tracked); a.momentum = momentum; a.eps = eps;
   a.scale = scale; a.shift = shift; a.save_mean = save_mean; a.save_invstd = save_invstd;
@@ -393,9 +415,10 @@ extern "C" int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int 
                           : launch_colred<float, 1>(M, C, dout, lddo, y, ldy, out, ldout, relu, save_mean, save_invstd, slab, st, mscale, mshift);
 }
 
-extern "C" int dc_bn_bwd_finalize(int C, const float* slab, int rows, float* dgamma, float* dbeta, void* stream) {
+extern "C" int dc_bn_bwd_finalize(int C, float* slab, int rows, float* dgamma, float* dbeta, void* stream) {
   DC_REQUIRE(C > 0 && rows > 0 && slab && dgamma && dbeta, "dc_bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, (hipStream_t)stream, C, slab, rows, dgamma, dbeta);
+  const int parts = fold_large_slab(slab, rows, C, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, (hipStream_t)stream, C, (const float*)slab, rows, parts, dgamma, dbeta);
   DC_CHECK_LAUNCH();
   return 0;
 }
@@ -415,14 +438,15 @@ extern "C" int dc_bn_bwd_apply(int dtype, long M, int C, long count, const void*
   DC_REQUIRE(gamma && save_mean && save_invstd && dgamma && dbeta && M > 0 && count > 0, "dc_bn_bwd_apply: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const int kpv = dtype == DC_BF16 ? 8 : 4;
-  const int APPLY_ROWS = g_bn_rows;
+  // a block as narrow as the tensor (see narrow_cg); the rows per block grow with the row lanes so that every thread has its four rows
+  const int cgw = narrow_cg(C / kpv, g_bn_cgw);
+  const int APPLY_ROWS = g_bn_rows * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
   DC_REQUIRE(cdiv(M, APPLY_ROWS) <= 65535, "dc_bn_bwd_apply: too many rows for one launch");
-  const int cgw = g_bn_cgw;
   const dim3 blocks(cdiv(C / kpv, cgw), cdiv(M, APPLY_ROWS));
   const float inv = 1.0f / (float)count;
 #define BN_BA(TT, W) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, W>), blocks, dim3(256), 0, st, M, C, APPLY_ROWS, inv, (const TT*)dout, lddo, (const TT*)y, ldy, (const TT*)out, ldout, relu, gamma, save_mean, save_invstd, dgamma, dbeta, (TT*)dy, lddy, (TT*)g_out, ldg, mscale, mshift)
-  if (dtype == DC_BF16) { if (cgw == 64) BN_BA(bf16, 64); else if (cgw == 32) BN_BA(bf16, 32); else BN_BA(bf16, 16); }
-  else                  { if (cgw == 64) BN_BA(float, 64); else if (cgw == 32) BN_BA(float, 32); else BN_BA(float, 16); }
+  if (dtype == DC_BF16) { if (cgw == 64) BN_BA(bf16, 64); else if (cgw == 32) BN_BA(bf16, 32); else if (cgw == 16) BN_BA(bf16, 16); else if (cgw == 8) BN_BA(bf16, 8); else BN_BA(bf16, 4); }
+  else                  { if (cgw == 64) BN_BA(float, 64); else if (cgw == 32) BN_BA(float, 32); else if (cgw == 16) BN_BA(float, 16); else if (cgw == 8) BN_BA(float, 8); else BN_BA(float, 4); }
 #undef BN_BA
   DC_CHECK_LAUNCH();
   return 0;

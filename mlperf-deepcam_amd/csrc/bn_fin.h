@@ -9,7 +9,7 @@ namespace dc {
 
 struct BnFinArgs {
   const float* slab;      // [2][rows][C]: sum, sum of squares
-  int rows, C;
+  int rows, C, parts;     // parts > 0: the slab went through slab_fold_kernel (stage-one results in place)
   double inv_count, unbias;
   const float* gamma;
   const float* beta;
@@ -24,13 +24,14 @@ struct BnFinArgs {
 };
 
 // Column sums of a [rows][C] fp32 slab in fp64: 4 channels x 64 row-lanes per 256-thread block, so that even the
-// 3456-row slabs of the 384x576 layers cost ~50 dependent loads per thread instead of thousands.
+// 3456-row slabs of the 192x288 layers cost ~50 dependent loads per thread instead of thousands.  `ld(which, row)` returns element
+// (row, this thread's channel) of slab `which` as a double.
 constexpr int FIN_CH = 4, FIN_RL = 64;
-__device__ inline void slab_colsum2(const float* __restrict__ s0, const float* __restrict__ s1, int rows, int C, int c,
-                                    bool ok, double (&red)[2][FIN_RL][FIN_CH], double& a, double& b) {
+template <typename Load>
+__device__ inline void slab_colsum2(Load ld, int rows, bool ok, double (&red)[2][FIN_RL][FIN_CH], double& a, double& b) {
   const int cl = threadIdx.x & (FIN_CH - 1), rl = threadIdx.x / FIN_CH;
-  // FIN_UR independent partial sums per thread and slab: the 13 824-row slabs of the 384 x 576 layers are 216 rows per thread, and
-  // with two loads in flight the kernel was a chain of ~100 memory latencies (63-83 us); the partials are combined in a fixed order
+  // FIN_UR independent partial sums per thread and slab: with two loads in flight the kernel was a chain of ~100 memory latencies on
+  // the largest slabs; the partials are combined in a fixed order
   constexpr int FIN_UR = 8;
   double xs[FIN_UR], ys[FIN_UR];
 #pragma unroll
@@ -38,24 +39,24 @@ __device__ inline void slab_colsum2(const float* __restrict__ s0, const float* _
   if (ok) {
     int r = rl;
     for (; r + (FIN_UR - 1) * FIN_RL < rows; r += FIN_UR * FIN_RL) {
-      float fx[FIN_UR], fy[FIN_UR];
+      double fx[FIN_UR], fy[FIN_UR];
 #pragma unroll
       for (int u = 0; u < FIN_UR; ++u) {
-        fx[u] = s0[(size_t)(r + u * FIN_RL) * C + c];
-        fy[u] = s1[(size_t)(r + u * FIN_RL) * C + c];
+        fx[u] = ld(0, r + u * FIN_RL);
+        fy[u] = ld(1, r + u * FIN_RL);
       }
 #pragma unroll
       for (int u = 0; u < FIN_UR; ++u) {
-        xs[u] += (double)fx[u];
-        ys[u] += (double)fy[u];
+        xs[u] += fx[u];
+        ys[u] += fy[u];
       }
     }
 #pragma unroll
     for (int u = 0; u < FIN_UR - 1; ++u) {          // at most FIN_UR - 1 rows left (static indices: the partials stay in registers)
       const int rr = r + u * FIN_RL;
       if (rr < rows) {
-        xs[u] += (double)s0[(size_t)rr * C + c];
-        ys[u] += (double)s1[(size_t)rr * C + c];
+        xs[u] += ld(0, rr);
+        ys[u] += ld(1, rr);
       }
     }
   }
@@ -72,13 +73,46 @@ __device__ inline void slab_colsum2(const float* __restrict__ s0, const float* _
   }
 }
 
+// Slabs of thousands of rows (one row per 128-pixel tile of a 384 x 576 layer: 13 824) and few channels leave the finalize kernels with
+// C / 4 workgroups on 256 CUs (8 for the 32-channel stem: 44 - 80 us per launch).  Those slabs are folded in two stages: stage one
+// (slab_fold_kernel, C / 4 x rows / FIN_CHUNK workgroups) sums FIN_CHUNK rows and leaves the fp64 result IN the slab, in the first two
+// rows of its own chunk (low word, high word; rows and channels no other workgroup touches), stage two sums those.
+constexpr int FIN_CHUNK = 512, FIN_TWO_STAGE_ROWS = 4096;
+inline int fin_parts(int rows) {
+  if (rows <= FIN_TWO_STAGE_ROWS || rows % FIN_CHUNK == 1) return 0;      // (a last chunk of one row could not hold its two words)
+  return (rows + FIN_CHUNK - 1) / FIN_CHUNK;
+}
+// the two element loaders: a plain slab, and the stage-one results (parts > 0)
+struct SlabLoad {
+  const float* s0; const float* s1; int C, c, parts;
+  __device__ inline double operator()(int which, int row) const {
+    const float* s = which ? s1 : s0;
+    if (parts == 0) return (double)s[(size_t)row * C + c];
+    const size_t at = (size_t)row * FIN_CHUNK * C + c;
+    const unsigned lo = __float_as_uint(s[at]), hi = __float_as_uint(s[at + C]);
+    return __hiloint2double((int)hi, (int)lo);
+  }
+};
+__device__ inline void slab_fold_block(float* slab, int rows, int C, double (&red)[2][FIN_RL][FIN_CH]) {
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
+  const int r0 = blockIdx.y * FIN_CHUNK;
+  const int n = rows - r0 < FIN_CHUNK ? rows - r0 : FIN_CHUNK;
+  float* s0 = slab + (size_t)r0 * C;
+  float* s1 = slab + ((size_t)rows + r0) * C;
+  double a, b;
+  slab_colsum2(SlabLoad{s0, s1, C, c, 0}, n, c < C, red, a, b);     // ends with a barrier behind every read of the chunk
+  if (threadIdx.x < FIN_CH && c < C) {
+    s0[c] = __uint_as_float((unsigned)__double2loint(a)); s0[C + c] = __uint_as_float((unsigned)__double2hiint(a));
+    s1[c] = __uint_as_float((unsigned)__double2loint(b)); s1[C + c] = __uint_as_float((unsigned)__double2hiint(b));
+  }
+}
 
 // One 4-channel block of dc_bn_finalize (256 threads; red: 4 KiB of LDS).
 __device__ inline void bn_finalize_block(const BnFinArgs& a, int cblock, double (&red)[2][FIN_RL][FIN_CH]) {
   const int C = a.C;
   const int c = cblock * FIN_CH + (threadIdx.x & (FIN_CH - 1));
   double s, q;
-  slab_colsum2(a.slab, a.slab + (size_t)a.rows * C, a.rows, C, c, c < C, red, s, q);
+  slab_colsum2(SlabLoad{a.slab, a.slab + (size_t)a.rows * C, C, c, a.parts}, a.parts ? a.parts : a.rows, c < C, red, s, q);
   if (cblock == 0 && threadIdx.x == 0 && a.nbt != nullptr) *a.nbt += 1;
   if (threadIdx.x >= FIN_CH || c >= C) return;
   const double mean = s * a.inv_count;

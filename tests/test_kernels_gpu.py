@@ -1044,7 +1044,8 @@ def test_depthwise_with_fused_bn_prologue(case, dtype, prelu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(2, 728, 12, 10), (2, 32, 40, 33), (2, 256, 1, 1)], ids=["c728", "c32", "pool"])
+@pytest.mark.parametrize("shape", [(2, 728, 12, 10), (2, 32, 40, 33), (2, 256, 1, 1), (2, 64, 37, 29), (2, 128, 19, 23), (3, 24, 17, 9)],
+                         ids=["c728", "c32", "pool", "c64", "c128", "c24"])
 @pytest.mark.parametrize("relu,use_res", [(1, 0), (1, 1), (0, 1), (0, 0)])
 def test_batchnorm_train_fwd_bwd(shape, dtype, relu, use_res):
     N, Cc, H, W = shape
@@ -1106,6 +1107,35 @@ def test_batchnorm_train_fwd_bwd(shape, dtype, relu, use_res):
     assert_close(dbeta.cpu(), grads[2], dtype, f32=5e-4, bf16=2e-2)
     if use_res:
         assert_close(from_nhwc(gv), grads[3], dtype, bf16=1e-2)
+
+
+@pytest.mark.parametrize("rows,Cc", [(13824, 32), (6912, 256), (4097, 64), (4611, 24), (5000, 728), (4096, 32)],
+                         ids=["r13824c32", "r6912c256", "r4097c64_fallback", "r4611c24_ragged", "r5000c728", "r4096_single"])
+def test_finalize_of_large_slabs_in_two_stages(rows, Cc):
+    """Slabs above 4096 rows (one row per 128-pixel tile of the 384 x 576 layers) are folded in two stages, the first leaving its fp64
+    results in the slab (bn_fin.h); forward and backward finalize against fp64 column sums of the same slab."""
+    g = torch.Generator().manual_seed(rows + Cc)
+    M = rows * 128
+    sx = torch.randn(rows, Cc, generator=g) * 20 + 64          # sum x per tile
+    sq = sx * sx / 128 + torch.rand(rows, Cc, generator=g) * 300   # sum x^2 per tile (var > 0)
+    slab = torch.stack([sx, sq]).contiguous().to(dev())
+    ref_s, ref_q = sx.double().sum(0), sq.double().sum(0)
+    gam, bet = (torch.rand(Cc, generator=g) + 0.5).to(dev()), torch.randn(Cc, generator=g).to(dev())
+    scale, shift, smean, sinv = (torch.empty(Cc, device=dev()) for _ in range(4))
+    slab_b = slab.clone()
+    L.call("dc_bn_finalize", Cc, M, vptr(slab), rows, vptr(gam), vptr(bet), None, None, None, 0.1, 1e-5, vptr(scale), vptr(shift),
+           vptr(smean), vptr(sinv), S())
+    dg, db = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
+    L.call("dc_bn_bwd_finalize", Cc, vptr(slab_b), rows, vptr(dg), vptr(db), S())
+    torch.cuda.synchronize()
+    mean = ref_s / M
+    var = (ref_q / M - mean * mean).clamp_min(0)
+    inv = 1.0 / torch.sqrt(var + 1e-5)
+    np.testing.assert_allclose(smean.cpu().numpy(), mean.float().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(sinv.cpu().numpy(), inv.float().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(scale.cpu().numpy(), (gam.cpu().double() * inv).float().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(db.cpu().numpy(), ref_s.float().numpy(), rtol=1e-6)          # "dbeta" = column sum of slab 0
+    np.testing.assert_allclose(dg.cpu().numpy(), ref_q.float().numpy(), rtol=1e-6)
 
 
 def test_bn_single_value_per_channel_raises():
