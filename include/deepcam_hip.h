@@ -222,7 +222,7 @@ int dc_bn_stat_rows(long M);
 int dc_bn_stats(int dtype, long M, int C, const void* x, int ldx, float* slab, void* stream);
 /* slab[2][rows][C] -> batch mean / biased var -> scale = gamma*rsqrt(var+eps), shift = beta - mean*scale;
  * running_mean/var (momentum, unbiased var) and num_batches_tracked (int64) are updated when non-NULL.
- * The slab is CONSUMED: above 4096 rows it is folded in two stages and the first stage leaves its fp64 results in the slab itself
+ * The slab is CONSUMED: above 1024 rows it is folded in two stages and the first stage leaves its fp64 results in the slab itself
  * (same for dc_bn_bwd_finalize). */
 int dc_bn_finalize(int C, long count, float* slab, int rows, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,

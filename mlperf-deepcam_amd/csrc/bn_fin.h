@@ -73,11 +73,12 @@ __device__ inline void slab_colsum2(Load ld, int rows, bool ok, double (&red)[2]
   }
 }
 
-// Slabs of thousands of rows (one row per 128-pixel tile of a 384 x 576 layer: 13 824) and few channels leave the finalize kernels with
-// C / 4 workgroups on 256 CUs (8 for the 32-channel stem: 44 - 80 us per launch).  Those slabs are folded in two stages: stage one
-// (slab_fold_kernel, C / 4 x rows / FIN_CHUNK workgroups) sums FIN_CHUNK rows and leaves the fp64 result IN the slab, in the first two
-// rows of its own chunk (low word, high word; rows and channels no other workgroup touches), stage two sums those.
-constexpr int FIN_CHUNK = 512, FIN_TWO_STAGE_ROWS = 4096;
+// Slabs of thousands of rows (one row per 128-pixel tile: 3456 on the 192 x 288 layers, 13 824 on the 384 x 576 ones) leave the finalize
+// kernels with C / 4 workgroups of 50 - 200 dependent rows per thread (8 workgroups for the 32-channel stem; 36 - 80 us per launch).
+// Those slabs are folded in two stages: stage one (slab_fold_kernel, C / 4 x rows / FIN_CHUNK workgroups) sums FIN_CHUNK rows and leaves
+// the fp64 result IN the slab, in the first two rows of its own chunk (low word, high word; rows and channels no other workgroup
+// touches), stage two sums those.
+constexpr int FIN_CHUNK = 256, FIN_TWO_STAGE_ROWS = 1024;
 inline int fin_parts(int rows) {
   if (rows <= FIN_TWO_STAGE_ROWS || rows % FIN_CHUNK == 1) return 0;      // (a last chunk of one row could not hold its two words)
   return (rows + FIN_CHUNK - 1) / FIN_CHUNK;

@@ -218,7 +218,18 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const ThinFwdArgs a) {
   for (int c = 0; c < MB * 4; ++c) ssum[c] = ssq[c] = 0.f;
   bf16* __restrict__ yout = reinterpret_cast<bf16*>(a.out);
   const int chunks = (a.M + 255) / 256;
-  for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+  // Workgroups of one XCD (equal id mod 8) walk ONE contiguous eighth of the pixel chunks together: the rows above and below a chunk
+  // are then read by workgroups that share its L2 at about the same time.  (Round-robin over all chunks put the three readers of an
+  // input row on three XCDs: 2.4x the compulsory bytes crossed the fabric, profiles/r04_roofline_table_b8.md.)
+  int cbeg = 0, cend = chunks, cfirst = blockIdx.x, cstep = gridDim.x;
+  if (gridDim.x >= 8) {
+    const int xcd = blockIdx.x & 7;
+    cbeg = (int)((long)chunks * xcd / 8);
+    cend = (int)((long)chunks * (xcd + 1) / 8);
+    cfirst = cbeg + (blockIdx.x >> 3);
+    cstep = (gridDim.x - xcd + 7) >> 3;          // workgroups on this XCD
+  }
+  for (int chunk = cfirst; chunk < cend; chunk += cstep) {
     const int mbase = chunk * 256 + wave * 64;
     // pixel coordinates of this lane's pixel in each of the 4 pixel blocks
     int iy0[PB], ix0[PB];

@@ -23,7 +23,7 @@ with open(sys.argv[2], "w") as out:
         s, e, q = int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "")
         gap = (s - last_end[q]) / 1e3 if q in last_end else 0.0
         last_end[q] = e
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dc::", "").replace("(anonymous namespace)::", "")
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("dc::", "")
         if name.startswith("_ZN2dc"):
             name = name[6:40]
         grid = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)

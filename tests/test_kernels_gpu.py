@@ -1109,10 +1109,10 @@ def test_batchnorm_train_fwd_bwd(shape, dtype, relu, use_res):
         assert_close(from_nhwc(gv), grads[3], dtype, bf16=1e-2)
 
 
-@pytest.mark.parametrize("rows,Cc", [(13824, 32), (6912, 256), (4097, 64), (4611, 24), (5000, 728), (4096, 32)],
-                         ids=["r13824c32", "r6912c256", "r4097c64_fallback", "r4611c24_ragged", "r5000c728", "r4096_single"])
+@pytest.mark.parametrize("rows,Cc", [(13824, 32), (3456, 256), (1025, 64), (4611, 24), (5000, 728), (1024, 32), (16385, 8)],
+                         ids=["r13824c32", "r3456c256", "r1025c64_fallback", "r4611c24_ragged", "r5000c728", "r1024_single", "r16385_fallback"])
 def test_finalize_of_large_slabs_in_two_stages(rows, Cc):
-    """Slabs above 4096 rows (one row per 128-pixel tile of the 384 x 576 layers) are folded in two stages, the first leaving its fp64
+    """Slabs above 1024 rows (one row per 128-pixel tile of the 192 x 288 and 384 x 576 layers) are folded in two stages, the first leaving its fp64
     results in the slab (bn_fin.h); forward and backward finalize against fp64 column sums of the same slab."""
     g = torch.Generator().manual_seed(rows + Cc)
     M = rows * 128
