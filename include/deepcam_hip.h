@@ -303,6 +303,14 @@ int dc_head_fwd_loss_bnin(int dtype, int N, int Cin, int Hi, int Wi, const void*
 int dc_head_bwd_bnin(int dtype, int N, int Cin, int Hi, int Wi, const void* y, int ldy, const float* scale, const float* shift,
                      int relu, const float* dlogits_nchw, const float* w, void* dx, int lddx, float* grad_w, void* workspace,
                      const float* bn_mean, const float* bn_invstd, float* bn_slab, int parts, void* stream);
+/* dx == NULL in dc_head_bwd_bnin (bf16, 256 channels, bn_slab given): the head's data gradient -- 906 MB at local batch 8, read once, by that
+ * BatchNorm's backward -- is not stored; the sums are taken all the same.  After dc_bn_bwd_finalize(bn_slab) this second pass forms the
+ * gradient again (one MFMA step from the gathered image still in `workspace`) and writes the BatchNorm INPUT's gradient
+ * dy = gamma*invstd*(g - dbeta/count - xhat*dgamma/count), bit-equal to the stored-dx path + dc_bn_bwd_apply(relu = 2): the pair moves
+ * 2.9 GB instead of 4.6 (deeplab_xception.py:371-374 backward). */
+int dc_head_bwd_bnin_apply(int dtype, int N, int Cin, int Hi, int Wi, const void* y, int ldy, const float* scale, const float* shift,
+                           int relu, const float* gamma, const float* bn_mean, const float* bn_invstd, const float* dgamma,
+                           const float* dbeta, long count, void* dy, int lddy, void* workspace, void* stream);
 
 /* NCHW fp32 (the layout train_hdf5_ddp.py:348 hands over) -> NHWC `dtype`: the one layout pass of the step. */
 int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, void* out, int ldo, void* stream);

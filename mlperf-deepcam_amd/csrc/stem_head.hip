@@ -775,6 +775,12 @@ extern "C" int dc_conv_dgrad_bnstats(const dc_conv_desc* d, int N, int Hi, int W
 // fragment and (BST) the BatchNorm input at its own outputs straight from memory, four pixel groups in flight; the output leaves from
 // the accumulators.  BST: the BatchNorm-backward sums of dc_conv_dgrad_bnstats (sum g, sum g * xhat, g masked by the ReLU recomputed
 // from y), one slab row per 128 pixels as there.  Same MFMA per output element as the tiled kernels: dx bit-equal.
+//
+// The gradient dx is 906 MB at local batch 8 and its only reader is that BatchNorm's backward, so it need not exist: MODE HD_SUMS takes
+// the sums without storing dx, and -- once dc_bn_bwd_finalize has made dgamma / dbeta of them -- MODE HD_APPLY forms the same dx again
+// (one MFMA step from the 64-byte gathered gradient row) and writes dy = gamma*invstd*(g - dbeta/count - xhat*dgamma/count) directly,
+// element for element the arithmetic of bn_bwd_apply_kernel on the rounded dx (bn.hip): 2.9 GB of traffic for the pair instead of 4.6.
+enum { HD_STORE = 0, HD_SUMS = 1, HD_APPLY = 2 };
 struct HeadDgradBst {
   const bf16* y;
   int ldy;
@@ -785,6 +791,11 @@ struct HeadDgradBst {
   int relu;
   float* slab;     // [2][rows][256]
   int rows;
+  // HD_APPLY only
+  const float* gamma;
+  const float* dgamma;
+  const float* dbeta;
+  float inv_count;
 };
 
 __device__ inline float head_row_sum16(float v) {      // sum over the 16 lanes of a DPP row (the 16 pixels of a group)
@@ -797,10 +808,11 @@ __device__ inline float head_row_sum16(float v) {      // sum over the 16 lanes 
 
 __device__ inline uint32_t head_swap_rows16(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); }   // lane ^ 16
 
-template <bool BST>
+template <int MODE>
 __global__ __launch_bounds__(256) void head_dgrad_kernel(const bf16* __restrict__ dP, const bf16* __restrict__ wb, bf16* __restrict__ dx,
                                                          int lddx, long M, const HeadDgradBst b) {
   constexpr int CIN = 256, GPB = 4;                     // pixel groups (of 16) requested together
+  constexpr bool BST = true, SUMS = MODE != HD_APPLY, APPLY = MODE == HD_APPLY;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const bool odd = fg & 1;
@@ -812,7 +824,7 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const bf16* __restrict_
   // (igemm256.hip's register epilogue), after which a lane owns EIGHT consecutive channels of its pixel per block pair p:
   //   cpair(p) = 64 * wave + (2 * p + odd) * 16 + (fg >> 1) * 8      -> 16-byte stores, 16-byte BatchNorm-input loads
   auto cpair = [&](int p) { return 64 * wave + (2 * p + (odd ? 1 : 0)) * 16 + (fg >> 1) * 8; };
-  [[maybe_unused]] float mu[2][8], is[2][8], ms[2][8], mh[2][8];
+  [[maybe_unused]] float mu[2][8], is[2][8], ms[2][8], mh[2][8], cb[2][8], cd[2][8];    // APPLY: is[] holds ca = gamma * invstd
   if constexpr (BST) {
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -823,12 +835,19 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const bf16* __restrict_
         is[p][e] = b.invstd[c];
         ms[p][e] = b.relu ? b.mscale[c] : 0.f;
         mh[p][e] = b.relu ? b.mshift[c] : 0.f;
+        if constexpr (APPLY) {      // the coefficients of bn_bwd_apply_kernel, expression for expression
+          const float inv = is[p][e];
+          const float ca = b.gamma[c] * inv;
+          cb[p][e] = -ca * inv * b.dgamma[c] * b.inv_count;
+          cd[p][e] = -ca * b.dbeta[c] * b.inv_count;
+          is[p][e] = ca;
+        }
       }
   }
   const long chunks = (M + 127) / 128;
   for (long chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
     [[maybe_unused]] float s0[2][8], s1[2][8];
-    if constexpr (BST) {
+    if constexpr (SUMS) {
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -865,8 +884,25 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const bf16* __restrict_
           o.w[1] = odd ? r1 : a1;
           o.w[2] = odd ? b0 : r0;
           o.w[3] = odd ? b1 : r1;
-          if (ok[u]) stg16(dx + (size_t)px * lddx + cpair(p), o);
-          if constexpr (BST) {
+          if constexpr (MODE == HD_STORE) {
+            if (ok[u]) stg16(dx + (size_t)px * lddx + cpair(p), o);
+          }
+          if constexpr (APPLY) {
+            if (ok[u]) {
+              float f[8], yf[8];
+              unpack(o, f, bf16());
+              unpack(yv[u][p], yf, bf16());
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float gm = (!b.relu || fmaf(yf[e], ms[p][e], mh[p][e]) > 0.f) ? f[e] : 0.f;
+                f[e] = fmaf(is[p][e], gm, fmaf(cb[p][e], yf[e] - mu[p][e], cd[p][e]));
+              }
+              vec16 v;
+              pack(v, f, bf16());
+              stg16(dx + (size_t)px * lddx + cpair(p), v);      // dx: the BatchNorm input's gradient here
+            }
+          }
+          if constexpr (SUMS) {
             if (ok[u]) {
               // the stored (bf16-rounded) gradient and the BatchNorm input, element for element as the tiled kernels' epilogue
               float f[8], yf[8];
@@ -883,7 +919,7 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const bf16* __restrict_
         }
       }
     }
-    if constexpr (BST) {
+    if constexpr (SUMS) {
       // fold the 16 pixels of a group (the lanes of a DPP row); lane fr == 0 of every row then owns its eight channels of every pair
 #pragma unroll
       for (int p = 0; p < 2; ++p)
@@ -917,7 +953,13 @@ static int head_bwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* 
     DC_REQUIRE(bn_y != nullptr && bn_mscale != nullptr && bn_mshift != nullptr && dtype == DC_BF16, "dc_head_bwd_bnin: needs the BatchNorm input and its forward scale / shift (bf16)");
     if (int e = dc_check_view(bn_y, bn_ldy, Cin, dtype, "dc_head_bwd_bnin y")) return e;
   }
-  if (int e = dc_check_view(dx, lddx, Cin, dtype, "dc_head_bwd dx")) return e;
+  const bool streaming = dtype == DC_BF16 && Cin == 256 && g_head_dgrad_fused && bn_y != nullptr && bn_slab != nullptr;
+  if (dx != nullptr) {
+    if (int e = dc_check_view(dx, lddx, Cin, dtype, "dc_head_bwd dx")) return e;
+  } else {
+    // dx == NULL: only the BatchNorm's sums are wanted (dc_head_bwd_bnin_apply writes that BatchNorm's input gradient later)
+    DC_REQUIRE(streaming || !(parts & 1), "dc_head_bwd: dx may be NULL only where the streaming data-gradient kernel takes the BatchNorm sums (bf16, 256 channels)");
+  }
   DC_REQUIRE(w && dlogits_nchw && grad_w && workspace && N > 0 && (parts & 3) != 0 && (parts & ~3) == 0, "dc_head_bwd: bad argument");
   DC_REQUIRE(((uintptr_t)workspace & 255) == 0, "dc_head_bwd: workspace must be 256-byte aligned");
   HeadWs ws = head_ws(dtype, N, Cin, Hi, Wi, workspace);
@@ -946,14 +988,17 @@ static int head_bwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* 
     DC_CHECK_LAUNCH();
   }
   if (!(parts & 1)) return 0;
-  if (dtype == DC_BF16 && Cin == 256 && g_head_dgrad_fused && bn_y != nullptr && bn_slab != nullptr) {
+  if (streaming) {
     // (without the BatchNorm sums the streaming kernel has too little in flight per wave and loses to the tiled kernels: 755 vs 714 us)
     const int chunks = cdiv(P, 128);
     const int grid = chunks < 2048 ? chunks : 2048;
     if (int e = dc_check_view(bn_y, bn_ldy, Cin, dtype, "dc_head_bwd bn_y")) return e;
     DC_REQUIRE(bn_mean && bn_invstd && (!bn_relu || (bn_mscale && bn_mshift)), "dc_head_bwd: missing BatchNorm vectors");
-    const HeadDgradBst b{(const bf16*)bn_y, bn_ldy, bn_mean, bn_invstd, bn_mscale, bn_mshift, bn_relu, bn_slab, chunks};
-    hipLaunchKernelGGL(head_dgrad_kernel<true>, dim3(grid), dim3(256), 0, st, (const bf16*)ws.dP, (const bf16*)ws.wb, (bf16*)dx, lddx, (long)P, b);
+    const HeadDgradBst b{(const bf16*)bn_y, bn_ldy, bn_mean, bn_invstd, bn_mscale, bn_mshift, bn_relu, bn_slab, chunks, nullptr, nullptr, nullptr, 0.f};
+    if (dx != nullptr)
+      hipLaunchKernelGGL(head_dgrad_kernel<HD_STORE>, dim3(grid), dim3(256), 0, st, (const bf16*)ws.dP, (const bf16*)ws.wb, (bf16*)dx, lddx, (long)P, b);
+    else
+      hipLaunchKernelGGL(head_dgrad_kernel<HD_SUMS>, dim3(grid), dim3(256), 0, st, (const bf16*)ws.dP, (const bf16*)ws.wb, (bf16*)nullptr, 0, (long)P, b);
     DC_CHECK_LAUNCH();
     return 0;
   }
@@ -987,6 +1032,29 @@ extern "C" int dc_head_bwd_bnin(int dtype, int N, int Cin, int Hi, int Wi, const
   DC_REQUIRE(bn_slab == nullptr || (bn_mean != nullptr && bn_invstd != nullptr), "dc_head_bwd_bnin: the BatchNorm sums need mean and invstd");
   return head_bwd_impl(dtype, N, Cin, Hi, Wi, nullptr, 0, dlogits_nchw, w, dx, lddx, grad_w, workspace, stream, y, ldy, bn_mean, bn_invstd, scale,
                        shift, relu, bn_slab, parts);
+}
+
+// Second pass of dc_head_bwd_bnin(..., dx = NULL, bn_slab, parts & 1): the head's data gradient is formed again from the gathered gradient
+// image that call left in `workspace` and leaves as the BatchNorm INPUT's gradient dy (see head_dgrad_kernel, HD_APPLY); dgamma / dbeta
+// are dc_bn_bwd_finalize's outputs for the slab of the first pass.  Bit-equal to dc_head_bwd_bnin with a stored dx + dc_bn_bwd_apply(relu = 2).
+extern "C" int dc_head_bwd_bnin_apply(int dtype, int N, int Cin, int Hi, int Wi, const void* y, int ldy, const float* scale, const float* shift,
+                                      int relu, const float* gamma, const float* bn_mean, const float* bn_invstd, const float* dgamma,
+                                      const float* dbeta, long count, void* dy, int lddy, void* workspace, void* stream) {
+  DC_REQUIRE(dtype == DC_BF16 && Cin == 256 && g_head_dgrad_fused, "dc_head_bwd_bnin_apply: served by the streaming data-gradient kernel only (bf16, 256 channels)");
+  DC_REQUIRE(y && gamma && bn_mean && bn_invstd && dgamma && dbeta && workspace && N > 0 && count > 0 && (!relu || (scale && shift)),
+             "dc_head_bwd_bnin_apply: bad argument");
+  DC_REQUIRE(((uintptr_t)workspace & 255) == 0, "dc_head_bwd_bnin_apply: workspace must be 256-byte aligned");
+  if (int e = dc_check_view(y, ldy, Cin, dtype, "dc_head_bwd_bnin_apply y")) return e;
+  if (int e = dc_check_view(dy, lddy, Cin, dtype, "dc_head_bwd_bnin_apply dy")) return e;
+  HeadWs ws = head_ws(dtype, N, Cin, Hi, Wi, workspace);
+  const long P = (long)N * Hi * Wi;
+  const int chunks = cdiv(P, 128);
+  const int grid = chunks < 2048 ? chunks : 2048;
+  const HeadDgradBst b{(const bf16*)y, ldy, bn_mean, bn_invstd, scale, shift, relu, nullptr, chunks, gamma, dgamma, dbeta, 1.0f / (float)count};
+  hipLaunchKernelGGL(head_dgrad_kernel<HD_APPLY>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)ws.dP, (const bf16*)ws.wb, (bf16*)dy,
+                     lddy, (long)P, b);
+  DC_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int dc_nchw_to_nhwc(int dtype, int N, int C, int H, int W, const float* x_nchw, void* out, int ldo, void* stream) {

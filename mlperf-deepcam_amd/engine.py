@@ -176,6 +176,9 @@ class Engine:
         # (dc_head_fwd_loss_bnin / dc_head_bwd_bnin): the 256-channel 384 x 576 activation is never stored (at local batch 8: a 0.35 ms
         # dc_bn_apply pass and 1.8 GB of traffic less per step).  bf16 only (the fused head kernel).
         self.fuse_bn_into_head = dtype == torch.bfloat16 and os.environ.get("DC_FUSE_BN_INTO_HEAD", "1") != "0"
+        # the head's data gradient (906 MB at local batch 8, read once) is not stored: the head's kernel takes the BatchNorm sums in a first
+        # pass and writes the BatchNorm input's gradient itself in a second one (dc_head_bwd_bnin_apply)
+        self.fuse_head_apply = os.environ.get("DC_FUSE_HEAD_APPLY", "1") != "0"
         # depthwise weight gradient taken inside the depthwise data gradient (dc_dwconv_dgrad_bnstats_wgrad) where the layer's input is a
         # never-stored BatchNorm output: the separate dc_dwconv_wgrad launch (and its second read of dy and y) disappears.  On the tiled
         # kernel the fusion held 232 registers (two workgroups per CU instead of three) and paid from local batch 8 only; on the persistent
@@ -564,7 +567,8 @@ class Engine:
         bslab = self._f32(2 * brows * Cc)
 
         def make_bwd():
-            do = lz.grad if lazy else o.grad
+            apply_by = getattr(lz, "apply_by", None) if lazy else None      # the consumer writes dy itself (the head, two passes)
+            do = None if apply_by is not None else (lz.grad if lazy else o.grad)
             assert y.take_grad_mode() == 0, "a conv output feeds exactly one BatchNorm"
             dy = y.grad
             g_out = None
@@ -591,6 +595,9 @@ class Engine:
                            L.dptr(invstd), L.dptr(bslab), L.dptr(scale), L.dptr(shift), self._st())
                 if self._debug_skip_finalize not in ("bwd", "both"):
                     L.call("dc_bn_bwd_finalize", Cc, L.dptr(rslab), rrows, dgam, dbet, self._st())
+                if apply_by is not None:
+                    apply_by(gam, dgam, dbet, dy)
+                    return
                 L.call("dc_bn_bwd_apply", bdt, M, Cc, M, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, gam, L.dptr(mean),
                        L.dptr(invstd), dgam, dbet, dy.ptr, dy.ld, g_out.ptr if g_out is not None else None,
                        g_out.ld if g_out is not None else 0, L.dptr(scale), L.dptr(shift), self._st())
@@ -817,8 +824,9 @@ class Engine:
 
         def head_bwd_make():
             assert a.take_grad_mode() == 0
-            da = a.grad
             bsrc = getattr(a, "bn_src", None) if self.fuse_bn_head else None
+            two_pass = lazy_in and self.fuse_bn_head and self.fuse_head_apply and self.dt == L.DC_BF16
+            da = None if two_pass else a.grad
             if lazy_in:
                 bsrc = None
                 sslab = None
@@ -826,6 +834,11 @@ class Engine:
                     srows = (a.M + 127) // 128
                     sslab = self._f32(2 * srows * 256)
                     a.fused_bwd = (sslab, srows)
+                if two_pass:
+                    def head_apply(gam, dgam, dbet, dy):       # called by the BatchNorm's backward behind its dc_bn_bwd_finalize
+                        L.call("dc_head_bwd_bnin_apply", self.dt, B, 256, a.H, a.W, a.y.ptr, a.y.ld, L.dptr(a.scale), L.dptr(a.shift), int(a.relu),
+                               gam, L.dptr(a.mean), L.dptr(a.invstd), dgam, dbet, a.M, dy.ptr, dy.ld, hptr, self._st())
+                    a.apply_by = head_apply
             elif bsrc is not None:
                 srows = (a.M + 127) // 128
                 sslab = self._f32(2 * srows * 256)
@@ -838,7 +851,8 @@ class Engine:
                     # batch 8) behind it on the weight-gradient stream like every other one
                     def call(parts):
                         L.call("dc_head_bwd_bnin", self.dt, B, 256, a.H, a.W, a.y.ptr, a.y.ld, L.dptr(a.scale), L.dptr(a.shift), int(a.relu),
-                               L.dptr(self.dlogits), self.pptr(wl), da.ptr, da.ld, self.gptr(wl), hptr, L.dptr(a.mean), L.dptr(a.invstd),
+                               L.dptr(self.dlogits), self.pptr(wl), da.ptr if da is not None else None, da.ld if da is not None else 0,
+                               self.gptr(wl), hptr, L.dptr(a.mean), L.dptr(a.invstd),
                                L.dptr(sslab) if sslab is not None else None, parts, self._st())
                     call(1)
                     self._on_side(lambda ws_: call(2))

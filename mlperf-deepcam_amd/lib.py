@@ -102,6 +102,7 @@ _SIGS = {
     "dc_head_fwd_bnin": (I, [I, I, I, I, I, P, I, P, P, I, P, P, P, P]),
     "dc_head_fwd_loss_bnin": (I, [I, I, I, I, I, P, I, P, P, I, P, P, P, P, I, P, F, P, P, P, P, P]),
     "dc_head_bwd_bnin": (I, [I, I, I, I, I, P, I, P, P, I, P, P, P, I, P, P, P, P, P, I, P]),
+    "dc_head_bwd_bnin_apply": (I, [I, I, I, I, I, P, I, P, P, I, P, P, P, P, P, L, P, I, P, P]),
     "dc_nchw_to_nhwc": (I, [I, I, I, I, I, P, P, I, P]),
     "dc_input_normalize_hwc": (I, [I, L, I, I, P, P, P, P, P, I, P]),
     "dc_input_normalize_hwc_to_nchw": (I, [I, L, I, I, P, P, P, P, P, P]),

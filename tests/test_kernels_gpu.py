@@ -1405,6 +1405,35 @@ def test_head_on_unstored_batchnorm_output(shape, relu):
         assert not torch.isnan(gw).any()
         assert (gw - ref_gw).abs().max().item() <= 1e-5 * ref_gw.abs().max().item()
         print(f"[head weight gradient, register-staged vs LDS-DMA kernel] bit-equal: {torch.equal(gw, ref_gw)}")
+    # two passes, the data gradient never stored: sums with dx = NULL, dc_bn_bwd_finalize, then dc_head_bwd_bnin_apply writes the BatchNorm
+    # input's gradient -- against the stored dx + dc_bn_bwd_apply (mask recomputed from y), bit for bit
+    gamma = (rnd(Cin, seed=11).abs() + 0.4).to(dev())
+    dg, db = torch.empty(Cin, device=dev()), torch.empty(Cin, device=dev())
+    slab_c = ref_slab.clone()               # (the finalize consumes its slab)
+    L.call("dc_bn_bwd_finalize", Cin, vptr(slab_c), rows, vptr(dg), vptr(db), S())
+    _, ref_dy = empty_nhwc(N, H, W, Cin, dtype, ld=Cin + 8)
+    L.call("dc_bn_bwd_apply", dt, M, Cin, M, vptr(ref_dx), Cin, vptr(yv), Cin + 16, None, 0, 2 if relu else 0, vptr(gamma), vptr(mean), vptr(invstd),
+           vptr(dg), vptr(db), vptr(ref_dy), Cin + 8, None, 0, vptr(scale), vptr(shift), S())
+    slab = torch.full((2, rows, Cin), float("nan"), device=dev())
+    gw = torch.full((Cin, 3, 3, 3), float("nan"), device=dev())
+    L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, vptr(yv), Cin + 16, vptr(scale), vptr(shift), relu, vptr(ref_dl), vptr(wd), None, 0,
+           vptr(gw), wsp, vptr(mean), vptr(invstd), vptr(slab), 1, S())
+    torch.cuda.synchronize()
+    assert torch.equal(slab, ref_slab)
+    dg2, db2 = torch.empty(Cin, device=dev()), torch.empty(Cin, device=dev())
+    L.call("dc_bn_bwd_finalize", Cin, vptr(slab), rows, vptr(dg2), vptr(db2), S())
+    _, dy = empty_nhwc(N, H, W, Cin, dtype, ld=Cin + 8)
+    L.call("dc_head_bwd_bnin_apply", dt, N, Cin, H, W, vptr(yv), Cin + 16, vptr(scale), vptr(shift), relu, vptr(gamma), vptr(mean), vptr(invstd),
+           vptr(dg2), vptr(db2), M, vptr(dy), Cin + 8, wsp, S())
+    L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, vptr(yv), Cin + 16, vptr(scale), vptr(shift), relu, vptr(ref_dl), vptr(wd), None, 0,
+           vptr(gw), wsp, vptr(mean), vptr(invstd), None, 2, S())                      # the weight-gradient part still runs without a dx
+    torch.cuda.synchronize()
+    assert torch.equal(dg, dg2) and torch.equal(db, db2)
+    assert torch.equal(from_nhwc(dy), from_nhwc(ref_dy))
+    assert (gw - ref_gw).abs().max().item() <= 1e-5 * ref_gw.abs().max().item()
+    with pytest.raises(L.DeepcamHipError, match="dx may be NULL only"):
+        L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, vptr(yv), Cin + 16, vptr(scale), vptr(shift), relu, vptr(ref_dl), vptr(wd), None, 0,
+               vptr(gw), wsp, vptr(mean), vptr(invstd), None, 1, S())
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
