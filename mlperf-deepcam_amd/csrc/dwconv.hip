@@ -550,7 +550,12 @@ extern "C" int dc_dwconv_dgrad_bnstats(int dtype, int C, int stride, int dil, in
 // layer's forward input is act(ybn*mscale + mshift) (the never-stored BatchNorm output), so nothing is read that the data gradient
 // with statistics does not read already.
 extern "C" int dc_dwconv_dgrad_wgrad_rows(int dtype, int C, int stride, int dil, int N, int Hi, int Wi) {
-  if (stride != 1 || (dil != 1 && dil != 2) || !g_dw_tile) return 0;
+  if (!g_dw_tile) return 0;
+  if (stride == 2 && dil == 1) {          // the stride-2 data-gradient kernel walks its tiles: one row per workgroup
+    const int rows = dc_dwconv_dgrad_bnstats_rows(dtype, C, stride, dil, N, Hi, Wi);
+    return rows > 0 && rows <= DWT_MAX_ROWS ? rows : 0;
+  }
+  if (stride != 1 || (dil != 1 && dil != 2)) return 0;
   if (dc_dwconv_dgrad_bnstats_rows(dtype, C, stride, dil, N, Hi, Wi) <= 0) return 0;
   const int pr = dw_pipe_rows(dtype, C, dil, N, Hi, Wi);
   if (pr > 0) return pr;
@@ -571,6 +576,7 @@ extern "C" int dc_dwconv_dgrad_bnstats_wgrad(int dtype, int C, int stride, int d
   DwBnStats bs;
   bs.y = ybn; bs.ldy = ldybn; bs.mean = save_mean; bs.invstd = save_invstd; bs.mscale = mscale; bs.mshift = mshift; bs.relu = relu ? 1 : 0;
   bs.slab = slab; bs.rows = 0; bs.wslab = wslab;
+  if (stride == 2) return launch_dw_tile_s2(dtype, 1, N, Hi, Wi, C, dy, lddy, w, nullptr, 0, dx, lddx, nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, 0, &bs);
   return launch_dw_tile(dtype, dil, true, dy, lddy, w, nullptr, 0, dx, lddx, N, Hi, Wi, C, (hipStream_t)stream, nullptr, nullptr, 0, &bs);
 }
 
@@ -591,6 +597,7 @@ extern "C" int dc_dwconv_dgrad_wgrad(int dtype, int C, int stride, int dil, int 
   DwBnStats bs;
   bs.y = x; bs.ldy = ldx; bs.mean = bs.invstd = nullptr; bs.mscale = pscale; bs.mshift = pshift; bs.relu = (pscale != nullptr && prelu) ? 1 : 0;
   bs.slab = nullptr; bs.rows = 0; bs.wslab = wslab;
+  if (stride == 2) return launch_dw_tile_s2(dtype, 1, N, Hi, Wi, C, dy, lddy, w, addend, ldadd, dx, lddx, nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, 0, &bs);
   return launch_dw_tile(dtype, dil, true, dy, lddy, w, addend, ldadd, dx, lddx, N, Hi, Wi, C, (hipStream_t)stream, nullptr, nullptr, 0, &bs);
 }
 

@@ -125,104 +125,145 @@ __global__ __launch_bounds__(256) void dws2_fwd_kernel(const T* __restrict__ in,
 }
 
 // ---- data gradient -------------------------------------------------------------------------------------------------------
-template <typename T, int CG>
+// A workgroup walks `tpb` consecutive dx tiles of one channel block and keeps what rides along -- the BatchNorm sums of the producer
+// (DwBnStats::slab) and, WG, THIS layer's weight-gradient products (DwBnStats::wslab: dW[t] += dy[(p + 1 - t) / 2] * xhat[p] over the same
+// (dy element, tap) pairs the data gradient multiplies, xhat = act(y*ms + mh) recomputed from the BatchNorm input the sums read anyway) --
+// in registers across them: ONE slab row per workgroup (~1 000 rows instead of one per tile: 13 824 on the 384 x 576 layer), and the
+// separate weight-gradient kernel's second pass over x (453 MB there) and dy disappears.
+template <typename T, int CG, bool WG>
 __global__ __launch_bounds__(256) void dws2_dgrad_kernel(const T* __restrict__ dy, int lddy, const float* __restrict__ wp,
                                                          const T* __restrict__ addend, int ldadd, T* __restrict__ dx, int lddx, S2Args a,
-                                                         const DwBnStats st) {
+                                                         const DwBnStats st, int ntiles, int tpb) {
   typedef S2Cfg<CG, 8> K;   // tile over dx (input resolution): 8 x TW
   constexpr int KPV = Elem<T>::kPerVec, KH = KPV / 2;
   constexpr int HH = K::TH / 2 + 1, HW = K::TW / 2 + 1;   // dy tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = xcd_remap(blockIdx.x, gridDim.x);
   const int cgb = t % a.ncgb;
-  const int tile_id = t / a.ncgb;
-  int r = t / a.ncgb;
-  const int tx = r % a.ntx;
-  r /= a.ntx;
-  const int ty = r % a.nty, n = r / a.nty;
+  const int srow = t / a.ncgb;
   const int ngroups = a.C / KPV;
-  const int cg0 = cgb * CG, y0 = ty * K::TH, x0 = tx * K::TW;
-  stage_tile<T, HH, HW, CG>(smem, dy, lddy, n, y0 / 2, x0 / 2, cg0, ngroups, a.Ho, a.Wo);
+  const int cg0 = cgb * CG;
   const int h = threadIdx.x % (2 * CG), sl = threadIdx.x / (2 * CG);
   const bool cok = cg0 + (h >> 1) < ngroups;
   const int ch0 = cok ? cg0 * KPV + h * KH : 0;
   float wk[9][KH];
   load_taps<KH>(wp, ch0, a.C, false, wk);
-  __syncthreads();
   const bool stats = st.slab != nullptr;
-  if (!cok && !stats) return;
   BnAcc<KH> bn;
   if (stats) bn.init(st, ch0);
+  else if (WG) bn.init_affine(st, ch0);
+  float dwa[WG ? 9 : 1][KH];
+#pragma unroll
+  for (int t9 = 0; t9 < (WG ? 9 : 1); ++t9)
+#pragma unroll
+    for (int e = 0; e < KH; ++e) dwa[t9][e] = 0.f;
   const char* tile = smem + h * 8;
+  const int tbeg = srow * tpb, tend = min(ntiles, tbeg + tpb);
+  for (int ti = tbeg; ti < tend; ++ti) {
+    const int tx = ti % a.ntx;
+    int r = ti / a.ntx;
+    const int ty = r % a.nty, n = r / a.nty;
+    const int y0 = ty * K::TH, x0 = tx * K::TW;
+    if (ti != tbeg) __syncthreads();   // every strip of the previous tile has left the LDS
+    stage_tile<T, HH, HW, CG>(smem, dy, lddy, n, y0 / 2, x0 / 2, cg0, ngroups, a.Ho, a.Wo);
+    __syncthreads();
 #pragma unroll 1
-  for (int k = 0; k < (cok ? K::SPT : 0); ++k) {
-    const int q = sl + K::NSL * k;
-    const int row = q / K::SPR, xs = (q % K::SPR) * DT_PX;   // tile-local dx row, first column of the strip (a multiple of 4)
-    const int iy = y0 + row;
-    vec8 yv[DT_PX];
-    if (stats) {
+    for (int k = 0; k < (cok ? K::SPT : 0); ++k) {
+      const int q = sl + K::NSL * k;
+      const int row = q / K::SPR, xs = (q % K::SPR) * DT_PX;   // tile-local dx row, first column of the strip (a multiple of 4)
+      const int iy = y0 + row;
+      vec8 yv[DT_PX];
+      if (stats || WG) {
 #pragma unroll
-      for (int j = 0; j < DT_PX; ++j) {
-        const int ix = x0 + xs + j;
-        vec8 z;
-        z.w[0] = z.w[1] = 0u;
-        yv[j] = (iy < a.Hi && ix < a.Wi) ? *reinterpret_cast<const vec8*>(reinterpret_cast<const T*>(st.y) + (((size_t)n * a.Hi + iy) * a.Wi + ix) * st.ldy + ch0) : z;
+        for (int j = 0; j < DT_PX; ++j) {
+          const int ix = x0 + xs + j;
+          vec8 z;
+          z.w[0] = z.w[1] = 0u;
+          yv[j] = (iy < a.Hi && ix < a.Wi) ? *reinterpret_cast<const vec8*>(reinterpret_cast<const T*>(st.y) + (((size_t)n * a.Hi + iy) * a.Wi + ix) * st.ldy + ch0) : z;
+        }
       }
-    }
-    vec8 av[DT_PX];
-    if (addend != nullptr) {
+      vec8 av[DT_PX];
+      if (addend != nullptr) {
 #pragma unroll
-      for (int j = 0; j < DT_PX; ++j) {
-        const int ix = x0 + xs + j;
-        vec8 z;
-        z.w[0] = z.w[1] = 0u;
-        av[j] = (iy < a.Hi && ix < a.Wi) ? *reinterpret_cast<const vec8*>(addend + (((size_t)n * a.Hi + iy) * a.Wi + ix) * ldadd + ch0) : z;
+        for (int j = 0; j < DT_PX; ++j) {
+          const int ix = x0 + xs + j;
+          vec8 z;
+          z.w[0] = z.w[1] = 0u;
+          av[j] = (iy < a.Hi && ix < a.Wi) ? *reinterpret_cast<const vec8*>(addend + (((size_t)n * a.Hi + iy) * a.Wi + ix) * ldadd + ch0) : z;
+        }
       }
-    }
-    float acc[DT_PX][KH];
-#pragma unroll
-    for (int j = 0; j < DT_PX; ++j)
-#pragma unroll
-      for (int e = 0; e < KH; ++e) acc[j][e] = 0.f;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      // dy row (iy + 1 - ky)/2 when that is an integer; the row parity differs between the lanes of a wave, so the tap is
-      // switched off by zeroing the loaded values instead of branching
-      const int num = row + 1 - ky;
-      const bool yfit = (num & 1) == 0;
-      const int trow = yfit ? num >> 1 : 0;
+      float acc[DT_PX][KH];
 #pragma unroll
       for (int j = 0; j < DT_PX; ++j)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          if (((j + 1 - kx) & 1) == 0) {   // column parity is known at compile time (xs is a multiple of 4)
-            const int tcol = (xs + j + 1 - kx) / 2;          // xs + j + 1 - kx >= 0 whenever the parity fits
-            float f[KH];
-            unpack8(*reinterpret_cast<const vec8*>(tile + (trow * HW + tcol) * (CG * 16)), f, T());
+        for (int e = 0; e < KH; ++e) acc[j][e] = 0.f;
+      // WG: the layer's forward input at the strip's own pixels, act(y*ms + mh) rounded to T exactly as the forward kernel's prologue
+      // did (bn_transform_tile); zero outside the image
+      float xh[WG ? DT_PX : 1][KH];
+      if constexpr (WG) {
 #pragma unroll
-            for (int e = 0; e < KH; ++e) acc[j][e] = fmaf(yfit ? f[e] : 0.f, wk[ky * 3 + kx][e], acc[j][e]);
+        for (int j = 0; j < DT_PX; ++j) {
+          const bool in = iy < a.Hi && x0 + xs + j < a.Wi;
+          float yf[KH];
+          unpack8(yv[j], yf, T());
+#pragma unroll
+          for (int e = 0; e < KH; ++e) {
+            const float v = fmaf(yf[e], bn.ms[e], bn.mh[e]);
+            yf[e] = st.relu ? fmaxf(v, 0.f) : v;
+          }
+          vec8 rr;
+          pack8(rr, yf, T());
+          unpack8(rr, xh[j], T());
+          if (!in) {
+#pragma unroll
+            for (int e = 0; e < KH; ++e) xh[j][e] = 0.f;
           }
         }
-    }
-    if (iy < a.Hi) {
+      }
 #pragma unroll
-      for (int j = 0; j < DT_PX; ++j) {
-        const int ix = x0 + xs + j;
-        if (ix < a.Wi) {
-          if (addend != nullptr) {
-            float ad[KH];
-            unpack8(av[j], ad, T());
+      for (int ky = 0; ky < 3; ++ky) {
+        // dy row (iy + 1 - ky)/2 when that is an integer; the row parity differs between the lanes of a wave, so the tap is
+        // switched off by zeroing the loaded values instead of branching
+        const int num = row + 1 - ky;
+        const bool yfit = (num & 1) == 0;
+        const int trow = yfit ? num >> 1 : 0;
 #pragma unroll
-            for (int e = 0; e < KH; ++e) acc[j][e] += ad[e];
+        for (int j = 0; j < DT_PX; ++j)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            if (((j + 1 - kx) & 1) == 0) {   // column parity is known at compile time (xs is a multiple of 4)
+              const int tcol = (xs + j + 1 - kx) / 2;          // xs + j + 1 - kx >= 0 whenever the parity fits
+              float f[KH];
+              unpack8(*reinterpret_cast<const vec8*>(tile + (trow * HW + tcol) * (CG * 16)), f, T());
+#pragma unroll
+              for (int e = 0; e < KH; ++e) {
+                const float fv = yfit ? f[e] : 0.f;
+                acc[j][e] = fmaf(fv, wk[ky * 3 + kx][e], acc[j][e]);
+                if constexpr (WG) dwa[ky * 3 + kx][e] = fmaf(fv, xh[j][e], dwa[ky * 3 + kx][e]);
+              }
+            }
           }
-          vec8 v;
-          pack8(v, acc[j], T());
-          *reinterpret_cast<vec8*>(dx + (((size_t)n * a.Hi + iy) * a.Wi + ix) * lddx + ch0) = v;
-          if (stats) {
-            float gs[KH], yf[KH];
-            unpack8(v, gs, T());
-            unpack8(yv[j], yf, T());
-            bn.add(gs, yf, st.relu);
+      }
+      if (iy < a.Hi) {
+#pragma unroll
+        for (int j = 0; j < DT_PX; ++j) {
+          const int ix = x0 + xs + j;
+          if (ix < a.Wi) {
+            if (addend != nullptr) {
+              float ad[KH];
+              unpack8(av[j], ad, T());
+#pragma unroll
+              for (int e = 0; e < KH; ++e) acc[j][e] += ad[e];
+            }
+            vec8 v;
+            pack8(v, acc[j], T());
+            *reinterpret_cast<vec8*>(dx + (((size_t)n * a.Hi + iy) * a.Wi + ix) * lddx + ch0) = v;
+            if (stats) {
+              float gs[KH], yf[KH];
+              unpack8(v, gs, T());
+              unpack8(yv[j], yf, T());
+              bn.add(gs, yf, st.relu);
+            }
           }
         }
       }
@@ -230,7 +271,29 @@ __global__ __launch_bounds__(256) void dws2_dgrad_kernel(const T* __restrict__ d
   }
   if (stats) {
     __syncthreads();
-    bn_acc_store<KH, K::NSL, CG * KPV>(reinterpret_cast<float*>(smem), bn.a, bn.b, cok, h, sl, st, tile_id, cg0 * KPV, a.C);
+    bn_acc_store<KH, K::NSL, CG * KPV>(reinterpret_cast<float*>(smem), bn.a, bn.b, cok, h, sl, st, srow, cg0 * KPV, a.C);
+  }
+  if constexpr (WG) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int CW = CG * KPV;
+    if (cok) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int e = 0; e < KH; ++e) red[(sl * 9 + tp) * CW + h * KH + e] = dwa[tp][e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * CW; i += 256) {
+      const int tp = i / CW, cl = i % CW;
+      const int c = cg0 * KPV + cl;
+      if (c < a.C) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < K::NSL; ++q) s += red[(q * 9 + tp) * CW + cl];
+        st.wslab[((size_t)srow * 9 + tp) * a.C + c] = s;
+      }
+    }
   }
 }
 
@@ -333,6 +396,20 @@ __global__ __launch_bounds__(256) void dws2_wgrad_kernel(const T* __restrict__ x
 
 static int pick_cg(int ngroups) { return ngroups <= 8 ? 8 : ngroups <= 16 ? 16 : 32; }
 
+// The data-gradient launch: about S2_DGRAD_WGS workgroups (four per CU, all resident: a workgroup's tile loop has no software pipeline, its
+// neighbours on the CU cover its staging latency), each walking `tpb` consecutive 8 x TW tiles of one channel block; rows = workgroups per
+// channel block = slab rows of the sums that ride along.
+constexpr int S2_DGRAD_WGS = 1024;
+static int s2_dgrad_plan(int kpv, int C, int N, int Hi, int Wi, int* tpb_out) {
+  const int cg = pick_cg(C / kpv);
+  const int ntiles = N * cdiv(Hi, 8) * cdiv(Wi, 8 * (32 / cg));
+  const int ncgb = cdiv(C / kpv, cg);
+  int tpb = cdiv((long)ntiles * ncgb, S2_DGRAD_WGS);
+  if (tpb < 1) tpb = 1;
+  if (tpb_out) *tpb_out = tpb;
+  return cdiv(ntiles, tpb);
+}
+
 template <typename T, int CG>
 static void launch3(int mode, S2Args a, int N, const void* p0, int ld0, const float* wp, const void* p1, int ld1, void* out, int ldout,
                     float* slab, int* rows_out, hipStream_t st, DwBnStats bs) {
@@ -350,10 +427,18 @@ static void launch3(int mode, S2Args a, int N, const void* p0, int ld0, const fl
     DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_fwd_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_F));
     hipLaunchKernelGGL((dws2_fwd_kernel<T, CG>), dim3(ntiles * a.ncgb), dim3(256), LDS_F, st, (const T*)p0, ld0, wp, (T*)out, ldout, a);
   } else if (mode == 1) {
-    DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_dgrad_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
-    if (bs.slab != nullptr) bs.rows = ntiles;
-    if (rows_out) *rows_out = ntiles;
-    hipLaunchKernelGGL((dws2_dgrad_kernel<T, CG>), dim3(ntiles * a.ncgb), dim3(256), LDS_D, st, (const T*)p0, ld0, wp, (const T*)p1, ld1, (T*)out, ldout, a, bs);
+    int tpb = 1;
+    const int rows = s2_dgrad_plan(Elem<T>::kPerVec, a.C, N, a.Hi, a.Wi, &tpb);
+    bs.rows = rows;
+    if (rows_out) *rows_out = rows;
+    if (bs.wslab != nullptr) {
+      constexpr int LDS_DW = LDS_D > FOLD ? LDS_D : FOLD;
+      DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_dgrad_kernel<T, CG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DW));
+      hipLaunchKernelGGL((dws2_dgrad_kernel<T, CG, true>), dim3(rows * a.ncgb), dim3(256), LDS_DW, st, (const T*)p0, ld0, wp, (const T*)p1, ld1, (T*)out, ldout, a, bs, ntiles, tpb);
+    } else {
+      DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_dgrad_kernel<T, CG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_D));
+      hipLaunchKernelGGL((dws2_dgrad_kernel<T, CG, false>), dim3(rows * a.ncgb), dim3(256), LDS_D, st, (const T*)p0, ld0, wp, (const T*)p1, ld1, (T*)out, ldout, a, bs, ntiles, tpb);
+    }
   } else {
     constexpr int LDS_W = LDS_F > FOLD ? LDS_F : FOLD;
     DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dws2_wgrad_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_W));
@@ -397,10 +482,7 @@ int launch_dw_tile_s2(int dtype, int mode, int N, int Hi, int Wi, int C, const v
   return 0;
 }
 
-// pixel tiles of the stride-2 data-gradient kernel (8 x TW tiles of the input-resolution tensor) = slab rows of its fused statistics
-int dw_tile_s2_dgrad_rows(int dtype, int C, int N, int Hi, int Wi) {
-  const int cg = pick_cg(C / (dtype == DC_BF16 ? 8 : 4));
-  return N * cdiv(Hi, 8) * cdiv(Wi, 8 * (32 / cg));
-}
+// workgroups per channel block of the stride-2 data-gradient kernel = slab rows of the sums that ride along (statistics, weight-gradient rows)
+int dw_tile_s2_dgrad_rows(int dtype, int C, int N, int Hi, int Wi) { return s2_dgrad_plan(dtype == DC_BF16 ? 8 : 4, C, N, Hi, Wi, nullptr); }
 
 }  // namespace dc

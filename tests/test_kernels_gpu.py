@@ -664,6 +664,8 @@ DW_CASES = [("s1", 728, 1, 1, 2, 12, 10), ("s2", 128, 2, 1, 2, 16, 12), ("d2", 1
             ("thin128", 128, 1, 1, 1, 17, 37), ("thin64", 64, 1, 1, 2, 9, 40), ("thin32d2", 32, 1, 2, 1, 11, 35),
             # stride-2 tiled path: several tiles, ragged edges, odd extents, all three channel-group widths
             ("s2_728", 728, 2, 1, 1, 22, 34), ("s2_256", 256, 2, 1, 2, 13, 41), ("s2_64", 64, 2, 1, 1, 18, 70),
+            # more stride-2 tiles than data-gradient workgroups: every workgroup walks two tiles with its sums in registers
+            ("s2_walk", 64, 2, 1, 3, 264, 420),
             # extents that are multiples of 8 with >= 128 channels: the persistent pipelined kernel (dwpipe.hip) in bf16
             ("pipe728", 728, 1, 1, 2, 16, 24), ("pipe1024d2", 1024, 1, 2, 1, 16, 8), ("pipe128", 128, 1, 1, 3, 24, 40)]
 
@@ -705,9 +707,9 @@ def test_depthwise(case, dtype):
     L.call("dc_dwconv_wgrad", dt, Cc, stride, dil, N, H, W, vptr(xv), Cc + 8, vptr(gyv), Cc, vptr(ws), vptr(gw), None, None, 0, S())
     torch.cuda.synchronize()
     assert_close(gw.cpu(), gw_ref, dtype, f32=2e-4, bf16=2e-3)
-    # data gradient (onto an addend) and weight gradient in ONE kernel, where the tiled stride-1 path serves the shape
+    # data gradient (onto an addend) and weight gradient in ONE kernel (the tiled stride-1 kernels and the stride-2 data-gradient kernel)
     rows = L.load().dc_dwconv_dgrad_wgrad_rows(dt, Cc, stride, dil, N, H, W)
-    assert (rows > 0) == (stride == 1)
+    assert rows > 0
     if rows > 0:
         _, gxv2 = empty_nhwc(N, H, W, Cc, dtype)
         wslab = torch.full((rows, 9, Cc), float("nan"), device=dev())
@@ -723,7 +725,7 @@ def test_depthwise(case, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("relu", [1, 0])
-@pytest.mark.parametrize("case", [c for c in DW_CASES if c[2] == 1], ids=lambda c: c[0])
+@pytest.mark.parametrize("case", DW_CASES, ids=lambda c: c[0])
 def test_depthwise_dgrad_with_fused_weight_gradient(case, dtype, relu):
     """dc_dwconv_dgrad_bnstats_wgrad + dc_dwconv_wgrad_reduce = dc_dwconv_dgrad_bnstats followed by dc_dwconv_wgrad with the BatchNorm
     prologue: the same dx bits and BatchNorm sums, the same weight gradient up to the order of the additions (and both against autograd
@@ -741,7 +743,7 @@ def test_depthwise_dgrad_with_fused_weight_gradient(case, dtype, relu):
         xhat = xhat.clamp_min(0)
     xhat = q(xhat, dtype)
     wr = w.clone().requires_grad_(True)
-    yref = F.conv2d(F.pad(xhat, (dil, dil, dil, dil)), wr, None, 1, 0, dil, groups=Cc)
+    yref = F.conv2d(F.pad(xhat, (dil, dil, dil, dil)), wr, None, stride, 0, dil, groups=Cc)
     gy = q(rnd(*yref.shape, seed=3), dtype)
     (gw_ref,) = torch.autograd.grad(yref, (wr,), gy)
     wd = torch.empty(9 * Cc, device=dev())
