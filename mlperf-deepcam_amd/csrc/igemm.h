@@ -65,6 +65,7 @@ inline long pw384_tiles(const IgemmParams& p, int npb) { return (long)((p.g.Cout
 
 // thinconv.hip: the thin 3x3 stem convolutions (forward and data gradient) without LDS staging of the pixel operand
 bool thin_fwd_eligible(const GatherGeom& g, int dtype, int bias, int accumulate, int out32);
+void thin_set_tile(int v);
 int launch_thin_fwd(const GatherGeom& g, int N, const void* in, int ldin, const void* w, int ldw, void* out, int ldout, float* slab,
                     int slab_rows, hipStream_t st);
 

@@ -877,6 +877,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm256p_min") == 0) { g_igemm256p_min = value; return 0; }
   if (name != nullptr && strcmp(name, "pw384_k64") == 0) { g_pw384_k64 = value; return 0; }
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
+  if (name != nullptr && strcmp(name, "thin_tile") == 0) { thin_set_tile(value); return 0; }
   if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }
   if (name != nullptr && strcmp(name, "pack_blocks") == 0 && value > 0) { g_pack_blocks = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_phase_fast") == 0) { igemm256_set_phase_fast(value); return 0; }
@@ -899,7 +900,7 @@ extern "C" int dc_set_option(const char* name, int value) {
 // tests on an experimental kernel), and the library applies the same table when it is loaded, so the table IS the default.
 static const struct { const char* name; int value; } kOptionDefaults[] = {
     {"igemm_mode", 2}, {"igemm256", 1}, {"pw384", 1}, {"pw384_k64", 1}, {"igemm256p", 1}, {"igemm256p_wgs", 0}, {"igemm256p_min", 257},
-    {"thin_fwd", 1}, {"igemm256_rel", 0}, {"pack_blocks", 2048},
+    {"thin_fwd", 1}, {"thin_tile", 1}, {"igemm256_rel", 0}, {"pack_blocks", 2048},
     {"igemm256_phase_fast", 1}, {"wgrad_target_blocks", 768},
     {"wgrad_mode", 1}, {"wgrad_min_steps", 16}, {"wgrad256", 1}, {"wgrad256_pad", 115}, {"thin_wgrad", 1}, {"wgrad256_slots", 192}, {"head_fused", 1},
     {"head_dgrad_fused", 1}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_pipe", 1}, {"bn_cgw", 32}, {"bn_rows", 32},

@@ -335,6 +335,169 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const ThinFwdArgs a) {
   }
 }
 
+// The stride-1 layers (32 -> 64 forward, its 64 -> 32 data gradient) with the input staged in LDS.  thin_fwd_kernel gathers every
+// K-step fragment from global memory: a pixel's 64 / 128 bytes pass through the vector L1 nine times, and with four workgroups per CU a
+// tap's 32 KiB working set evicts the previous tap's, so the nine passes are L2 reads at a CU's miss rate (2 GB per launch at 7.7 TB/s:
+// 265 us for 340 MB of tensors).  Here a workgroup owns a 2 x 64 output tile: its 4 x 66 pixel halo arrives ONCE by LDS-DMA (zero page for
+// the padding), the nine taps are address offsets into it.  A pixel occupies CIN/8 + 1 sixteen-byte slots (the last one a pad that is
+// fetched from the zero page): with a pitch of 80 / 144 bytes the sixteen pixels of a ds_read_b128 group fall on sixteen different bank
+// quads.  Same weight image, same K order, same MFMA per output element as thin_fwd_kernel: outputs bit-identical.
+template <int CIN, int COUT>
+struct ThinTile {
+  static constexpr int TH = 2, TW = 64;
+  static constexpr int SPP = CIN / 8 + 1;            // slots per pixel
+  static constexpr int HH = TH + 2, HW = TW + 2;
+  static constexpr int ROWS = HW * SPP;              // slots per halo row
+  static constexpr int SLOTS = HH * ROWS;
+  static constexpr int ITER = (SLOTS + 255) / 256;
+  static constexpr int HALO = ITER * 256 * 16;
+  static constexpr int KS = (9 * CIN + 31) / 32;
+  static constexpr int WIMG = KS * COUT * 64;
+  static constexpr int LDS = WIMG + HALO;
+  static constexpr int WGS_PER_CU = (160 * 1024) / LDS;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void thin_tile_kernel(const ThinFwdArgs a) {
+  typedef ThinTile<CIN, COUT> K;
+  constexpr int KS = K::KS, MB = COUT / 16, PB = 2;
+  static_assert(CIN == 32 || CIN == 64, "stride-1 layers only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem + K::WIMG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const bf16* __restrict__ xin = reinterpret_cast<const bf16*>(a.in);
+  const bf16* __restrict__ wg = reinterpret_cast<const bf16*>(a.w);
+  // ---- weight image (thin_fwd_kernel's)
+  for (int i = tid; i < KS * COUT * 4; i += 256) {
+    const int sl = i & 3, row = (i >> 2) % COUT, ks = i / (4 * COUT);
+    const int bi = row >> 4, g = (row >> 2) & 3, r = row & 3;
+    const int co = COUT == 64 ? (bi >> 1) * 32 + g * 8 + (bi & 1) * 4 + r : g * 8 + bi * 4 + r;
+    int tap, coff;
+    if (CIN == 32) { tap = ks; coff = sl * 8; }
+    else { tap = ks >> 1; coff = (ks & 1) * 32 + sl * 8; }
+    const vec16 v = ldg16(wg + ((size_t)a.twidx[tap] * COUT + co) * a.ldw + coff);
+    *reinterpret_cast<vec16*>(smem + (ks * COUT + row) * 64 + ((sl ^ ((row >> 1) & 3)) << 4)) = v;
+  }
+  float ssum[MB * 4], ssq[MB * 4];
+#pragma unroll
+  for (int c = 0; c < MB * 4; ++c) ssum[c] = ssq[c] = 0.f;
+  bf16* __restrict__ yout = reinterpret_cast<bf16*>(a.out);
+  const int ntx = (a.Wout + K::TW - 1) / K::TW, nty = (a.Hout + K::TH - 1) / K::TH;
+  const int ntiles = a.N * nty * ntx;
+  // one contiguous band of tiles per XCD (see thin_fwd_kernel)
+  int cend = ntiles, cfirst = blockIdx.x, cstep = gridDim.x;
+  if (gridDim.x >= 8) {
+    const int xcd = blockIdx.x & 7;
+    const int cbeg = (int)((long)ntiles * xcd / 8);
+    cend = (int)((long)ntiles * (xcd + 1) / 8);
+    cfirst = cbeg + (blockIdx.x >> 3);
+    cstep = (gridDim.x - xcd + 7) >> 3;
+  }
+  const uintptr_t zp = (uintptr_t)thin_zero_page;
+  // this wave's two pixel blocks of 16: block b = row b / 4, columns 16 * (b % 4) ..
+  int prow[PB], pcol[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int b = wave * PB + j;
+    prow[j] = b >> 2;
+    pcol[j] = (b & 3) * 16 + fr;
+  }
+  for (int tile = cfirst; tile < cend; tile += cstep) {
+    const int tx = tile % ntx;
+    const int r = tile / ntx;
+    const int ty = r % nty, n = r / nty;
+    const int y0 = ty * K::TH, x0 = tx * K::TW;
+    __syncthreads();                 // the weight image is written / the previous tile's fragments have been read
+    const bf16* base = xin + (size_t)n * a.Hin * a.Win * a.ldin;
+#pragma unroll
+    for (int it = 0; it < K::ITER; ++it) {
+      const int slot = it * 256 + tid;
+      const int hy = slot / K::ROWS, rem = slot - hy * K::ROWS;
+      const int hx = rem / K::SPP, sp = rem - hx * K::SPP;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = slot < K::SLOTS && sp < CIN / 8 && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+      const uintptr_t src = ok ? (uintptr_t)(base + ((size_t)iy * a.Win + ix) * a.ldin + sp * 8) : zp;
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(halo + (it * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+    __syncthreads();                 // vmcnt(0) + barrier: the halo tile has landed
+    f32x4 acc[MB][PB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      int tap, coff;
+      if (CIN == 32) { tap = ks; coff = fg; }                       // coff: 16-byte slot inside the pixel
+      else { tap = ks >> 1; coff = (ks & 1) * 4 + fg; }
+      const int dy = a.tdy[tap], dx = a.tdx[tap];
+      vec16 fb[PB];
+#pragma unroll
+      for (int j = 0; j < PB; ++j)
+        fb[j] = *reinterpret_cast<const vec16*>(halo + (((prow[j] + 1 + dy) * K::HW + pcol[j] + 1 + dx) * K::SPP + coff) * 16);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const int row = i * 16 + fr;
+        const vec16 fa = *reinterpret_cast<const vec16*>(smem + (ks * COUT + row) * 64 + ((fg ^ ((row >> 1) & 3)) << 4));
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+      }
+    }
+    // ---- store + statistics of the stored values (thin_fwd_kernel's epilogue)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int oy = y0 + prow[j], ox = x0 + pcol[j];
+      if (oy < a.Hout && ox < a.Wout) {
+        const size_t m = ((size_t)n * a.Hout + oy) * a.Wout + ox;
+        bf16* dst = yout + m * a.ldout + fg * 8;
+#pragma unroll
+        for (int hh = 0; hh < MB / 2; ++hh) {
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = acc[2 * hh + (e >> 2)][j][e & 3];
+          vec16 v;
+          pack(v, f, bf16());
+          stg16(dst + 32 * hh, v);
+          unpack(v, f, bf16());
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            ssum[8 * hh + e] += f[e];
+            ssq[8 * hh + e] = fmaf(f[e], f[e], ssq[8 * hh + e]);
+          }
+        }
+      }
+    }
+  }
+  if (a.slab != nullptr) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+      for (int c = 0; c < MB * 4; ++c) {
+        ssum[c] += __shfl_xor(ssum[c], off, 64);
+        ssq[c] += __shfl_xor(ssq[c], off, 64);
+      }
+    __syncthreads();   // the weight image is dead
+    float* red = reinterpret_cast<float*>(smem);   // [wave][2][COUT]
+    if (fr == 0) {
+#pragma unroll
+      for (int c = 0; c < MB * 4; ++c) {
+        const int ch = 32 * (c >> 3) + fg * 8 + (c & 7);
+        red[(wave * 2 + 0) * COUT + ch] = ssum[c];
+        red[(wave * 2 + 1) * COUT + ch] = ssq[c];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+      const int which = tid / COUT, ch = tid % COUT;
+      const float s = (red[(0 * 2 + which) * COUT + ch] + red[(1 * 2 + which) * COUT + ch]) + (red[(2 * 2 + which) * COUT + ch] + red[(3 * 2 + which) * COUT + ch]);
+      a.slab[((size_t)which * a.slab_rows + blockIdx.x) * COUT + ch] = s;
+    }
+  }
+}
+
 struct ThinPlan {
   int nseg, nchunk, rows_per, blocks;
 };
@@ -389,6 +552,9 @@ int launch_thin_wgrad(const dc_conv_desc& d, int N, int Hi, int Wi, const void* 
 
 // Gather-form forward / data gradient of a thin 3x3 convolution (see thin_fwd_kernel).  `slab_rows` is the row count the caller's
 // statistics slab was sized for (dc_conv_stat_rows); rows this kernel does not write are zeroed.
+static int g_thin_tile = 1;      // tuning switch "thin_tile": 0 = the gather-form kernel for the stride-1 layers too
+void thin_set_tile(int v) { g_thin_tile = v ? 1 : 0; }
+
 bool thin_fwd_eligible(const GatherGeom& g, int dtype, int bias, int accumulate, int out32) {
   if (dtype != DC_BF16 || bias || accumulate || out32 || g.os != 1 || g.ntaps != 9) return false;
   return (g.Cin == 16 && g.Cout == 32) || (g.Cin == 32 && g.Cout == 64) || (g.Cin == 64 && g.Cout == 32);
@@ -404,8 +570,12 @@ int launch_thin_fwd(const GatherGeom& g, int N, const void* in, int ldin, const 
   for (int t = 0; t < 9; ++t) { a.tdy[t] = g.taps[t].dy; a.tdx[t] = g.taps[t].dx; a.twidx[t] = g.taps[t].widx; }
   a.div_hw = make_fastdiv(g.Hout * g.Wout);
   a.div_w = make_fastdiv(g.Wout);
-  const int chunks = cdiv(a.M, 256);
-  int grid = chunks < 1024 ? chunks : 1024;
+  // stride 1 with every tap one pixel away at most (the 3 x 3 "same" convolution and its data gradient): the LDS-tiled kernel
+  bool tiled = g_thin_tile && g.is == 1 && g.Cin != 16;
+  for (int t = 0; t < 9; ++t) tiled = tiled && a.tdy[t] >= -1 && a.tdy[t] <= 1 && a.tdx[t] >= -1 && a.tdx[t] <= 1;
+  const int chunks = tiled ? N * cdiv(g.Hout, 2) * cdiv(g.Wout, 64) : cdiv(a.M, 256);
+  const int wgs = !tiled ? 1024 : 256 * (g.Cin == 32 ? ThinTile<32, 64>::WGS_PER_CU : ThinTile<64, 32>::WGS_PER_CU);
+  int grid = chunks < wgs ? chunks : wgs;
   if (slab != nullptr && grid > slab_rows) grid = slab_rows;
   if (slab != nullptr && slab_rows > grid) {
     for (int which = 0; which < 2; ++which) {
@@ -419,9 +589,16 @@ int launch_thin_fwd(const GatherGeom& g, int N, const void* in, int ldin, const 
     DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel<CI, CO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
     hipLaunchKernelGGL((thin_fwd_kernel<CI, CO>), dim3(grid), dim3(256), LDS, st, a);                                           \
   } while (0)
+#define THIN_TILE(CI, CO)                                                                                                       \
+  do {                                                                                                                          \
+    constexpr int LDS = ThinTile<CI, CO>::LDS;                                                                                  \
+    DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_tile_kernel<CI, CO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+    hipLaunchKernelGGL((thin_tile_kernel<CI, CO>), dim3(grid), dim3(256), LDS, st, a);                                          \
+  } while (0)
   if (g.Cin == 16) THIN_FWD(16, 32);
-  else if (g.Cin == 32) THIN_FWD(32, 64);
-  else THIN_FWD(64, 32);
+  else if (g.Cin == 32) { if (tiled) THIN_TILE(32, 64); else THIN_FWD(32, 64); }
+  else { if (tiled) THIN_TILE(64, 32); else THIN_FWD(64, 32); }
+#undef THIN_TILE
 #undef THIN_FWD
   DC_CHECK_LAUNCH();
   return 0;

@@ -244,6 +244,53 @@ def test_conv_persistent_tiles_same_bits(case):
         assert (a - b).abs().max().item() <= 2e-5 * (a.abs().max().item() + 1e-12) + 1e-6
 
 
+THIN_TILE_CASES = [
+    # cin, cout, N, H, W
+    (32, 64, 2, 7, 96), (32, 64, 1, 21, 150), (32, 64, 3, 64, 192), (32, 64, 1, 1, 3),
+]
+
+
+@pytest.mark.parametrize("case", THIN_TILE_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_thin_conv_lds_tiled_kernel_same_bits(case):
+    """The LDS-tiled kernel of the stride-1 thin layers (thinconv.hip thin_tile_kernel: 32 -> 64 forward, 64 -> 32 data gradient; the halo
+    of a 2 x 64 pixel tile staged once, the nine taps as address offsets) against the gather-form kernel it replaces: outputs and data
+    gradients bit for bit (ragged tiles, one-row images, several tiles per workgroup), BatchNorm sums up to the order of the additions."""
+    cin, cout, N, H, W = case
+    dtype = torch.bfloat16
+    d = desc(dtype, 3, 1, 1, 1, 0, cin, cout)
+    x = q(rnd(N, cin, H, W, seed=1), dtype)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
+    gy = q(rnd(N, cout, H, W, seed=3), dtype)
+    nwf, nwb = C.c_size_t(), C.c_size_t()
+    L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
+    wf = torch.empty(nwf.value, dtype=dtype, device=dev())
+    wb = torch.empty(nwb.value, dtype=dtype, device=dev())
+    L.call("dc_conv_pack_weights", C.byref(d), vptr(w.to(dev())), vptr(wf), vptr(wb), S())
+    _, xv = to_nhwc(x, dtype, ld=cin + 16, off=8)
+    _, gyv = to_nhwc(gy, dtype)
+    rows = L.load().dc_conv_stat_rows(C.byref(d), N, H, W)
+    got = []
+    try:
+        for tiled in (0, 1):
+            L.call("dc_set_option", b"thin_tile", tiled)
+            ybuf, yv = empty_nhwc(N, H, W, cout, dtype, ld=cout + 24, off=16)
+            slab = torch.full((2, rows, cout), float("nan"), device=dev())
+            L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, vptr(slab), 0, S())
+            gbuf, gxv = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
+            L.call("dc_conv_dgrad", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(gxv), cin + 8, 0, S())
+            torch.cuda.synchronize()
+            assert torch.isnan(ybuf[..., :16].float()).all() and torch.isnan(ybuf[..., 16 + cout:].float()).all()
+            assert torch.isnan(gbuf[..., cin:].float()).all()
+            got.append((from_nhwc(yv), from_nhwc(gxv), slab.double().sum(1).cpu()))
+    finally:
+        L.call("dc_set_option", b"thin_tile", 1)
+    assert_close(got[0][0], conv_ref(x, q(w, dtype), None, 3, 1, 1, 1, 0), dtype)
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    a, b = got[0][2], got[1][2]
+    assert not torch.isnan(b).any()
+    assert (a - b).abs().max().item() <= 2e-5 * (a.abs().max().item() + 1e-12) + 1e-6
+
+
 BNSTAT_CASES = [
     # name, k, stride, pad, dil, transposed, cin, cout, N, H, W
     ("dense3x3", 3, 1, 1, 1, 0, 256, 256, 2, 12, 20),
