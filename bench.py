@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (default: eager launches, which "
                     "measured faster once weight gradients moved to a side stream: 55.3 vs 59.5 ms at B=8)")
+    ap.add_argument("--program", action="store_true", help="replay the step from the C-side launch list (TrainStep.enable_program: dc_program_run, "
+                    "one call per step, no Python between launches); single GPU only.  The GPU work is the same list of launches")
     a = ap.parse_args()
 
     # timing-experiment switches that make backward skip work must never produce a bench line
@@ -216,6 +218,11 @@ def main():
         step(x, y)
         step.enable_graph()
         graphed = True
+    programmed = False
+    if world == 1 and a.program and not graphed:
+        step(x, y)
+        step.enable_program()
+        programmed = True
 
     def barrier():
         if world > 1:
@@ -262,6 +269,7 @@ def main():
     roof = None
     # every rank runs these extra steps (they contain the gradient collectives); only rank 0 brackets its launches with events
     step.graphed = False                         # per-launch events need eager launches (same kernels, same streams)
+    step.programmed = False
     nroof = min(a.steps, 3)
     def timed_pass():
         if rank == 0:
@@ -297,6 +305,7 @@ def main():
         enc = (t_fwd, t_bwd)
     eng.use_side_stream = side
     step.graphed = graphed
+    step.programmed = programmed
     barrier()
     if rank == 0:
         peak = PEAK[a.dtype]
@@ -355,7 +364,7 @@ def main():
                                       f"{' + RCCL grad all-reduce' if world > 1 else ''}), {H}x{W}x16, local_batch={B}, "
                                       f"{a.dtype} activations / fp32 master weights, random-init seed 333",
                           "local_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": a.optimizer,
-                          "hip_graph": graphed, "switches": switches},
+                          "hip_graph": graphed, "launch_list_replay": programmed, "switches": switches},
                "loss_last_step": round(loss, 6), "roofline": roof}
         if comm is not None:
             out["comm"] = comm

@@ -46,6 +46,28 @@ int dc_reset_options(void);
 int dc_stream_create(int level, void** stream);
 int dc_stream_destroy(void* stream);
 int dc_stream_priority_range(int* least, int* greatest);
+/* `to_stream` waits for everything enqueued on `from_stream` so far (the reference's loop relies on PyTorch's stream semantics for the
+ * same order, train_hdf5_ddp.py:358-364: backward, all-reduce, optimizer). */
+int dc_stream_fence(void* from_stream, void* to_stream);
+int dc_memset_async(void* dst, int byte, size_t bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The launch list of a train step as a C object.  The reference's step is the Python loop body train_hdf5_ddp.py:345-371, a chain of
+ * operator calls; here it is ~700 calls of THIS header per step.  A program records such a chain once (entry point name + argument
+ * words in issue order, stream fences included) and dc_program_run issues it again from C, with no interpreter between two launches.
+ *   words:  one 8-byte word per argument in declaration order -- ints / longs / size_t sign-extended, float as the bit pattern of the
+ *           double of equal value, pointers as they are.  Pointers to HOST objects (dc_conv_desc, dc_fold_entry tables, pointer arrays)
+ *           are recorded as addresses: the caller keeps those objects alive and unchanged while the program lives.
+ *   slots:  NULL, or per argument -1 (use the word) or a slot index whose value dc_program_bind supplies before a run (a batch pointer).
+ * Every int-returning entry point of this header except dc_program_* itself can be recorded.
+ * ------------------------------------------------------------------------------------------------ */
+int dc_program_create(void** program);
+int dc_program_destroy(void* program);
+int dc_program_append(void* program, const char* entry_point, int nargs, const long long* words, const int* slots);
+int dc_program_bind(void* program, int slot, long long word);
+int dc_program_len(void* program);
+const char* dc_program_op_name(void* program, int index);
+int dc_program_run(void* program, int* failed_op);   /* first failing call's code; *failed_op = its index or -1 */
 
 /* ------------------------------------------------------------------------------------------------
  * Dense convolution family: nn.Conv2d (k=1 or 3, stride 1|2, dilation, zero padding) and

@@ -291,7 +291,8 @@ class Engine:
         if not self.use_side_stream:
             fn(self._wsptr())
             return
-        self.side.wait_event(torch.cuda.current_stream().record_event())
+        # (a library call, not a torch event: the fence is then part of a recorded launch list, lib.Program)
+        L.call("dc_stream_fence", L.stream_ptr(), C.c_void_p(self.side.cuda_stream))
         with torch.cuda.stream(self.side):
             fn(C.c_void_p(self.workspace2.data_ptr()))
 
@@ -1010,6 +1011,6 @@ class Engine:
             if cb is not None:
                 cb(ready)
         if self.use_side_stream:
-            torch.cuda.current_stream().wait_stream(self.side)
+            L.call("dc_stream_fence", C.c_void_p(self.side.cuda_stream), L.stream_ptr())
         if marks is not None:
             marks.append(("bwd_end", torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))))

@@ -49,6 +49,15 @@ _SIGS = {
     "dc_stream_create": (I, [I, P]),
     "dc_stream_destroy": (I, [P]),
     "dc_stream_priority_range": (I, [P, P]),
+    "dc_stream_fence": (I, [P, P]),
+    "dc_memset_async": (I, [P, I, SZ, P]),
+    "dc_program_create": (I, [P]),
+    "dc_program_destroy": (I, [P]),
+    "dc_program_append": (I, [P, C.c_char_p, I, P, P]),
+    "dc_program_bind": (I, [P, I, C.c_longlong]),
+    "dc_program_len": (I, [P]),
+    "dc_program_op_name": (C.c_char_p, [P, I]),
+    "dc_program_run": (I, [P, P]),
     "dc_conv_out_hw": (I, [CD, I, I, C.POINTER(I), C.POINTER(I)]),
     "dc_conv_packed_elems": (I, [CD, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "dc_conv_pack_weights": (I, [CD, P, P, P, P]),
@@ -174,11 +183,120 @@ def check(rc: int) -> None:
         raise DeepcamHipError(last_error())
 
 
+_recorder: Optional["Program"] = None     # set by Program.recording(): every call() is appended to it (and executed as usual)
+
+
 def call(name: str, *args):
     """Call an int-returning entry point and raise on failure."""
+    if _recorder is not None:
+        _recorder.append(name, *args)
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise DeepcamHipError(f"{name}: {last_error()}")
+
+
+class Slot:
+    """A Program argument whose value is bound before each run (Program.bind): a batch pointer that changes from step to step."""
+
+    def __init__(self, name: str, value):
+        self.name, self.value = name, value
+
+
+def _word(ctype, v) -> int:
+    """The 8-byte word dc_program_append stores for one argument (include/deepcam_hip.h)."""
+    import struct
+    if ctype is F:
+        return struct.unpack("q", struct.pack("d", float(v)))[0]
+    if ctype in (I, L, SZ, C.c_longlong):
+        return int(v.value if hasattr(v, "value") else v)
+    # pointer-like: None, int, c_void_p, byref(obj), a ctypes array / structure (its address)
+    if v is None:
+        return 0
+    if isinstance(v, int):
+        return v
+    if isinstance(v, C.c_void_p):
+        return v.value or 0
+    if hasattr(v, "_obj"):                      # ctypes.byref(obj)
+        return C.addressof(v._obj)
+    if isinstance(v, (C.Array, C.Structure)):
+        return C.addressof(v)
+    if isinstance(v, C._Pointer):
+        return C.cast(v, C.c_void_p).value or 0
+    raise DeepcamHipError(f"Program: cannot record an argument of type {type(v).__name__}")
+
+
+class Program:
+    """A recorded launch list (dc_program_*): `with prog.recording(): step()` appends every library call of the block -- which also runs
+    as usual --, `prog.run()` issues the list again from C.  The recorder keeps every argument object alive (descriptors, fold tables and
+    pointer arrays are recorded by address), and the buffers the recorded device pointers refer to belong to the caller."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        check(load().dc_program_create(C.byref(self._h)))
+        self._keep = []
+        self._slots = {}
+
+    def __del__(self):
+        try:
+            if self._h:
+                load().dc_program_destroy(self._h)
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return load().dc_program_len(self._h)
+
+    def append(self, name: str, *args) -> None:
+        res, argtypes = _SIGS[name]
+        if res is not I or len(argtypes) != len(args):
+            raise DeepcamHipError(f"Program: {name} cannot be recorded with {len(args)} arguments")
+        n = len(args)
+        words, slots = (C.c_longlong * max(n, 1))(), (C.c_int * max(n, 1))()
+        bound = []
+        for k, (t, v) in enumerate(zip(argtypes, args)):
+            slots[k] = -1
+            if isinstance(v, Slot):
+                slots[k] = self._slots.setdefault(v.name, len(self._slots))
+                bound.append(v)
+                v = v.value
+            words[k] = _word(t, v)
+        self._keep.append(args)
+        check(load().dc_program_append(self._h, name.encode(), n, words, slots))
+        for v in bound:                      # the value the slot was recorded with stays bound until bind() replaces it
+            self.bind(v.name, v.value)
+
+    def bind(self, slot: str, value, _check: bool = True) -> None:
+        if slot not in self._slots:
+            if _check:
+                raise DeepcamHipError(f"Program: no slot named {slot!r}")
+            return
+        check(load().dc_program_bind(self._h, self._slots[slot], _word(P, value)))
+
+    def recording(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            global _recorder
+            if _recorder is not None:
+                raise DeepcamHipError("Program: a recording is already in progress")
+            _recorder = self
+            try:
+                yield self
+            finally:
+                _recorder = None
+        return ctx()
+
+    def run(self) -> None:
+        failed = C.c_int(-1)
+        rc = load().dc_program_run(self._h, C.byref(failed))
+        if rc != 0:
+            nm = load().dc_program_op_name(self._h, failed.value)
+            raise DeepcamHipError(f"program call {failed.value} ({nm.decode() if nm else '?'}): {last_error()}")
+
+    def names(self):
+        lib = load()
+        return [lib.dc_program_op_name(self._h, k).decode() for k in range(len(self))]
 
 
 def dtype_code(torch_dtype) -> int:

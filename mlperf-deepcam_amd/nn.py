@@ -506,9 +506,9 @@ class TrainStep:
 
     def launch(self, x: torch.Tensor, labels: torch.Tensor) -> None:
         eng = self.eng
-        self.loss_sum.zero_()
+        L.call("dc_memset_async", L.dptr(self.loss_sum), 0, 8, L.stream_ptr())
         if self.counts is not None:
-            self.counts.zero_()
+            L.call("dc_memset_async", L.dptr(self.counts), 0, 8 * self.counts.numel(), L.stream_ptr())
         if self.fuse_head_loss:
             # the loss pass rides inside the classifier's forward kernel (dc_head_fwd_loss): the logits are neither stored nor re-read
             t = labels.squeeze(1) if labels.dim() == 4 else labels
@@ -558,9 +558,39 @@ class TrainStep:
         # callers enable the graph before training starts (bench) or accept two extra steps on stale data
         self.graphed = True
 
+    def enable_program(self) -> None:
+        """Record the whole step as a C-side launch list (lib.Program, dc_program_*: every library call of one step with its arguments,
+        stream fences included) and replay it with ONE call per step: later calls copy the batch into static buffers, push the
+        optimizer's scalars and run the list -- no Python between two launches.  The recording pass is a real step on whatever the
+        static buffers hold, as with enable_graph.  Single-process only: the gradient reducer's hooks are Python."""
+        if self.after_backward is not None or self.eng.on_grad_ready is not None:
+            raise L.DeepcamHipError("the recorded launch list is for the single-GPU step (the all-reduce hooks run in Python)")
+        eng = self.eng
+        self._gx = eng.x_static
+        self._gy = torch.zeros((eng.B, eng.H, eng.W), dtype=torch.int64, device=eng.device)
+        eng.packed_version = -1           # weights change every step: repacking is part of the recorded sequence
+        self.opt.step_count += 1
+        self.opt.sync_scalars()
+        self.launch(self._gx, self._gy)   # warm-up (lazy attribute setup); a real step, like the recording pass below
+        torch.cuda.synchronize()
+        eng.packed_version = -1
+        self.opt.step_count += 1
+        self.opt.sync_scalars()
+        self._program = L.Program()
+        with self._program.recording():
+            self.launch(self._gx, self._gy)
+        eng.packed_version = -1
+        self.programmed = True
+
     def __call__(self, x: torch.Tensor, labels: torch.Tensor) -> None:
         self.opt.step_count += 1
         self.opt.sync_scalars()
+        if getattr(self, "programmed", False):
+            self._gx.copy_(x, non_blocking=True)
+            self._gy.copy_(labels.squeeze(1) if labels.dim() == 4 else labels, non_blocking=True)
+            self._program.run()
+            self.eng.version[0] += 1
+            return
         if getattr(self, "graphed", False):
             self._gx.copy_(x, non_blocking=True)
             self._gy.copy_(labels, non_blocking=True)

@@ -24,3 +24,16 @@ for _ in range(10): step(x, y)
 torch.cuda.synchronize()
 gpu = (time.perf_counter() - t0) / 10
 print(f"host enqueue {min(ts) * 1e3:.1f} ms (median {sorted(ts)[2] * 1e3:.1f}) per step; step {gpu * 1e3:.1f} ms; threads {torch.get_num_threads()}, cpus {os.cpu_count()}")
+# the same step replayed from the C-side launch list (TrainStep.enable_program -> dc_program_run): one library call per step
+step.enable_program()
+torch.cuda.synchronize()
+tp = []
+for _ in range(5):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); step._program.run(); tp.append(time.perf_counter() - t0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10): step(x, y)
+torch.cuda.synchronize()
+gpu2 = (time.perf_counter() - t0) / 10
+print(f"launch-list replay: host {min(tp) * 1e3:.2f} ms (median {sorted(tp)[2] * 1e3:.2f}) per step for {len(step._program)} recorded calls; step {gpu2 * 1e3:.1f} ms (includes the copy of the batch into the static buffers)")

@@ -10,6 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from mlperf_deepcam_amd import nn as dnn  # noqa: E402
+from mlperf_deepcam_amd import lib as L  # noqa: E402
 from mlperf_deepcam_amd.engine import Engine  # noqa: E402
 from oracle import loss_metric as olm  # noqa: E402  (checker only)
 from oracle import model as omodel  # noqa: E402
@@ -247,6 +248,71 @@ def test_train_step_is_bit_reproducible(optname):
     for (la, ia, pa, ba), (lb, ib, pb, bb) in zip(a, b):
         assert abs(la - lb) <= 1e-12 * abs(la) and ia == ib      # the reported loss is a double-precision atomic sum (1e-16 jitter)
         assert torch.equal(pa, pb) and torch.equal(ba, bb)
+
+
+@pytest.mark.parametrize("optname", ["LAMB", "AdamW"])
+def test_recorded_launch_list_replays_the_eager_steps(optname):
+    """TrainStep.enable_program(): the step recorded once as a C-side launch list (lib.Program / dc_program_*: ~700 library calls with their
+    arguments, stream fences and the optimizer included) and replayed by ONE call per step, against the same steps issued call by call
+    from Python: parameters, BatchNorm buffers, loss and IoU bit for bit, with different batches from step to step (the batch enters through
+    the static buffers) and the lr changing between steps (it enters through the optimizer's device scalars)."""
+    dev = torch.device("cuda", 0)
+    B, H, W = 4, 96, 160
+    batches = [make_inputs(B, H, W, seed=s) for s in (1, 2, 3, 4)]
+
+    def run(program):
+        net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=torch.bfloat16, seed=333)
+        net.materialize(B, H, W)
+        net.train()
+        opt = dnn.make_optimizer(optname, net, 1e-3, 1e-8, 1e-2)
+        step = dnn.TrainStep(net, opt, olm.class_weights(-0.125), B, H, W, with_metrics=True)
+        # the recording (and its warm-up) is two real steps on the static buffers: give the eager run the same two steps
+        z = (torch.zeros(B, 16, H, W, device=dev), torch.zeros(B, H, W, dtype=torch.int64, device=dev))
+        if program:
+            net.engine.x_static.zero_()
+            step.enable_program()
+            names = step._program.names()
+            assert len(names) > 300 and "dc_stream_fence" in names and "dc_pack_all" in names
+            assert ("dc_lamb_step" if optname == "LAMB" else "dc_adam_step") in names
+        else:
+            step(*z)
+            step(*z)
+        out = []
+        for i, (x, y) in enumerate(batches):
+            opt.param_groups[0]["lr"] = 1e-3 * (1 + i)
+            step(x.to(dev), y.to(dev))
+            torch.cuda.synchronize()
+            out.append((step.loss(), step.iou(), net.engine.params.clone(), net.engine.buffers.clone()))
+        return out
+
+    a, b = run(False), run(True)
+    for (la, ia, pa, ba), (lb, ib, pb, bb) in zip(a, b):
+        assert abs(la - lb) <= 1e-12 * abs(la) and ia == ib
+        assert torch.equal(pa, pb) and torch.equal(ba, bb)
+
+
+def test_program_slots_and_errors():
+    """dc_program_* by hand: a slot bound before each run, the failing call reported by index and name, unrecordable names refused."""
+    dev = torch.device("cuda", 0)
+    a, b = torch.full((64,), 7, dtype=torch.uint8, device=dev), torch.full((64,), 7, dtype=torch.uint8, device=dev)
+    prog = L.Program()
+    st = L.stream_ptr()
+    prog.append("dc_memset_async", L.Slot("buf", L.dptr(a)), 1, 64, st)
+    prog.append("dc_stream_fence", st, st)
+    assert len(prog) == 2 and prog.names() == ["dc_memset_async", "dc_stream_fence"]
+    prog.run()
+    prog.bind("buf", L.dptr(b))
+    prog.run()
+    torch.cuda.synchronize()
+    assert int(a.sum()) == 64 and int(b.sum()) == 64
+    with pytest.raises(L.DeepcamHipError, match="no slot named"):
+        prog.bind("nope", 0)
+    with pytest.raises(L.DeepcamHipError, match="cannot be recorded"):
+        prog.append("dc_last_error")
+    bad = L.Program()
+    bad.append("dc_memset_async", None, 0, 16, st)          # null destination: the entry point refuses, the program reports which call
+    with pytest.raises(L.DeepcamHipError, match=r"program call 0 \(dc_memset_async\)"):
+        bad.run()
 
 
 def test_steps_enqueued_ahead_match_synchronised_steps():
