@@ -554,8 +554,8 @@ class TrainStep:
         eng.packed_version = -1
         with torch.cuda.graph(self._graph):
             self.launch(self._gx, self._gy)
-        # the warm-up and the capture pass each applied one optimizer update with whatever was in the static buffers:
-        # callers enable the graph before training starts (bench) or accept two extra steps on stale data
+        # the warm-up applied one optimizer update with whatever was in the static buffers (the capture pass records, it executes nothing):
+        # callers enable the graph before training starts (bench) or accept one extra step on stale data
         self.graphed = True
 
     def enable_program(self) -> None:

@@ -250,6 +250,39 @@ def test_train_step_is_bit_reproducible(optname):
         assert torch.equal(pa, pb) and torch.equal(ba, bb)
 
 
+def test_hip_graph_replays_the_eager_steps():
+    """TrainStep.enable_graph() (bench.py --graph; slower than eager launches since the weight gradients moved to a second stream, kept as an
+    option): the captured step -- both streams, the library's stream fences and memsets included -- replays the eager steps bit for bit."""
+    dev = torch.device("cuda", 0)
+    B, H, W = 4, 96, 160
+    batches = [make_inputs(B, H, W, seed=s) for s in (5, 6, 7)]
+    z = (torch.zeros(B, 16, H, W, device=dev), torch.zeros(B, H, W, dtype=torch.int64, device=dev))
+
+    def run(graph):
+        net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=torch.bfloat16, seed=333)
+        net.materialize(B, H, W)
+        net.train()
+        opt = dnn.make_optimizer("LAMB", net, 1e-3, 1e-8, 1e-2)
+        step = dnn.TrainStep(net, opt, olm.class_weights(-0.125), B, H, W, with_metrics=True)
+        step(*z)
+        if graph:
+            net.engine.x_static.zero_()
+            step.enable_graph()             # its warm-up is one more launch with the scalars of the step before; the capture pass executes nothing
+        else:
+            step.launch(*z)
+        out = []
+        for x, y in batches:
+            step(x.to(dev), y.to(dev))
+            torch.cuda.synchronize()
+            out.append((step.loss(), step.iou(), net.engine.params.clone(), net.engine.buffers.clone()))
+        return out
+
+    a, b = run(False), run(True)
+    for (la, ia, pa, ba), (lb, ib, pb, bb) in zip(a, b):
+        assert abs(la - lb) <= 1e-12 * abs(la) and ia == ib
+        assert torch.equal(pa, pb) and torch.equal(ba, bb)
+
+
 @pytest.mark.parametrize("optname", ["LAMB", "AdamW"])
 def test_recorded_launch_list_replays_the_eager_steps(optname):
     """TrainStep.enable_program(): the step recorded once as a C-side launch list (lib.Program / dc_program_*: ~700 library calls with their
