@@ -27,6 +27,7 @@ int conv_wgrad_bnin(const dc_conv_desc* d, int N, int Hi, int Wi, const void* y,
                     const void* dy, int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream);
 constexpr int WG_MAXGROUP = 4;   // layers of one geometry per grouped launch (dc_conv_wgrad_group)
 void wgrad256_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group = 1);
+void wgrad256_set_min_stages(int n);   // fewest 32-pixel stages a split of the 256-tile kernel may have (default 96)
 void wgrad256_set_slots(int n);   // workgroups a launch of the 256-tile kernel aims for (default 256 = one per CU)
 // group > 1: xs / dys / slabs hold `group` pointers (entry 0 repeats p.x / p.dy / p.slab)
 int launch_wgrad256(const WgradParams& p, hipStream_t st, int group = 1, const void* const* xs = nullptr, const void* const* dys = nullptr,

@@ -497,6 +497,12 @@ extern "C" int dc_wgrad_set_256(int m) {
   return 0;
 }
 
+extern "C" int dc_wgrad_set_min_stages(int n) {
+  if (n < 1) return dc_fail("dc_set_option: wgrad256_min_stages must be positive", __FILE__, __LINE__);
+  wgrad256_set_min_stages(n);
+  return 0;
+}
+
 extern "C" int dc_wgrad_set_slots(int n) {
   if (n < 1) return dc_fail("dc_set_option: wgrad256_slots must be positive", __FILE__, __LINE__);
   wgrad256_set_slots(n);

@@ -409,13 +409,19 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_)
 
 }  // namespace
 
-// About one workgroup per CU (g_wgrad256_slots of them); every split at least four stages long.  `group` layers share the launch.
+// About one workgroup per CU (g_wgrad256_slots of them); every split at least g_wgrad256_min_stages stages long.  `group` layers share the launch.
 static int g_wgrad256_slots = 192;   // 64 CUs stay free for the HBM-bound kernels of the backward chain (step -0.3 ms vs 256)
+// A workgroup pays its ring fill, its 256 KiB fp32 slab tile and the fold's read of it whatever its share of the pixels: below ~100 stages
+// (3 072 pixels) that fixed cost wins.  At local batch 2 / 4 the 728-channel groups were cut into 7 splits of 31 / 62 stages; now 3 / 5 splits
+// of 72 / 87 stages: 13.88 -> 13.47 ms and 21.50 -> 20.92 ms per step (profiles/r04_ab_step_2.txt); local batch 8 keeps its 7 splits of 123.
+static int g_wgrad256_min_stages = 96;
 void wgrad256_set_slots(int n) { g_wgrad256_slots = n; }
+void wgrad256_set_min_stages(int n) { g_wgrad256_min_stages = n < 4 ? 4 : n; }
 void wgrad256_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group) {
   const long tiles = (long)cdiv(g.Cin, WT) * cdiv(g.Cout, WT) * g.ntaps * group;
   long want = g_wgrad256_slots / tiles;
-  const long maxs = (M + 4 * WBP - 1) / (4 * WBP);
+  const long per = (long)g_wgrad256_min_stages * WBP;
+  const long maxs = (M + per - 1) / per;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   long c = (M + want - 1) / want;
