@@ -21,8 +21,8 @@ for LB in 8 4; do
   echo "pmc passes at local batch $LB done"
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats4 -o run -- python3 $R/bench.py --steps 10 --warmup 3 --local_batch_size 4 --no_cpu_baseline > $OUT/bench_b4.json 2> $OUT/bench_b4.err || exit 1
-rocprofv3 --kernel-trace --output-format csv -d $OUT/plain -o run -- python3 $R/scripts/run_steps.py 8 8 > $OUT/plain.log 2>&1 || exit 1
-DC_SIDE_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d $OUT/serial -o run -- python3 $R/scripts/run_steps.py 8 8 > $OUT/serial.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/plain -o run -- python3 $R/scripts/run_steps.py 8 16 > $OUT/plain.log 2>&1 || exit 1
+DC_SIDE_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d $OUT/serial -o run -- python3 $R/scripts/run_steps.py 8 16 > $OUT/serial.log 2>&1 || exit 1
 echo "traces done"
 cd $R
 first() { ls $1/*/*$2 $1/*$2 2>/dev/null | head -1; }
@@ -32,10 +32,10 @@ for LB in 8 4; do
   mkdir -p $OUT/rf$LB && ln -sfn $OUT/fetch$LB $OUT/rf$LB/FETCH_SIZE && ln -sfn $OUT/write$LB $OUT/rf$LB/WRITE_SIZE && ln -sfn $OUT/mfma$LB $OUT/rf$LB/SQ_INSTS_VALU_MFMA_MOPS_BF16
   python3 scripts/roofline_report.py $OUT/rf$LB $OUT/roofline_table_b$LB.md $LB > $OUT/roofline_table_b$LB.txt 2>&1
 done
-python3 scripts/step_timeline.py $(first $OUT/plain kernel_trace.csv) 6 > $OUT/step_timeline.txt 2>&1
+python3 scripts/step_timeline.py $(first $OUT/plain kernel_trace.csv) 12 > $OUT/step_timeline.txt 2>&1
 python3 scripts/trace_gaps.py $(first $OUT/plain kernel_trace.csv) > $OUT/trace_gaps.txt 2>&1
-python3 scripts/step_dump.py $(first $OUT/plain kernel_trace.csv) $OUT/step_both.tsv 6 > /dev/null 2>&1
-python3 scripts/step_dump.py $(first $OUT/serial kernel_trace.csv) $OUT/step_serial.tsv 6 > /dev/null 2>&1
+python3 scripts/step_dump.py $(first $OUT/plain kernel_trace.csv) $OUT/step_both.tsv 12 > /dev/null 2>&1
+python3 scripts/step_dump.py $(first $OUT/serial kernel_trace.csv) $OUT/step_serial.tsv 12 > /dev/null 2>&1
 cp $(first $OUT/stats kernel_stats.csv) $OUT/kernel_stats_b8.csv
 cp $(first $OUT/stats4 kernel_stats.csv) $OUT/kernel_stats_b4.csv
 python3 bench.py --steps 20 --warmup 5 --local_batch_size 2 --no_cpu_baseline > $OUT/bench_b2.json 2>> $OUT/bench_b8.err
