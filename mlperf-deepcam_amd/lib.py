@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import threading
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -183,12 +184,13 @@ def check(rc: int) -> None:
         raise DeepcamHipError(last_error())
 
 
-_recorder: Optional["Program"] = None     # set by Program.recording(): every call() is appended to it (and executed as usual)
+_recorder: Optional["Program"] = None     # set by Program.recording(): every call() of THAT thread is appended to it (and executed as usual)
+_recorder_thread = 0                       # (an input pipeline's reader threads issue library calls of their own: not part of the step's list)
 
 
 def call(name: str, *args):
     """Call an int-returning entry point and raise on failure."""
-    if _recorder is not None:
+    if _recorder is not None and threading.get_ident() == _recorder_thread:
         _recorder.append(name, *args)
     rc = getattr(load(), name)(*args)
     if rc != 0:
@@ -277,10 +279,10 @@ class Program:
 
         @contextlib.contextmanager
         def ctx():
-            global _recorder
+            global _recorder, _recorder_thread
             if _recorder is not None:
                 raise DeepcamHipError("Program: a recording is already in progress")
-            _recorder = self
+            _recorder, _recorder_thread = self, threading.get_ident()
             try:
                 yield self
             finally:

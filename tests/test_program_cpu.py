@@ -42,3 +42,21 @@ def test_argument_words():
     assert L._word(L.P, arr) == C.addressof(arr)
     with pytest.raises(L.DeepcamHipError):
         L._word(L.P, "a string")
+
+
+def test_record_and_replay_without_a_gpu_and_only_the_recording_thread():
+    """dc_program_* need no device for entry points that launch nothing: record dc_reset_options / dc_set_option from two threads, only the
+    recording thread's calls land in the list; the replay runs them again (the option is back after a reset in between)."""
+    import threading
+    from mlperf_deepcam_amd import lib as L
+    lib = L.load()
+    prog = L.Program()
+    with prog.recording():
+        L.call("dc_reset_options")
+        t = threading.Thread(target=lambda: L.call("dc_reset_options"))
+        t.start(); t.join()
+    assert prog.names() == ["dc_reset_options"]
+    prog.run()
+    with pytest.raises(L.DeepcamHipError, match="cannot record an argument of type bytes"):
+        prog.append("dc_set_option", b"pw384", 1)      # a char* argument: host strings are not recordable words
+    assert len(prog) == 1
