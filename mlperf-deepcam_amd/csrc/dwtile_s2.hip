@@ -166,22 +166,29 @@ __global__ __launch_bounds__(256) void dws2_dgrad_kernel(const T* __restrict__ d
     const int y0 = ty * K::TH, x0 = tx * K::TW;
     if (ti != tbeg) __syncthreads();   // every strip of the previous tile has left the LDS
     stage_tile<T, HH, HW, CG>(smem, dy, lddy, n, y0 / 2, x0 / 2, cg0, ngroups, a.Ho, a.Wo);
+    // the BatchNorm input at a strip's own pixels is requested one strip ahead: strip 0's beside the tile's LDS-DMA (the barrier below waits
+    // for both at once), strip k+1's before the stencil of strip k (requested at the top of its own strip, every strip began with an
+    // exposed round trip)
+    auto load_y = [&](int k, vec8 (&yv)[DT_PX]) {
+      const int q = sl + K::NSL * k;
+      const int iy = y0 + q / K::SPR, xs = (q % K::SPR) * DT_PX;
+#pragma unroll
+      for (int j = 0; j < DT_PX; ++j) {
+        const int ix = x0 + xs + j;
+        vec8 z;
+        z.w[0] = z.w[1] = 0u;
+        yv[j] = (iy < a.Hi && ix < a.Wi) ? *reinterpret_cast<const vec8*>(reinterpret_cast<const T*>(st.y) + (((size_t)n * a.Hi + iy) * a.Wi + ix) * st.ldy + ch0) : z;
+      }
+    };
+    vec8 yv[DT_PX], ynext[DT_PX];
+    if (cok && (stats || WG)) load_y(0, yv);
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < (cok ? K::SPT : 0); ++k) {
       const int q = sl + K::NSL * k;
       const int row = q / K::SPR, xs = (q % K::SPR) * DT_PX;   // tile-local dx row, first column of the strip (a multiple of 4)
       const int iy = y0 + row;
-      vec8 yv[DT_PX];
-      if (stats || WG) {
-#pragma unroll
-        for (int j = 0; j < DT_PX; ++j) {
-          const int ix = x0 + xs + j;
-          vec8 z;
-          z.w[0] = z.w[1] = 0u;
-          yv[j] = (iy < a.Hi && ix < a.Wi) ? *reinterpret_cast<const vec8*>(reinterpret_cast<const T*>(st.y) + (((size_t)n * a.Hi + iy) * a.Wi + ix) * st.ldy + ch0) : z;
-        }
-      }
+      if ((stats || WG) && k + 1 < K::SPT) load_y(k + 1, ynext);
       vec8 av[DT_PX];
       if (addend != nullptr) {
 #pragma unroll
@@ -267,6 +274,8 @@ __global__ __launch_bounds__(256) void dws2_dgrad_kernel(const T* __restrict__ d
           }
         }
       }
+#pragma unroll
+      for (int j = 0; j < DT_PX; ++j) yv[j] = ynext[j];
     }
   }
   if (stats) {
