@@ -179,6 +179,7 @@ class Engine:
         # the head's data gradient (906 MB at local batch 8, read once) is not stored: the head's kernel takes the BatchNorm sums in a first
         # pass and writes the BatchNorm input's gradient itself in a second one (dc_head_bwd_bnin_apply)
         self.fuse_head_apply = os.environ.get("DC_FUSE_HEAD_APPLY", "1") != "0"
+        self.inline_last_wgrad = os.environ.get("DC_INLINE_LAST_WGRAD", "1") != "0"
         # depthwise weight gradient taken inside the depthwise data gradient (dc_dwconv_dgrad_bnstats_wgrad) where the layer's input is a
         # never-stored BatchNorm output: the separate dc_dwconv_wgrad launch (and its second read of dy and y) disappears.  On the tiled
         # kernel the fusion held 232 registers (two workgroups per CU instead of three) and paid from local batch 8 only; on the persistent
@@ -381,7 +382,12 @@ class Engine:
                 def side(ws):
                     L.call("dc_conv_wgrad_partial", C.byref(d), N, H, W, cnt, xs, x.ld, dys, dy.ld, slabs, splits, self._st())
                     L.call("dc_fold_slabs", ents, nent, self._st())
-                self._on_side(side)
+                if not need_dx and self.inline_last_wgrad:
+                    # a layer without a data gradient (the stem) ends the backward chain: nothing is left for the main stream to run beside
+                    # this weight gradient, and on the side stream it would queue behind the previous layer's
+                    side(self._wsptr())
+                else:
+                    self._on_side(side)
 
             def bwd():
                 if bias:
