@@ -180,6 +180,7 @@ class Engine:
         # pass and writes the BatchNorm input's gradient itself in a second one (dc_head_bwd_bnin_apply)
         self.fuse_head_apply = os.environ.get("DC_FUSE_HEAD_APPLY", "1") != "0"
         self.inline_last_wgrad = os.environ.get("DC_INLINE_LAST_WGRAD", "1") != "0"
+        self.aspp_side = os.environ.get("DC_ASPP_SIDE", "1") != "0"       # forward: the small ASPP branches beside the grouped atrous launch
         # depthwise weight gradient taken inside the depthwise data gradient (dc_dwconv_dgrad_bnstats_wgrad) where the layer's input is a
         # never-stored BatchNorm output: the separate dc_dwconv_wgrad launch (and its second read of dy and y) disappears.  On the tiled
         # kernel the fusion held 232 registers (two workgroups per CU instead of three) and paid from local batch 8 only; on the persistent
@@ -403,6 +404,25 @@ class Engine:
 
         self.bwd.append(make_bwd)
         return y, slab, rows
+
+    def _fork_forward(self, begin) -> None:
+        """Moves the forward ops appended since `begin` (indices into fwd_train / fwd_eval) onto the side stream: one closure that orders
+        the side stream behind the main stream's current position and issues them there.  The caller appends the join (a fence back)."""
+        for lst, b in ((self.fwd_train, begin[0]), (self.fwd_eval, begin[1])):
+            ops = lst[b:]
+            del lst[b:]
+
+            def forked(ops=ops):
+                if not self.use_side_stream:          # (bench.py's one-stream passes switch it off at run time)
+                    for op in ops:
+                        op()
+                    return
+                L.call("dc_stream_fence", L.stream_ptr(), C.c_void_p(self.side.cuda_stream))
+                with torch.cuda.stream(self.side):
+                    for op in ops:
+                        op()
+            lst.append(forked)
+        self._forked = True
 
     def _dilated_group_fwd(self, members: list) -> None:
         """One launch for the forward of several "same" dilated 3x3 convolutions of one input (the atrous ASPP branches,
@@ -718,6 +738,7 @@ class Engine:
 
         # ---- ASPP: five branches write channel slices of one buffer (torch.cat is free)
         cat1 = Act(self, "aspp_cat", B, h16, w16, 1280)
+        small_begin = (len(self.fwd_train), len(self.fwd_eval))     # the image-pool and 1 x 1 branches: see _fork_forward below
         # image-pool branch first, so that in the backward program it is the LAST contributor to d(e)
         pooled = Act(self, "gap", B, 1, 1, 2048, dtype=torch.float32)     # this branch runs in fp32 (B values per channel)
         HW = h16 * w16
@@ -771,17 +792,31 @@ class Engine:
                 pending.append((y, slab, rows, i))
             else:
                 self._bn(y, slab, rows, f"aspp{i}.bn", True, out=cat1.slice(f"aspp{i}", 256 * (i - 1), 256))
+            if rate == 1 and group is not None and self.aspp_side:
+                # The image-pool branch (five launches on B x 2048 values), the 1 x 1 branch and the decoder's low-level projection (it reads
+                # block1's output, ready long before) are ~200 us of small kernels; the grouped atrous launch behind them is 324 tiles on
+                # 256 CUs, i.e. a second round with 188 CUs idle.  Forward only: the small branches go to the (otherwise idle) side stream
+                # and run in that shadow; the projection conv joins them.
+                cat2 = Act(self, "dec_cat", B, H // 4, W // 4, 304)
+                yl, slab, rows = self._conv(low, "conv2.weight", 48, name="lowproj")
+                self._bn(yl, slab, rows, "bn2", True, out=cat2.slice("low48", 256, 48))
+                self._fork_forward(small_begin)
         if group:
             self._dilated_group_fwd(group)
             for y, slab, rows, i in pending:
                 self._bn(y, slab, rows, f"aspp{i}.bn", True, out=cat1.slice(f"aspp{i}", 256 * (i - 1), 256))
+        if getattr(self, "_forked", False):
+            join = lambda: L.call("dc_stream_fence", C.c_void_p(self.side.cuda_stream), L.stream_ptr())   # noqa: E731
+            self.fwd_train.append(join)
+            self.fwd_eval.append(join)
         y, slab, rows = self._conv(cat1, "conv1.weight", 256, name="proj")
         p = self._bn(y, slab, rows, "bn1", True)
 
         # ---- decoder
-        cat2 = Act(self, "dec_cat", B, H // 4, W // 4, 304)
-        yl, slab, rows = self._conv(low, "conv2.weight", 48, name="lowproj")
-        self._bn(yl, slab, rows, "bn2", True, out=cat2.slice("low48", 256, 48))
+        if not getattr(self, "_forked", False):
+            cat2 = Act(self, "dec_cat", B, H // 4, W // 4, 304)
+            yl, slab, rows = self._conv(low, "conv2.weight", 48, name="lowproj")
+            self._bn(yl, slab, rows, "bn2", True, out=cat2.slice("low48", 256, 48))
         U = "upsample."
         y, slab, rows = self._conv(p, U + "deconv1.0.weight", 256, transposed=True, name="deconv1", sole_consumer=True)
         a = self._bn(y, slab, rows, U + "deconv1.1", True)
