@@ -180,6 +180,8 @@ class Engine:
         # pass and writes the BatchNorm input's gradient itself in a second one (dc_head_bwd_bnin_apply)
         self.fuse_head_apply = os.environ.get("DC_FUSE_HEAD_APPLY", "1") != "0"
         self.inline_last_wgrad = os.environ.get("DC_INLINE_LAST_WGRAD", "1") != "0"
+        self.pack_side = os.environ.get("DC_PACK_SIDE", "1") != "0"       # the batch's layout pass beside the weight repack
+        self._layout_forked = False
         self.aspp_side = os.environ.get("DC_ASPP_SIDE", "1") != "0"       # forward: the small ASPP branches beside the grouped atrous launch
         # depthwise weight gradient taken inside the depthwise data gradient (dc_dwconv_dgrad_bnstats_wgrad) where the layer's input is a
         # never-stored BatchNorm output: the separate dc_dwconv_wgrad launch (and its second read of dy and y) disappears.  On the tiled
@@ -690,8 +692,14 @@ class Engine:
             self._x0_own = x0.buf
 
             def layout_fwd():
+                if self._layout_forked:          # issued beside the weight repack (_run_forward): join the side stream here
+                    self._layout_forked = False
+                    L.call("dc_stream_fence", C.c_void_p(self.side.cuda_stream), L.stream_ptr())
+                    return
                 if self.x_in is not None:        # NCHW fp32 batch: the one layout pass; else x0.buf already IS the NHWC batch
                     L.call("dc_nchw_to_nhwc", self.dt, B, self.n_input, H, W, L.dptr(self.x_in), x0.ptr, x0.ld, self._st())
+
+            self._layout_op = layout_fwd
 
             self.fwd_train.append(layout_fwd)
             self.fwd_eval.append(layout_fwd)
@@ -1020,6 +1028,13 @@ class Engine:
         if train and self.B < 2:
             raise ValueError("Expected more than 1 value per channel when training, got input size torch.Size([1, 256, 1, 1])")
         if self.packed_version != self.version[0]:
+            if (self.pack_side and self.use_side_stream and self.x_in is not None and getattr(self, "_layout_op", None) is not None):
+                # the layout pass of the batch (NCHW fp32 -> NHWC) does not need the weights: it runs on the side stream beside the repack
+                # (both are short memory-bound kernels that leave the other room); layout_fwd joins
+                L.call("dc_stream_fence", L.stream_ptr(), C.c_void_p(self.side.cuda_stream))
+                with torch.cuda.stream(self.side):
+                    self._layout_op()
+                self._layout_forked = True
             self.pack_weights()
         marks = self.region_marks if train else None      # measurement hook: events at the encoder's boundaries
         if marks is not None:
