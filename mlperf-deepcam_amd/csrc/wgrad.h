@@ -33,6 +33,16 @@ void wgrad256_set_slots(int n);   // workgroups a launch of the 256-tile kernel 
 int launch_wgrad256(const WgradParams& p, hipStream_t st, int group = 1, const void* const* xs = nullptr, const void* const* dys = nullptr,
                     float* const* slabs = nullptr);
 
+// wgrad384.hip: pointwise (1x1, stride 1) layers on a 256 (co) x 384 (ci) tile; up to WG384_MAXL layers of one geometry per launch; outs[l] is
+// layer l's [splits][Co][Ci] slab or, with splits == 1, its gradient tensor
+constexpr int WG384_MAXL = 16;
+bool wgrad384_eligible(const GatherGeom& g, int ldx, int lddy, long M);
+void wgrad384_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group = 1);
+void wgrad384_set_slots(int n);
+void wgrad384_set_min_stages(int n);
+int launch_wgrad384(const WgradParams& p, hipStream_t st, int group = 1, const void* const* xs = nullptr, const void* const* dys = nullptr,
+                    float* const* outs = nullptr);
+
 // thinconv.hip: all nine taps of the 16->32 (stride 2) and 32->64 stem convolutions in one pass over x and dy
 bool thin_wgrad_eligible(const dc_conv_desc& d, int Hi, int Wi);
 int thin_wgrad_splits(const dc_conv_desc& d, int N, int Hi, int Wi);

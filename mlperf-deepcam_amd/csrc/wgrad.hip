@@ -456,6 +456,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 static int g_wgrad_mode = 1;               // 1 = LDS-DMA 3-stage kernel, 0 = register-staged kernel
 static int g_thin_wgrad = 1;               // one-pass kernel for the two thin stem convolutions (thinconv.hip)
 static int g_wgrad256_pad = 115;           // tuning switch "wgrad256_pad"
+static int g_wgrad384 = 1;                 // 256 x 384 pointwise kernel: 0 never, 1 planner, 2 wherever eligible (tests)
 static int g_wgrad256 = 1;                 // 0: 128-tile kernel only, 1: planner, 2: 256-tile kernel wherever eligible (bf16)
 static int g_wgrad_target_blocks = 768;    // resident capacity: 256 CUs x 3 workgroups (48 KiB LDS, 146 registers)
 
@@ -509,6 +510,21 @@ extern "C" int dc_wgrad_set_slots(int n) {
   return 0;
 }
 
+extern "C" int dc_wgrad_set_384(int m) {
+  g_wgrad384 = m;
+  return 0;
+}
+extern "C" int dc_wgrad_set_384_slots(int n) {
+  if (n < 1) return dc_fail("dc_set_option: wgrad384_slots must be positive", __FILE__, __LINE__);
+  wgrad384_set_slots(n);
+  return 0;
+}
+extern "C" int dc_wgrad_set_384_min_stages(int n) {
+  if (n < 1) return dc_fail("dc_set_option: wgrad384_min_stages must be positive", __FILE__, __LINE__);
+  wgrad384_set_min_stages(n);
+  return 0;
+}
+
 extern "C" int dc_wgrad_set_pad(int pct) {
   g_wgrad256_pad = pct < 100 ? 100 : pct;
   return 0;
@@ -526,6 +542,26 @@ static bool wgrad256_wins(const GatherGeom& g) {
   const long pad256 = (long)cdiv(g.Cin, 256) * 256 * cdiv(g.Cout, 256) * 256;
   const long pad128 = (long)cdiv(g.Cin, 128) * 128 * cdiv(g.Cout, 128) * 128;
   return pad256 * 100 <= pad128 * g_wgrad256_pad;   // at most (g_wgrad256_pad - 100) % more padded work than the small tile
+}
+
+// Pointwise layers whose input-channel extent pads no more on 384-wide tiles than on 256-wide ones go to the 256 x 384 kernel (wgrad384.hip)
+static bool wgrad384_wins(const GatherGeom& g) {
+  if (g_wgrad384 == 0 || !wgrad384_eligible(g, 0, 0, 0)) return false;
+  if (g_wgrad384 == 2) return true;
+  if (!wgrad256_wins(g)) return false;
+  const long pad384 = (long)cdiv(g.Cin, 384) * 384 * cdiv(g.Cout, 256) * 256;
+  const long pad256 = (long)cdiv(g.Cin, 256) * 256 * cdiv(g.Cout, 256) * 256;
+  return pad384 <= pad256 && g.Cin >= 384;
+}
+// the "big tile" plan and launch of a layer the 256-tile planner accepts: 256 x 384 where it wins, else 256 x 256
+static void wgrad_big_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group = 1) {
+  if (wgrad384_wins(g)) wgrad384_plan(g, M, splits, chunk, group);
+  else wgrad256_plan(g, M, splits, chunk, group);
+}
+static int launch_wgrad_big(const WgradParams& p, hipStream_t st, int group = 1, const void* const* xs = nullptr, const void* const* dys = nullptr,
+                            float* const* slabs = nullptr) {
+  if (wgrad384_wins(p.g)) return launch_wgrad384(p, st, group, xs, dys, slabs);
+  return launch_wgrad256(p, st, group, xs, dys, slabs);
 }
 
 static int launch_wgrad_reduce(const float* slab, float* grad_w, int splits, const GatherGeom& g, int transposed, hipStream_t st) {
@@ -549,7 +585,7 @@ extern "C" size_t dc_conv_wgrad_workspace(const dc_conv_desc* d, int N, int Hi, 
   plan_splits(g, (long)N * g.Qh * g.Qw, d->dtype == DC_BF16 ? 64 : 32, &splits, &chunk);
   if (d->dtype == DC_BF16) {   // either tile shape may serve the layer: size for the larger plan
     int s2, c2;
-    wgrad256_plan(g, (long)N * g.Qh * g.Qw, &s2, &c2);
+    wgrad_big_plan(g, (long)N * g.Qh * g.Qw, &s2, &c2);
     if (s2 > splits) splits = s2;
     if (thin_wgrad_eligible(*d, Hi, Wi)) {
       const int s3 = thin_wgrad_splits(*d, N, Hi, Wi);
@@ -568,17 +604,18 @@ static int plan_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, bool transfo
   DC_REQUIRE(M < (1L << 31) - 256, "dc_conv_wgrad: too many pixels for 32-bit indexing");
   p->N = N; p->M = (int)M;
   if (count > 1) {
-    DC_REQUIRE(count <= WG_MAXGROUP && !transform && d->dtype == DC_BF16 && !(g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi)) && wgrad256_wins(p->g),
+    DC_REQUIRE(!transform && d->dtype == DC_BF16 && !(g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi)) && wgrad256_wins(p->g) &&
+                   count <= (wgrad384_wins(p->g) ? WG384_MAXL : WG_MAXGROUP),
                "dc_conv_wgrad: this layer is not served by the grouped launch");
     *kind = WK_256;
-    wgrad256_plan(p->g, M, &p->splits, &p->chunk, count);
+    wgrad_big_plan(p->g, M, &p->splits, &p->chunk, count);
     return 0;
   }
   const int BP = d->dtype == DC_BF16 ? 64 : 32;    // chunk granularity (a multiple of both kernels' pixels per stage)
   const bool thin = !transform && g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi);
   const bool big = !transform && !thin && d->dtype == DC_BF16 && wgrad256_wins(p->g);
   if (thin) { p->splits = thin_wgrad_splits(*d, N, Hi, Wi); p->chunk = 0; *kind = WK_THIN; }
-  else if (big) { wgrad256_plan(p->g, M, &p->splits, &p->chunk); *kind = WK_256; }
+  else if (big) { wgrad_big_plan(p->g, M, &p->splits, &p->chunk); *kind = WK_256; }
   else { plan_splits(p->g, M, BP, &p->splits, &p->chunk); *kind = (g_wgrad_mode == 1 && !transform) ? WK_DMA : WK_REG; }
   return 0;
 }
@@ -590,7 +627,7 @@ static int launch_wgrad_partial(const dc_conv_desc* d, const WgradParams& p, Wgr
   if (kind == WK_THIN) {
     if (int e = launch_thin_wgrad(*d, N, Hi, Wi, p.x, p.ldx, p.dy, p.lddy, p.slab, st)) return e;
   } else if (kind == WK_256) {
-    if (int e = launch_wgrad256(p, st, group, xs, dys, slabs)) return e;
+    if (int e = launch_wgrad_big(p, st, group, xs, dys, slabs)) return e;
   } else if (kind == WK_DMA) {
     const size_t lds = 3 * 2 * 8192;
     if (d->dtype == DC_BF16) {
@@ -657,9 +694,9 @@ extern "C" size_t dc_conv_wgrad_group_workspace(const dc_conv_desc* d, int N, in
   GatherGeom g;
   if (d == nullptr || count < 1 || !build_geom(*d, Hi, Wi, kFwd, &g)) return 0;
   const size_t single = dc_conv_wgrad_workspace(d, N, Hi, Wi);
-  if (count == 1 || count > WG_MAXGROUP || !wgrad_group_eligible(*d, g, Hi, Wi)) return single;
+  if (count == 1 || !wgrad_group_eligible(*d, g, Hi, Wi) || count > (wgrad384_wins(g) ? WG384_MAXL : WG_MAXGROUP)) return single;
   int splits, chunk;
-  wgrad256_plan(g, (long)N * g.Qh * g.Qw, &splits, &chunk, count);
+  wgrad_big_plan(g, (long)N * g.Qh * g.Qw, &splits, &chunk, count);
   const size_t grouped = (size_t)count * splits * g.ntaps * g.Cout * g.Cin * sizeof(float);
   return grouped > single ? grouped : single;
 }
@@ -671,7 +708,7 @@ extern "C" int dc_conv_wgrad_group(const dc_conv_desc* d, int N, int Hi, int Wi,
   DC_REQUIRE(count >= 1, "dc_conv_wgrad_group: empty group");
   WgradParams p;
   if (!build_geom(*d, Hi, Wi, kFwd, &p.g)) return dc_fail("dc_conv_wgrad_group: unsupported geometry", __FILE__, __LINE__);
-  if (count == 1 || count > WG_MAXGROUP || !wgrad_group_eligible(*d, p.g, Hi, Wi)) {
+  if (count == 1 || !wgrad_group_eligible(*d, p.g, Hi, Wi) || count > (wgrad384_wins(p.g) ? WG384_MAXL : WG_MAXGROUP)) {
     for (int l = 0; l < count; ++l)
       if (int e = dc_conv_wgrad(d, N, Hi, Wi, xs[l], ldx, dys[l], lddy, workspace, workspace_bytes, grad_ws[l], stream)) return e;
     return 0;
@@ -683,15 +720,16 @@ extern "C" int dc_conv_wgrad_group(const dc_conv_desc* d, int N, int Hi, int Wi,
   }
   const long M = (long)N * p.g.Qh * p.g.Qw;
   DC_REQUIRE(M < (1L << 31) - 256, "dc_conv_wgrad_group: too many pixels for 32-bit indexing");
-  wgrad256_plan(p.g, M, &p.splits, &p.chunk, count);
+  wgrad_big_plan(p.g, M, &p.splits, &p.chunk, count);
   const size_t per_layer = (size_t)p.splits * p.g.ntaps * p.g.Cout * p.g.Cin;   // floats
   DC_REQUIRE(workspace_bytes >= per_layer * count * sizeof(float), "dc_conv_wgrad_group: workspace too small");
-  float* slabs[WG_MAXGROUP];
+  float* slabs[WG384_MAXL];
+  static_assert(WG384_MAXL >= WG_MAXGROUP, "slab pointer array");
   for (int l = 0; l < count; ++l) slabs[l] = (float*)workspace + per_layer * l;
   p.x = xs[0]; p.dy = dys[0]; p.slab = slabs[0];
   p.N = N; p.ldx = ldx; p.lddy = lddy; p.M = (int)M;
   hipStream_t st = (hipStream_t)stream;
-  if (int e = launch_wgrad256(p, st, count, xs, dys, slabs)) return e;
+  if (int e = launch_wgrad_big(p, st, count, xs, dys, slabs)) return e;
   for (int l = 0; l < count; ++l)
     if (int e = launch_wgrad_reduce(slabs[l], grad_ws[l], p.splits, p.g, d->transposed, st)) return e;
   return 0;

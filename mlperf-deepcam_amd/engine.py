@@ -197,7 +197,10 @@ class Engine:
         # 40.31 / 40.28 / 40.10 / 40.18) -- the fp32 split slabs (256 KiB per workgroup whatever the batch) are a third of a 728-channel
         # weight gradient's time at batch 2, and a group of three writes and re-reads a third of them.
         wg = os.environ.get("DC_WGRAD_GROUP", "auto")
-        self.wgrad_group = 3 if wg == "auto" else max(1, min(4, int(wg)))
+        # Round 5: the pointwise layers run on 256 x 384 tiles (csrc/wgrad384.hip), which take up to 16 layers per launch; groups of 3 / 4 / 6 / 12:
+        # local batch 8 35.35 / 35.20 / 35.02 / 34.95 ms, batch 2 13.27 / - / 13.09 / 13.14, batch 4 20.51 / - / 20.40 / 20.34 (one job each,
+        # profiles/r05_ab_wgrad384.txt); the 256 x 256 kernel keeps at most four
+        self.wgrad_group = 6 if wg == "auto" else max(1, min(16, int(wg)))
         self._wg_recs: List[dict] = []
         # Weight-gradient partial sums stay in per-layer slabs and are folded by dc_fold_slabs (csrc/fold.hip): one fold per dense
         # weight-gradient launch, which also takes the rows that the depthwise data-gradient kernels since the previous fold have left.
@@ -950,8 +953,8 @@ class Engine:
                 j += 1
             d, x = r0["d"], r0["x"]
             splits, sbytes = C.c_int(), C.c_size_t()
-            if j > i and lib.dc_conv_wgrad_plan(C.byref(d), x.N, x.H, x.W, j + 1 - i, C.byref(splits), C.byref(sbytes)) != 0:
-                j = i                                   # the grouped launch does not serve this geometry: one launch per layer
+            while j > i and lib.dc_conv_wgrad_plan(C.byref(d), x.N, x.H, x.W, j + 1 - i, C.byref(splits), C.byref(sbytes)) != 0:
+                j -= 1                                  # the grouped launch serves fewer layers of this geometry (or none: one launch per layer)
             members = recs[i:j + 1]
             cnt = len(members)
             L.call("dc_conv_wgrad_plan", C.byref(d), x.N, x.H, x.W, cnt, C.byref(splits), C.byref(sbytes))

@@ -28,6 +28,15 @@ def call(name, *args):
             macs = N * Ho * Wo * d.cin * d.cout * k * k
         fl = 2.0 * macs
         key = f"{name} k{k}s{d.stride}d{d.dil}{'T' if d.transposed else ''} {d.cin}->{d.cout} @{Hi}x{Wi}"
+    elif name == "dc_conv_wgrad_partial":
+        d = args[0]._obj; N, Hi, Wi, cnt = args[1], args[2], args[3], args[4]
+        k = 3 if d.transposed else d.k
+        if d.transposed: macs = N * Hi * Wi * d.cin * d.cout * 9
+        else:
+            Ho = (Hi + 2 * d.pad - d.dil * (k - 1) - 1) // d.stride + 1; Wo = (Wi + 2 * d.pad - d.dil * (k - 1) - 1) // d.stride + 1
+            macs = N * Ho * Wo * d.cin * d.cout * k * k
+        fl = 2.0 * macs * cnt
+        key = f"{name} x{cnt} splits{args[10]} k{k}s{d.stride}d{d.dil}{'T' if d.transposed else ''} {d.cin}->{d.cout} @{Hi}x{Wi}"
     elif name.startswith("dc_dwconv") and name != "dc_dwconv_pack_weights":
         key = f"{name} C{args[1]} s{args[2]} d{args[3]} @{args[5]}x{args[6]}"
     elif name in ("dc_bn_apply", "dc_bn_bwd_reduce", "dc_bn_bwd_apply"):

@@ -16,6 +16,7 @@ regenerated from seeds by the tests; expected outputs are stored here):
   model_full.json      G4  768x1152 B=2 (only with --full)
   model_full_b4.json   G4  768x1152 B=4, two Adam steps (only with --full or --only full_b4)
   model_full_b8.json   G4  768x1152 B=8 (the benched local batch), two Adam steps (only with --only full_b8; ~50 GB resident)
+  model_full_b8_adamw.json  G4  768x1152 B=8, two AdamW steps, wd 1e-2 (only with --only full_b8_adamw; ~50 GB resident)
   lr_schedule.json     G5  MultiStepLR sequences through the reference's get_lr_schedule
 """
 import argparse
@@ -261,6 +262,14 @@ def g4_model_full_b8():
     json.dump(out, open(os.path.join(HERE, "model_full_b8.json"), "w"), indent=0)
 
 
+def g4_model_full_b8_adamw():
+    """The decoupled-decay half of the benched LAMB path at the benched shape: two AdamW steps (wd 1e-2) of the
+    reference at local batch 8, full size (train_hdf5_ddp.py:215-216)."""
+    out = {"recipe": "as model_small.json with B=8, AdamW wd 1e-2", "H": 768, "W": 1152, "B": 8}
+    out["adamw_wd1e-2"], _ = run_model_steps(768, 1152, "AdamW", 2, 1e-2, B=8)
+    json.dump(out, open(os.path.join(HERE, "model_full_b8_adamw.json"), "w"), indent=0)
+
+
 def g5_lr():
     out = {}
     arg = {"type": "multistep", "milestones": "3 6", "decay_rate": "0.1"}
@@ -308,4 +317,6 @@ if __name__ == "__main__":
         g4_model_full_b4()
     if a.only == "full_b8":
         g4_model_full_b8()
+    if a.only == "full_b8_adamw":
+        g4_model_full_b8_adamw()
     print("golden fixtures written to", HERE)
