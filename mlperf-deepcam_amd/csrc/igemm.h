@@ -63,6 +63,10 @@ bool pw384_eligible(const IgemmParams& p);
 int launch_pw384(const IgemmParams& p, int npb, hipStream_t st);
 inline long pw384_tiles(const IgemmParams& p, int npb) { return (long)((p.g.Cout + 383) / 384) * ((p.M + 32 * npb - 1) / (32 * npb)); }
 
+// igemm192.hip: pointwise layers with few pixels (local batch 2) on a 128 x 192 tile, eight waves, four 64-deep ring stages
+long pw192_tiles(const IgemmParams& p);
+int launch_pw192(const IgemmParams& p, hipStream_t st);
+
 // thinconv.hip: the thin 3x3 stem convolutions (forward and data gradient) without LDS staging of the pixel operand
 bool thin_fwd_eligible(const GatherGeom& g, int dtype, int bias, int accumulate, int out32);
 void thin_set_tile(int v);

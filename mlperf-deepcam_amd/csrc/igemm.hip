@@ -538,12 +538,14 @@ static int g_igemm256p = 1;          // persistent 256-tile kernel for multi-rou
 static int g_igemm256p_wgs = 0;      // its workgroups ("igemm256p_wgs"); 0: fewest that keep the number of rounds
 static int g_igemm256p_min = 257;    // fewest tiles it is used for ("igemm256p_min")
 static int g_pw384 = 1;
+static int g_pw192 = 1;             // 128 x 192 tiles for one-round launches of few pixels ("pw192")
 static int g_pw384_k64 = 1;         // 256 x 384 tiles with 128-byte K rows where the planner picks that tile ("pw384_k64")
 static int pw384_plan(const IgemmParams& p) {
   if (g_pw384 == 0 || !pw384_eligible(p)) return 0;
   if (g_pw384 == 2) return 8;
   if (g_pw384 == 3) return 4;
   if (g_pw384 == 4) return 64;      // 256 x 384 tiles, 64-deep stages of 128-byte rows
+  if (g_pw384 == 5) return 192;     // 128 x 192 tiles (igemm192.hip)
   const long t128 = (long)cdiv(p.g.Cout, BN) * p.mtiles, t256 = igemm256_tiles(p);
   const double c_old = (double)(cdiv(t256, 256) < cdiv(t128, 768) ? cdiv(t256, 256) : cdiv(t128, 768));
   if (p.g.Cout * 10 < (long)cdiv(p.g.Cout, 384) * 384 * 9) return 0;      // a 384-wide tile that is more than a tenth empty loses
@@ -553,6 +555,10 @@ static int pw384_plan(const IgemmParams& p) {
   const bool k64 = g_pw384_k64 && p.g.Cin >= 128;
   const double c8 = t8 >= 160 ? cdiv(t8, 256) * (k64 ? 1.3 : 1.5) : 1e9, c4 = t4 >= 160 ? cdiv(t4, 256) * 0.8 : 1e9;
   const double best = c8 < c4 ? c8 : c4;
+  // few pixels (local batch 2): 128 x 192 tiles when they are ONE round of one workgroup per CU and neither 384-wide tile fills the chip
+  // (728 -> 728 at M = 6 912: 216 tiles; 24.6 -> 14 us against the 128 x 128 kernel's 324 tiles, scripts/pw384_bench.py)
+  const long t192 = pw192_tiles(p);
+  if (g_pw192 && best >= 1e9 && t192 >= 160 && t192 <= 256 && p.g.Cin >= 128 && p.g.Cout * 10 >= (long)cdiv(p.g.Cout, 192) * 192 * 9) return 192;
   if (best >= 0.9 * c_old) return 0;
   return c8 < c4 ? (k64 ? 64 : 8) : 4;
 }
@@ -614,7 +620,7 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   if (bst == nullptr && g_thin_fwd && thin_fwd_eligible(p.g, d->dtype, bias != nullptr, accumulate, out32))
     return launch_thin_fwd(p.g, N, in, ldin, w, p.ldw, out, ldout, slab, p.mtiles * p.g.os * p.g.os, st);
   if (d->dtype == DC_BF16 && !out32 && bst == nullptr) {      // (the BatchNorm-backward epilogue lives in the LDS-epilogue kernels)
-    if (const int npb = pw384_plan(p)) return launch_pw384(p, npb, st);
+    if (const int npb = pw384_plan(p)) return npb == 192 ? launch_pw192(p, st) : launch_pw384(p, npb, st);
   }
   if (d->dtype == DC_BF16 && !out32 && g_igemm256 != 0) {
     if (g_igemm256 == 2 || igemm256_wins(p)) {
@@ -880,6 +886,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm256p_wgs") == 0) { g_igemm256p_wgs = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256p_min") == 0) { g_igemm256p_min = value; return 0; }
   if (name != nullptr && strcmp(name, "pw384_k64") == 0) { g_pw384_k64 = value; return 0; }
+  if (name != nullptr && strcmp(name, "pw192") == 0) { g_pw192 = value; return 0; }
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "thin_tile") == 0) { thin_set_tile(value); return 0; }
   if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }
@@ -907,7 +914,7 @@ extern "C" int dc_set_option(const char* name, int value) {
 // so that a switch one test leaves behind cannot change what the next one measures -- a stale "restore" of this kind once ran the model
 // tests on an experimental kernel), and the library applies the same table when it is loaded, so the table IS the default.
 static const struct { const char* name; int value; } kOptionDefaults[] = {
-    {"igemm_mode", 2}, {"igemm256", 1}, {"pw384", 1}, {"pw384_k64", 1}, {"igemm256p", 1}, {"igemm256p_wgs", 0}, {"igemm256p_min", 257},
+    {"igemm_mode", 2}, {"igemm256", 1}, {"pw384", 1}, {"pw384_k64", 1}, {"pw192", 1}, {"igemm256p", 1}, {"igemm256p_wgs", 0}, {"igemm256p_min", 257},
     {"thin_fwd", 1}, {"thin_tile", 1}, {"igemm256_rel", 0}, {"pack_blocks", 2048},
     {"igemm256_phase_fast", 1}, {"wgrad_target_blocks", 768},
     {"wgrad_mode", 1}, {"wgrad_min_steps", 16}, {"wgrad256", 1}, {"wgrad256_pad", 115}, {"thin_wgrad", 1}, {"wgrad256_slots", 192}, {"wgrad256_min_stages", 96},

@@ -118,7 +118,7 @@ def test_conv_256_tile_wgrad_kernel(case):
 PW_CASES = [c for c in CONV_CASES if c[1] == 1 and c[2] == 1 and c[6] >= 64 and c[8] * c[9] * c[10] > 16]
 
 
-@pytest.mark.parametrize("mode", [2, 3], ids=["256x384", "128x384"])
+@pytest.mark.parametrize("mode", [2, 3, 5], ids=["256x384", "128x384", "128x192"])
 @pytest.mark.parametrize("case", PW_CASES, ids=[c[0] for c in PW_CASES])
 def test_conv_pointwise_384_tile_kernel(case, mode):
     """The two-waves-per-SIMD 256 x 384 / 128 x 384 pointwise kernel (csrc/igemm384.hip), forced on every eligible forward and
@@ -152,7 +152,7 @@ def test_conv_pointwise_384_tile_kernel_same_bits(shape):
     rows = L.load().dc_conv_stat_rows(C.byref(d), N, H, W)
     got = []
     try:
-        for mode in (0, 2, 3):
+        for mode in (0, 2, 3, 5):
             L.call("dc_set_option", b"pw384", mode)
             ybuf, yv = empty_nhwc(N, H, W, cout, dtype, ld=cout + 24, off=16)
             slab = torch.full((2, rows, cout), float("nan"), device=dev())
