@@ -548,6 +548,11 @@ static bool wgrad256_wins(const GatherGeom& g) {
 static bool wgrad384_wins(const GatherGeom& g) {
   if (g_wgrad384 == 0 || !wgrad384_eligible(g, 0, 0, 0)) return false;
   if (g_wgrad384 == 2) return true;
+  if (g.ntaps > 1) {
+    // 3 x 3 "same" convolutions: the x axis is [tap][ci] in quads of 64 channels, so any input width fills the 384-wide tiles to within
+    // half a tile (304 -> 256: 45 quads = 7.5 tiles); the layer must fill the 256 output channels of a tile to three quarters
+    return g_wgrad384 != 3 && g.Cin >= 64 && (long)cdiv(g.Cout, 256) * 256 * 3 <= (long)g.Cout * 4;
+  }
   if (!wgrad256_wins(g)) return false;
   const long pad384 = (long)cdiv(g.Cin, 384) * 384 * cdiv(g.Cout, 256) * 256;
   const long pad256 = (long)cdiv(g.Cin, 256) * 256 * cdiv(g.Cout, 256) * 256;
@@ -604,7 +609,7 @@ static int plan_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, bool transfo
   DC_REQUIRE(M < (1L << 31) - 256, "dc_conv_wgrad: too many pixels for 32-bit indexing");
   p->N = N; p->M = (int)M;
   if (count > 1) {
-    DC_REQUIRE(!transform && d->dtype == DC_BF16 && !(g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi)) && wgrad256_wins(p->g) &&
+    DC_REQUIRE(!transform && d->dtype == DC_BF16 && !(g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi)) && (wgrad256_wins(p->g) || wgrad384_wins(p->g)) &&
                    count <= (wgrad384_wins(p->g) ? WG384_MAXL : WG_MAXGROUP),
                "dc_conv_wgrad: this layer is not served by the grouped launch");
     *kind = WK_256;
@@ -613,7 +618,7 @@ static int plan_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, bool transfo
   }
   const int BP = d->dtype == DC_BF16 ? 64 : 32;    // chunk granularity (a multiple of both kernels' pixels per stage)
   const bool thin = !transform && g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi);
-  const bool big = !transform && !thin && d->dtype == DC_BF16 && wgrad256_wins(p->g);
+  const bool big = !transform && !thin && d->dtype == DC_BF16 && (wgrad256_wins(p->g) || wgrad384_wins(p->g));
   if (thin) { p->splits = thin_wgrad_splits(*d, N, Hi, Wi); p->chunk = 0; *kind = WK_THIN; }
   else if (big) { wgrad_big_plan(p->g, M, &p->splits, &p->chunk); *kind = WK_256; }
   else { plan_splits(p->g, M, BP, &p->splits, &p->chunk); *kind = (g_wgrad_mode == 1 && !transform) ? WK_DMA : WK_REG; }
@@ -687,7 +692,7 @@ int conv_wgrad_bnin(const dc_conv_desc* d, int N, int Hi, int Wi, const void* y,
 // Grouped form: `count` layers of ONE geometry (same descriptor, extents and row strides) in one launch of the 256-tile
 // kernel and one reduction per layer.  Layers the 256-tile kernel does not serve fall back to `count` plain calls.
 static bool wgrad_group_eligible(const dc_conv_desc& d, const GatherGeom& g, int Hi, int Wi) {
-  return d.dtype == DC_BF16 && !(g_thin_wgrad && thin_wgrad_eligible(d, Hi, Wi)) && wgrad256_wins(g);
+  return d.dtype == DC_BF16 && !(g_thin_wgrad && thin_wgrad_eligible(d, Hi, Wi)) && (wgrad256_wins(g) || wgrad384_wins(g));
 }
 
 extern "C" size_t dc_conv_wgrad_group_workspace(const dc_conv_desc* d, int N, int Hi, int Wi, int count) {

@@ -62,9 +62,14 @@ struct Wg384Params {
   const void* zero_page;
   int Cin, Cout, ldx, lddy;
   int M, splits, chunk, nlayers;
+  // the x axis of the GEMM is [tap][ci] in quads of 64 channels (cq per tap; a pointwise layer has one tap); TAPS kernels: a stride-1 "same"
+  // convolution of H x W images, tap t gathers at (oy + tdy[t], ox + tdx[t]) and writes slab plane twidx[t]
+  int ntaps, cq, H, W;
+  int tdy[9], tdx[9], twidx[9];
+  FastDiv div_hw, div_w;
   const void* x[WG384_MAXL];
   const void* dy[WG384_MAXL];
-  float* out[WG384_MAXL];       // [split][Co][Ci] per layer (splits == 1: the gradient tensor)
+  float* out[WG384_MAXL];       // [split][tap][Co][Ci] per layer
 };
 
 __device__ inline void mfma_v(f32x4& c, const bf16x8& av, const bf16x8& bv) {
@@ -92,7 +97,18 @@ __device__ inline void static_for(F&& f) {
     static_for<I + 1, N>(f);
   }
 }
+// a word of the kernel-argument segment at a wave-uniform (run-time) index: a scalar load (indexing the by-value struct would move it to
+// scratch memory)
+template <typename T>
+__device__ inline T karg(size_t field_offset, int index) {
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  return *(const T*)(ka + field_offset + sizeof(T) * index);
+}
 
+// TAPS = false: pointwise layers (one tap at (0, 0)); true: stride-1 "same" convolutions with several taps (3 x 3, dilated or not): the six
+// quads of a workgroup's x tile are consecutive quads of the [tap][ci] axis, so a tile may straddle two taps; every x instruction carries its
+// tap's pixel offset, and a lane tracks the image position of its pixel row for the halo test.
+template <bool TAPS>
 __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -101,13 +117,14 @@ __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
   const int wc = wave & 1;       // ci group (192 channels = quads 3 wc .. 3 wc + 2 of the x tile)
   const bool late = wave >= 4;   // the second wave of its SIMD
 
-  // ---- tile decode.  XCD-aware order: consecutive tiles of an XCD are the (ci, co) tiles of ONE pixel split of one layer.
-  const int nci = (p.Cin + TCI - 1) / TCI, nco = (p.Cout + TCO - 1) / TCO;
+  // ---- tile decode.  XCD-aware order: consecutive tiles of an XCD are the (x, co) tiles of ONE pixel split of one layer.
+  const int nq = p.ntaps * p.cq;                    // quads on the x axis
+  const int nxt = (nq + 5) / 6, nco = (p.Cout + TCO - 1) / TCO;
   const int nwg = gridDim.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
   int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + xslot;
-  const int ci0 = (tile % nci) * TCI;
-  tile /= nci;
+  const int q0 = (tile % nxt) * 6;
+  tile /= nxt;
   const int co0 = (tile % nco) * TCO;
   tile /= nco;
   const int split = tile % p.splits, layer = tile / p.splits;
@@ -115,43 +132,73 @@ __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
   const int mend = min(p.M, mbeg + p.chunk);
   const int npix = mend > mbeg ? mend - mbeg : 0;
   const int steps = (npix + BP - 1) / BP;
-  // the layer's pointers from the kernel-argument segment (scalar loads at a wave-uniform offset; indexing the by-value struct would
-  // move it to scratch memory)
-  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
-  const uintptr_t xbase = *(const uintptr_t*)(ka + __builtin_offsetof(Wg384Params, x) + 8 * layer);
-  const uintptr_t dbase = *(const uintptr_t*)(ka + __builtin_offsetof(Wg384Params, dy) + 8 * layer);
-  float* const obase = *(float* const*)(ka + __builtin_offsetof(Wg384Params, out) + 8 * layer);
+  const uintptr_t xbase = karg<uintptr_t>(__builtin_offsetof(Wg384Params, x), layer);
+  const uintptr_t dbase = karg<uintptr_t>(__builtin_offsetof(Wg384Params, dy), layer);
+  float* const obase = karg<float*>(__builtin_offsetof(Wg384Params, out), layer);
   const uintptr_t zp = (uintptr_t)p.zero_page;
 
   // ---- LDS-DMA bookkeeping.  Instruction q = 8 i + wave of a stage fills 1 KiB at q * 1024: rows 8 (q & 3) .. + 7 of quad q >> 2
-  // (q < 16: dy tile, else x tile).  q & 3 = wave & 3 for every i, so a lane's pixel row is the same in all five instructions.
+  // (q < 16: dy tile, else x tile).  q & 3 = wave & 3 for every i, so a lane's pixel row is the same in all five instructions; what
+  // differs per instruction is wave-uniform: the quad's channel base (and, for x, its tap).
   const int drow = 8 * (wave & 3) + (lane >> 3);                     // pixel row of the stage (0 .. 31)
   const int dsub = ((lane & 7) >> 1) ^ ((drow >> 1) & 3);            // logical 16-channel chunk of the quad this lane's 16 bytes belong to
   const int dch = dsub * 16 + (lane & 1) * 8;                        // channel inside the quad
-  unsigned src[IPW];                                                 // byte offset from the stage's first pixel row; ~0u: channel out of range
+  const unsigned lsrc_d = (unsigned)((drow * p.lddy + dch) * 2), lsrc_x = (unsigned)((drow * p.ldx + dch) * 2);
+  int dlim[2], xlim[3], tdy[3], tdx[3];
+  long doff[2], xoff[3];
 #pragma unroll
-  for (int i = 0; i < IPW; ++i) {
-    const int quad = 2 * i + (wave >> 2);                            // 0 .. 9; < 4: dy
-    if (i < 2) {
-      const int ch = co0 + quad * 64 + dch;
-      src[i] = ch < p.Cout ? (unsigned)(((size_t)drow * p.lddy + ch) * 2) : ~0u;
-    } else {
-      const int ch = ci0 + (quad - 4) * 64 + dch;
-      src[i] = ch < p.Cin ? (unsigned)(((size_t)drow * p.ldx + ch) * 2) : ~0u;
-    }
+  for (int i = 0; i < 2; ++i) {
+    const int c = co0 + (2 * i + (wave >> 2)) * 64;
+    doff[i] = (long)c * 2;
+    dlim[i] = p.Cout - c;                                            // the lane's 8 channels exist when dch < dlim (Cout % 8 == 0)
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int q = q0 + 2 * k + (wave >> 2);                          // quad of the [tap][ci] axis
+    const int tap = q / p.cq, ciq = q - tap * p.cq;
+    const bool qok = q < nq;
+    const int tt = qok ? tap : 0;
+    tdy[k] = TAPS ? karg<int>(__builtin_offsetof(Wg384Params, tdy), tt) : 0;
+    tdx[k] = TAPS ? karg<int>(__builtin_offsetof(Wg384Params, tdx), tt) : 0;
+    xoff[k] = ((long)(tdy[k] * p.W + tdx[k]) * p.ldx + ciq * 64) * 2;
+    xlim[k] = qok ? p.Cin - ciq * 64 : 0;
   }
   const size_t dstep = (size_t)BP * p.lddy * 2, xstep = (size_t)BP * p.ldx * 2;
   uintptr_t dcur = dbase + (size_t)mbeg * p.lddy * 2, xcur = xbase + (size_t)mbeg * p.ldx * 2;   // scalar: the stage the next DMAs belong to
   int rows_left = npix;                                                                         // pixels of the split from that stage on
+  int oy = 0, ox = 0;                                                                           // TAPS: image position of this lane's pixel row
+  if constexpr (TAPS) {
+    const int m = mbeg + drow < p.M ? mbeg + drow : 0;
+    const int n = fast_div(m, p.div_hw);
+    const int rem = m - n * (p.H * p.W);
+    oy = fast_div(rem, p.div_w);
+    ox = rem - oy * p.W;
+  }
   auto issue = [&](int i, int slot) {
-    const bool ok = (src[i] != ~0u) & (drow < rows_left);
-    const uintptr_t a = ok ? (i < 2 ? dcur : xcur) + src[i] : zp;
-    __builtin_amdgcn_global_load_lds((gas_ptr)a, (lds_ptr)(smem + slot * STAGE + (8 * i + wave) * 1024), 16, 0, DC_WG384_AUX);
+    bool ok = drow < rows_left;
+    uintptr_t a;
+    if (i < 2) {
+      ok &= dch < dlim[i];
+      a = dcur + doff[i] + lsrc_d;
+    } else {
+      const int k = i - 2;
+      ok &= dch < xlim[k];
+      if constexpr (TAPS) ok &= ((unsigned)(oy + tdy[k]) < (unsigned)p.H) & ((unsigned)(ox + tdx[k]) < (unsigned)p.W);
+      a = xcur + xoff[k] + lsrc_x;
+    }
+    __builtin_amdgcn_global_load_lds((gas_ptr)(ok ? a : zp), (lds_ptr)(smem + slot * STAGE + (8 * i + wave) * 1024), 16, 0, DC_WG384_AUX);
   };
   auto advance = [&]() {
     dcur += dstep;
     xcur += xstep;
     rows_left -= BP;
+    if constexpr (TAPS) {
+      ox += BP;                       // W >= 32: at most one row wrap per stage
+      if (ox >= p.W) {
+        ox -= p.W;
+        oy = oy + 1 == p.H ? 0 : oy + 1;
+      }
+    }
   };
 
   f32x4 acc[NCB][NPB];   // [ci block][co block]
@@ -228,17 +275,24 @@ __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
   // write and the first read of an accumulator by a store are spelled out)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-  // ---- epilogue: acc[i][j][r] = dW[co0 + grp*64 + j*16 + fr][ci0 + wc*192 + i*16 + fg*4 + r]
-  float* out = obase + (size_t)split * p.Cout * p.Cin;
+  // ---- epilogue: acc[i][j][r] = dW of co0 + grp*64 + j*16 + fr and channel (i & 3)*16 + fg*4 + r of this wave's quad i >> 2
 #pragma unroll
-  for (int j = 0; j < NPB; ++j) {
-    const int co = co0 + grp * 64 + j * 16 + fr;
-    if (co >= p.Cout) continue;
-    float* orow = out + (size_t)co * p.Cin;
+  for (int k = 0; k < 3; ++k) {
+    const int q = q0 + wc * 3 + k;
+    if (q >= nq) continue;                                      // (wave-uniform)
+    const int tap = q / p.cq, ciq = q - tap * p.cq;
+    const int plane = split * p.ntaps + (TAPS ? karg<int>(__builtin_offsetof(Wg384Params, twidx), tap) : 0);
+    float* out = obase + (size_t)plane * p.Cout * p.Cin + ciq * 64;
 #pragma unroll
-    for (int i = 0; i < NCB; ++i) {
-      const int ci = ci0 + wc * 192 + i * 16 + fg * 4;
-      if (ci < p.Cin) *reinterpret_cast<f32x4*>(orow + ci) = acc[i][j];      // Cin % 8 == 0: all four or none
+    for (int j = 0; j < NPB; ++j) {
+      const int co = co0 + grp * 64 + j * 16 + fr;
+      if (co >= p.Cout) continue;
+      float* orow = out + (size_t)co * p.Cin;
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int c = ii * 16 + fg * 4;
+        if (ciq * 64 + c < p.Cin) *reinterpret_cast<f32x4*>(orow + c) = acc[4 * k + ii][j];      // Cin % 8 == 0: all four or none
+      }
     }
   }
 }
@@ -246,9 +300,14 @@ __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
 }  // namespace
 
 bool wgrad384_eligible(const GatherGeom& g, int ldx, int lddy, long M) {
-  if (!(g.ntaps == 1 && g.os == 1 && g.is == 1 && g.taps[0].dy == 0 && g.taps[0].dx == 0)) return false;
+  if (g.os != 1 || g.is != 1 || g.ntaps < 1 || g.ntaps > 9) return false;
   if (g.Cin % 8 != 0 || g.Cout % 8 != 0) return false;
   if ((size_t)BP * ldx * 2 + 2 * TCI >= (1ull << 32) || (size_t)BP * lddy * 2 + 2 * TCO >= (1ull << 32)) return false;
+  if (g.ntaps == 1) return g.taps[0].dy == 0 && g.taps[0].dx == 0;
+  // several taps: a "same" convolution (the kernel walks output pixels linearly and adds the tap's pixel offset) of rows at least a stage long
+  if (g.Hin != g.Hout || g.Win != g.Wout || g.Win < BP) return false;
+  for (int t = 0; t < g.ntaps; ++t)
+    if (g.taps[t].phase != 0 || g.taps[t].dy <= -g.Hin || g.taps[t].dy >= g.Hin || g.taps[t].dx <= -g.Win || g.taps[t].dx >= g.Win) return false;
   (void)M;
   return true;
 }
@@ -257,8 +316,9 @@ static int g_wgrad384_slots = 192;
 static int g_wgrad384_min_stages = 96;
 void wgrad384_set_slots(int n) { g_wgrad384_slots = n < 1 ? 1 : n; }
 void wgrad384_set_min_stages(int n) { g_wgrad384_min_stages = n < 4 ? 4 : n; }
+static long wgrad384_tiles(const GatherGeom& g) { return (long)cdiv((long)g.ntaps * cdiv(g.Cin, 64), 6) * cdiv(g.Cout, TCO); }
 void wgrad384_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group) {
-  const long tiles = (long)cdiv(g.Cin, TCI) * cdiv(g.Cout, TCO) * group;
+  const long tiles = wgrad384_tiles(g) * group;
   long want = g_wgrad384_slots / tiles;
   const long per = (long)g_wgrad384_min_stages * BP;
   const long maxs = (M + per - 1) / per;
@@ -275,24 +335,34 @@ int launch_wgrad384(const WgradParams& w, hipStream_t st, int group, const void*
   static const void* zero_dev = nullptr;
   static hipError_t init_err = hipSuccess;
   DC_ONCE({
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad384_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad384_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad384_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void* zp = nullptr;
     init_err = hipGetSymbolAddress(&zp, HIP_SYMBOL(wg384_zero_page));
     zero_dev = zp;
   });
   if (init_err != hipSuccess) return dc_set_error(init_err, __FILE__, __LINE__);
   if (group < 1 || group > WG384_MAXL) return dc_fail("launch_wgrad384: group size out of range", __FILE__, __LINE__);
+  const GatherGeom& g = w.g;
   Wg384Params pp;
   pp.zero_page = zero_dev;
-  pp.Cin = w.g.Cin; pp.Cout = w.g.Cout; pp.ldx = w.ldx; pp.lddy = w.lddy;
+  pp.Cin = g.Cin; pp.Cout = g.Cout; pp.ldx = w.ldx; pp.lddy = w.lddy;
   pp.M = w.M; pp.splits = w.splits; pp.chunk = w.chunk; pp.nlayers = group;
+  pp.ntaps = g.ntaps; pp.cq = cdiv(g.Cin, 64); pp.H = g.Hin; pp.W = g.Win;
+  for (int t = 0; t < 9; ++t) {
+    pp.tdy[t] = t < g.ntaps ? g.taps[t].dy : 0;
+    pp.tdx[t] = t < g.ntaps ? g.taps[t].dx : 0;
+    pp.twidx[t] = t < g.ntaps ? g.taps[t].widx : 0;
+  }
+  pp.div_hw = g.div_hw; pp.div_w = g.div_w;
   for (int l = 0; l < WG384_MAXL; ++l) {
     pp.x[l] = l < group ? (group == 1 && xs == nullptr ? w.x : xs[l]) : nullptr;
     pp.dy[l] = l < group ? (group == 1 && dys == nullptr ? w.dy : dys[l]) : nullptr;
     pp.out[l] = l < group ? (group == 1 && outs == nullptr ? w.slab : outs[l]) : nullptr;
   }
-  const long blocks = (long)cdiv(w.g.Cin, TCI) * cdiv(w.g.Cout, TCO) * w.splits * group;
-  hipLaunchKernelGGL(wgrad384_kernel, dim3((unsigned)blocks), dim3(512), lds, st, pp);
+  const long blocks = wgrad384_tiles(g) * w.splits * group;
+  if (g.ntaps == 1) hipLaunchKernelGGL(wgrad384_kernel<false>, dim3((unsigned)blocks), dim3(512), lds, st, pp);
+  else hipLaunchKernelGGL(wgrad384_kernel<true>, dim3((unsigned)blocks), dim3(512), lds, st, pp);
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -563,29 +563,35 @@ def test_conv_wgrad_group(case, dtype):
 
 
 WG384_CASES = [
-    # name, cin, cout, N, H, W, layers, option overrides
-    ("pw728_x3_nosplit", 728, 728, 2, 24, 20, 3, {"wgrad384_min_stages": 4096}),     # one split per tile: the kernel writes the gradient-shaped slab itself
-    ("pw728_x4_splits", 728, 728, 3, 17, 13, 4, {"wgrad384_min_stages": 4, "wgrad384_slots": 256}),
-    ("pw728_1024", 728, 1024, 2, 12, 10, 1, {}),
-    ("pw1536_256", 1536, 256, 2, 9, 11, 2, {}),
-    ("ragged_400_264", 400, 264, 2, 7, 9, 2, {"wgrad384_min_stages": 4}),            # partial channel tiles on both axes
-    ("tiny_m", 384, 256, 1, 3, 5, 1, {}),                                             # fewer pixels than one stage
+    # name, k, dil, cin, cout, N, H, W, layers, option overrides
+    ("pw728_x3_nosplit", 1, 1, 728, 728, 2, 24, 20, 3, {"wgrad384_min_stages": 4096}),     # one split per tile
+    ("pw728_x4_splits", 1, 1, 728, 728, 3, 17, 13, 4, {"wgrad384_min_stages": 4, "wgrad384_slots": 256}),
+    ("pw728_1024", 1, 1, 728, 1024, 2, 12, 10, 1, {}),
+    ("pw1536_256", 1, 1, 1536, 256, 2, 9, 11, 2, {}),
+    ("ragged_400_264", 1, 1, 400, 264, 2, 7, 9, 2, {"wgrad384_min_stages": 4}),            # partial channel tiles on both axes
+    ("tiny_m", 1, 1, 384, 256, 1, 3, 5, 1, {}),                                             # fewer pixels than one stage
+    ("x6_group", 1, 1, 728, 728, 2, 9, 10, 6, {}),                                          # the engine's group size
+    ("3x3_256", 3, 1, 256, 256, 2, 11, 40, 1, {"wgrad384_min_stages": 4}),                  # 36 quads = 6 tiles of the [tap][ci] axis
+    ("3x3_304_256", 3, 1, 304, 256, 2, 9, 35, 1, {"wgrad384_min_stages": 4}),               # 4.75 quads per tap: a partial quad, 7.5 tiles
+    ("3x3_dil6_512_256", 3, 6, 512, 256, 2, 14, 33, 1, {"wgrad384_min_stages": 8}),         # atrous: taps at +-6, mostly halo at this size
+    ("3x3_96_136", 3, 1, 96, 136, 1, 33, 32, 2, {"wgrad384_min_stages": 4}),                # rows exactly one stage long, grouped
 ]
 
 
 @pytest.mark.parametrize("case", WG384_CASES, ids=[c[0] for c in WG384_CASES])
 def test_conv_wgrad_384_tile_kernel(case):
-    """The 256 x 384 pointwise weight-gradient kernel (wgrad384.hip) forced on (option wgrad384 = 2) against autograd and against the
-    256 x 256 kernel (same products, other summation order over the pixel axis)."""
-    name, cin, cout, N, H, W, layers, opts = case
+    """The 256 x 384 weight-gradient kernel (wgrad384.hip: pointwise layers and stride-1 "same" 3 x 3 convolutions) forced on (option
+    wgrad384 = 2) against autograd and against the other kernels (same products, other summation order over the pixel axis)."""
+    name, k, dil, cin, cout, N, H, W, layers, opts = case
     dtype = torch.bfloat16
-    d = desc(dtype, 1, 1, 0, 1, 0, cin, cout)
+    pad = dil * (k - 1) // 2
+    d = desc(dtype, k, 1, pad, dil, 0, cin, cout)
     xs, gys, refs, keep = [], [], [], []
     for l in range(layers):
         x = q(rnd(N, cin, H, W, seed=30 + l), dtype)
         gy = q(rnd(N, cout, H, W, seed=40 + l), dtype)
-        wr = torch.zeros((cout, cin, 1, 1), requires_grad=True)
-        refs.append(torch.autograd.grad(F.conv2d(x, wr), wr, gy)[0])
+        wr = torch.zeros((cout, cin, k, k), requires_grad=True)
+        refs.append(torch.autograd.grad(F.conv2d(x, wr, None, 1, pad, dil), wr, gy)[0])
         xb, xv = to_nhwc(x, dtype, ld=cin + 16, off=8)
         gb, gyv = to_nhwc(gy, dtype, ld=cout + 8)
         keep += [xb, gb]
@@ -597,11 +603,11 @@ def test_conv_wgrad_384_tile_kernel(case):
     for mode in (2, 0):
         L.call("dc_set_option", b"wgrad384", mode)
         L.call("dc_set_option", b"wgrad256", 2)
-        for k, v in opts.items():
-            L.call("dc_set_option", k.encode(), v)
+        for kk, v in opts.items():
+            L.call("dc_set_option", kk.encode(), v)
         wsb = lib.dc_conv_wgrad_group_workspace(C.byref(d), N, H, W, layers)
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev())
-        gws = [torch.full((cout, cin, 1, 1), float("nan"), device=dev()) for _ in range(layers)]
+        gws = [torch.full((cout, cin, k, k), float("nan"), device=dev()) for _ in range(layers)]
         L.call("dc_conv_wgrad_group", C.byref(d), N, H, W, layers, pa(xs), cin + 16, pa(gys), cout + 8, vptr(ws), wsb, pa(gws), S())
         torch.cuda.synchronize()
         outs[mode] = gws
