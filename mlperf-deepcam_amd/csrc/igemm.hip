@@ -869,6 +869,7 @@ extern "C" int dc_wgrad_set_slots(int n);
 extern "C" int dc_wgrad_set_min_stages(int n);
 extern "C" int dc_wgrad_set_384(int m);
 extern "C" int dc_wgrad_set_384_slots(int n);
+extern "C" int dc_wgrad_set_384_fill(int pct);
 extern "C" int dc_wgrad_set_384_min_stages(int n);
 extern "C" int dc_head_set_fused(int v);
 extern "C" int dc_head_set_dgrad_fused(int v);
@@ -902,6 +903,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "wgrad256_min_stages") == 0) return dc_wgrad_set_min_stages(value);
   if (name != nullptr && strcmp(name, "wgrad384") == 0) return dc_wgrad_set_384(value);
   if (name != nullptr && strcmp(name, "wgrad384_slots") == 0) return dc_wgrad_set_384_slots(value);
+  if (name != nullptr && strcmp(name, "wgrad384_fill") == 0) return dc_wgrad_set_384_fill(value);
   if (name != nullptr && strcmp(name, "wgrad384_min_stages") == 0) return dc_wgrad_set_384_min_stages(value);
   if (name != nullptr && strcmp(name, "head_fused") == 0) return dc_head_set_fused(value);
   if (name != nullptr && strcmp(name, "head_dgrad_fused") == 0) return dc_head_set_dgrad_fused(value);
@@ -918,7 +920,7 @@ static const struct { const char* name; int value; } kOptionDefaults[] = {
     {"thin_fwd", 1}, {"thin_tile", 1}, {"igemm256_rel", 0}, {"pack_blocks", 2048},
     {"igemm256_phase_fast", 1}, {"wgrad_target_blocks", 768},
     {"wgrad_mode", 1}, {"wgrad_min_steps", 16}, {"wgrad256", 1}, {"wgrad256_pad", 115}, {"thin_wgrad", 1}, {"wgrad256_slots", 192}, {"wgrad256_min_stages", 96},
-    {"wgrad384", 1}, {"wgrad384_slots", 192}, {"wgrad384_min_stages", 96}, {"head_fused", 1},
+    {"wgrad384", 1}, {"wgrad384_slots", 192}, {"wgrad384_fill", 66}, {"wgrad384_min_stages", 96}, {"head_fused", 1},
     {"head_dgrad_fused", 1}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_pipe", 1}, {"bn_cgw", 32}, {"bn_rows", 32},
 };
 

@@ -456,6 +456,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 static int g_wgrad_mode = 1;               // 1 = LDS-DMA 3-stage kernel, 0 = register-staged kernel
 static int g_thin_wgrad = 1;               // one-pass kernel for the two thin stem convolutions (thinconv.hip)
 static int g_wgrad256_pad = 115;           // tuning switch "wgrad256_pad"
+static int g_wgrad384_fill = 66;           // fewest percent of a 384-wide tile row a pointwise layer's input channels must fill ("wgrad384_fill")
 static int g_wgrad384 = 1;                 // 256 x 384 pointwise kernel: 0 never, 1 planner, 2 wherever eligible (tests)
 static int g_wgrad256 = 1;                 // 0: 128-tile kernel only, 1: planner, 2: 256-tile kernel wherever eligible (bf16)
 static int g_wgrad_target_blocks = 768;    // resident capacity: 256 CUs x 3 workgroups (48 KiB LDS, 146 registers)
@@ -514,6 +515,10 @@ extern "C" int dc_wgrad_set_384(int m) {
   g_wgrad384 = m;
   return 0;
 }
+extern "C" int dc_wgrad_set_384_fill(int pct) {
+  g_wgrad384_fill = pct;
+  return 0;
+}
 extern "C" int dc_wgrad_set_384_slots(int n) {
   if (n < 1) return dc_fail("dc_set_option: wgrad384_slots must be positive", __FILE__, __LINE__);
   wgrad384_set_slots(n);
@@ -553,10 +558,10 @@ static bool wgrad384_wins(const GatherGeom& g) {
     // half a tile (304 -> 256: 45 quads = 7.5 tiles); the layer must fill the 256 output channels of a tile to three quarters
     return g_wgrad384 != 3 && g.Cin >= 64 && (long)cdiv(g.Cout, 256) * 256 * 3 <= (long)g.Cout * 4;
   }
-  if (!wgrad256_wins(g)) return false;
-  const long pad384 = (long)cdiv(g.Cin, 384) * 384 * cdiv(g.Cout, 256) * 256;
-  const long pad256 = (long)cdiv(g.Cin, 256) * 256 * cdiv(g.Cout, 256) * 256;
-  return pad384 <= pad256 && g.Cin >= 384;
+  // pointwise: the x axis in quads of 64 channels must fill its 384-wide tiles to g_wgrad384_fill percent (256 channels: 4 of 6 quads = 67 %),
+  // the output channels their 256-wide tiles to three quarters
+  const long nq = cdiv(g.Cin, 64), nxt = cdiv(nq, 6);
+  return nq * 100 >= nxt * 6 * g_wgrad384_fill && (long)cdiv(g.Cout, 256) * 256 * 3 <= (long)g.Cout * 4;
 }
 // the "big tile" plan and launch of a layer the 256-tile planner accepts: 256 x 384 where it wins, else 256 x 256
 static void wgrad_big_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group = 1) {

@@ -58,7 +58,8 @@ def test_persistent_gemm_k_loops_hold_no_spills(tmp_path):
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
 @pytest.mark.parametrize("src,name,count", [("igemm384.hip", "pw384_kernel", 3), ("igemm256.hip", "igemm256_kernel", 1),
-                                            ("wgrad256.hip", "wgrad256_kernel", 1)])
+                                            ("wgrad256.hip", "wgrad256_kernel", 1), ("wgrad384.hip", "wgrad384_kernel", 2),
+                                            ("igemm192.hip", "pw192_kernel", 1)])
 def test_gemm_k_loops_hold_no_spills(tmp_path, src, name, count):
     """The other MFMA kernels that run at the register limit.  (This scan is what found the spills of the 128-byte-row mode of
     pw384_kernel: six scratch reloads, each behind a vmcnt(0), per K step -- the reason that mode first measured slower than 64-byte rows.)"""
@@ -69,3 +70,26 @@ def test_gemm_k_loops_hold_no_spills(tmp_path, src, name, count):
         assert mfma_loops, kname
         for a, b in mfma_loops:
             assert not any("scratch_" in x for x in lines[a:b]), f"{kname}: scratch access inside the K loop at asm lines {a}-{b}"
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_pipelined_depthwise_tile_loops_hold_only_counted_memory_operations(tmp_path):
+    """dwp_kernel (dwpipe.hip) decides "tile i has landed" from hand-counted `s_waitcnt vmcnt(N)` immediates: (NS-1) x stores + (NS-2) x LDS-DMAs.
+    That count is exact only while the tile loop holds no OTHER vector-memory operation: a register spilled inside the loop (scratch store /
+    reload) or a VGPR-destination global load would shift the in-order count, the stencil would read LDS before its DMA has arrived, and dx,
+    the BatchNorm sums and the weight-gradient rows would be silently wrong (the DIL = 2 statistics + weight-gradient variant sits
+    at 256 registers with one spill -- outside the loop).  Checked for every instantiation: inside every loop that issues LDS-DMAs there is no
+    scratch access and no load with a register destination."""
+    kernels = _kernels(_device_asm("dwpipe.hip", tmp_path), "dwp_kernel")
+    assert len(kernels) >= 8, sorted(kernels)
+    for name, lines in kernels.items():
+        # the tile loops proper issue LDS-DMAs AND meet at a barrier per tile (the prologue, which fills the ring and loads the per-block
+        # constants behind a vmcnt(0) of its own, is laid out with backward branches too but holds no barrier); innermost ones only
+        dma_loops = [(a, b) for a, b in _loops(lines) if any("global_load_lds" in x or ("buffer_load" in x and " lds" in x) for x in lines[a:b])
+                     and any("s_barrier" in x for x in lines[a:b])]
+        assert dma_loops, name
+        dma_loops = [(a, b) for a, b in dma_loops if not any((c, d) != (a, b) and a <= c and d <= b for c, d in dma_loops)]
+        for a, b in dma_loops:
+            body = lines[a:b]
+            bad = [x.strip() for x in body if "scratch_" in x or re.search(r"\b(global|buffer|flat)_load_(?!lds)", x) and " lds" not in x]
+            assert not bad, f"{name}: uncounted vector-memory operations inside the tile loop (asm lines {a}-{b}): {bad[:4]}"
