@@ -1,3 +1,5 @@
+// EXPERIMENTS ONLY (make experiments): wgrad256.hip as it stood in round 4 with its compile-time variants -- the 32x32x16 MFMA form (DC_WG256_MFMA32),
+// the five-stage ring (DC_WG256_STAGES) and the probe masks (DC_WG256_PROBE) -- none of which is part of the product library.  DESIGN section 5 has the numbers.
 // Dense-conv weight gradient, 256 output channels x 256 input channels of one tap per 512-thread workgroup (bf16).
 //
 //     dW_t[co][ci] = sum over output pixels m of dy[m][co] * x[gather(m,t)][ci]
@@ -14,7 +16,7 @@
 //             [split][tap][Co][Ci] and wgrad_reduce_kernel (wgrad.hip) adds them in a fixed order
 #include <type_traits>
 
-#include "wgrad.h"
+#include "../wgrad.h"
 
 namespace dc {
 
@@ -25,8 +27,14 @@ constexpr int WBP = 32;            // pixels per stage
 constexpr int WROW = WT * 2;       // bytes per LDS row (one pixel, 256 channels)
 constexpr int WOPER = WBP * WROW;  // 16 KiB
 constexpr int WSTAGE = 2 * WOPER;
-constexpr int WNST = 4;            // ring stages of 32 KiB (a fifth, the 32x32x16 MFMA form and the probe builds: experiments/wgrad256_variants.hip)
-__device__ inline int ring(int s) { return s & (WNST - 1); }
+#ifndef DC_WG256_STAGES
+#define DC_WG256_STAGES 4
+#endif
+constexpr int WNST = DC_WG256_STAGES;   // ring stages of 32 KiB (5 = the CU's whole LDS)
+__device__ inline int ring(int s) { return (WNST & (WNST - 1)) == 0 ? (s & (WNST - 1)) : s % WNST; }
+#ifndef DC_WG256_PROBE
+#define DC_WG256_PROBE 0     // diagnostic builds only (scripts/wgrad256_probe.py): 1 = no LDS-DMA, 2 = no LDS fragment reads, 4 = L2-resident operands, 8 = no slab stores
+#endif
 
 static __device__ __attribute__((aligned(256))) unsigned char wg256_zero_page[256];
 typedef __attribute__((address_space(1))) const void* gas_ptr;
@@ -45,11 +53,22 @@ struct Wgrad256Params {
   float* slabs[WG_MAXGROUP - 1];
 };
 
-// XOR key on the 32-byte chunk index of a 512-byte pixel row: a half-wave reads 8 rows x 32 B (rows 8g + 0..3 of two k-blocks): keys 0..7
-__device__ inline int swz_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+#ifndef DC_WG256_MFMA32
+#define DC_WG256_MFMA32 0    // 1: v_mfma_f32_32x32x16_bf16 (half the MFMA instructions per stage: an MFMA holds the SIMD's issue port for 8 cycles
+#endif                       //    whatever its shape, and this loop also issues 24 transposing LDS reads and 4 LDS-DMAs per wave and stage)
+constexpr bool M32 = DC_WG256_MFMA32 != 0;
+// XOR key on the 32-byte chunk index of a 512-byte pixel row.  16x16x32 fragments: a half-wave reads 8 rows x 32 B (rows 8g + 0..3 of two
+// k-blocks): keys 0..7.  32x32x16 fragments: a half-wave reads 4 rows x 64 B (two adjacent chunks): the key moves whole chunk PAIRS.
+__device__ inline int swz_key(int row) { return M32 ? ((row & 3) << 1) : ((row & 3) | (((row >> 3) & 1) << 2)); }
 
 // one MFMA operand fragment (16 channels of chunk `c`, the 8 pixels 8*fg .. 8*fg+7 of the stage) from a [pixel][channel] tile
 __device__ inline vec16 tr_frag(const char* tile, int c, int prow, int key0, int key1, int tp) {
+  if (DC_WG256_PROBE & 2) {
+    vec16 f;
+    f.w[0] = f.w[1] = f.w[2] = f.w[3] = 0x3f803f80u + (unsigned)c;
+    asm volatile("" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]));
+    return f;
+  }
   const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(tile + prow * WROW + ((c ^ key0) << 5) + 8 * tp));
   const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(tile + (prow + 4) * WROW + ((c ^ key1) << 5) + 8 * tp));
   const uint2 t0 = __builtin_bit_cast(uint2, a0), t1 = __builtin_bit_cast(uint2, a1);
@@ -57,6 +76,28 @@ __device__ inline vec16 tr_frag(const char* tile, int c, int prow, int key0, int
   f.w[0] = t0.x; f.w[1] = t0.y; f.w[2] = t1.x; f.w[3] = t1.y;
   return f;
 }
+
+// 32x32x16 operand fragment: 32 channels of block `cb` x the 16 pixels of k-half `kh` of the stage; lane l holds channel 32*cb + (l & 31),
+// pixels 16*kh + 8*(l >> 5) + 0..7 (two transposing reads of 4 pixels x 16 channels per 16-lane group)
+__device__ inline vec16 tr_frag32(const char* tile, int cb, int kh, int lane) {
+  if (DC_WG256_PROBE & 2) {
+    vec16 f;
+    f.w[0] = f.w[1] = f.w[2] = f.w[3] = 0x3f803f80u + (unsigned)cb;
+    asm volatile("" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]));
+    return f;
+  }
+  const int i = lane & 15, q = i >> 2, p = i & 3;
+  const int row = 16 * kh + 8 * (lane >> 5) + q;
+  const int chunk = 2 * cb + ((lane >> 4) & 1);
+  const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(tile + row * WROW + ((chunk ^ swz_key(row)) << 5) + 8 * p));
+  const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(tile + (row + 4) * WROW + ((chunk ^ swz_key(row + 4)) << 5) + 8 * p));
+  const uint2 t0 = __builtin_bit_cast(uint2, a0), t1 = __builtin_bit_cast(uint2, a1);
+  vec16 f;
+  f.w[0] = t0.x; f.w[1] = t0.y; f.w[2] = t1.x; f.w[3] = t1.y;
+  return f;
+}
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_) {
   const WgradParams& p = pp_.w;
@@ -135,7 +176,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_)
     for (int i = 0; i < 2; ++i) {
       const int j = 2 * wave + i;
       const int m = mbeg + istage * WBP + 2 * j + lrow;
-      __builtin_amdgcn_global_load_lds(pick((m < mend) & cq_ok[i], dg + offq[i]), (lds_ptr)(q + j * 1024), 16, 0, 0);
+      if (!(DC_WG256_PROBE & 1)) __builtin_amdgcn_global_load_lds(pick((m < mend) & cq_ok[i], dg + offq[i]), (lds_ptr)(q + j * 1024), 16, 0, 0);
     }
   };
   auto issue_p = [&](int slot) {
@@ -146,8 +187,9 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_)
       const int m = mbeg + istage * WBP + 2 * j + lrow;
       const int iy = rqy[i] * g.is + tap.dy, ix = rqx[i] * g.is + tap.dx;
       const bool ok = (m < mend) & cp_ok[i] & ((unsigned)iy < (unsigned)g.Hin) & ((unsigned)ix < (unsigned)g.Win);
-      __builtin_amdgcn_global_load_lds(pick(ok, xg + offp[i]), (lds_ptr)(x_ + j * 1024), 16, 0, 0);
+      if (!(DC_WG256_PROBE & 1)) __builtin_amdgcn_global_load_lds(pick(ok, xg + offp[i]), (lds_ptr)(x_ + j * 1024), 16, 0, 0);
       // advance this row by one stage
+      if (DC_WG256_PROBE & 4) continue;   // diagnostic: every stage re-reads the first stage's (then L2-resident) rows
       rqx[i] += WBP;
       if (rqx[i] < g.Qw) {
         offq[i] += stepq;
@@ -166,6 +208,106 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_)
     ++istage;
   };
 
+  if constexpr (M32) {
+    // ---- 32x32x16 form: wave tile 128 co x 64 ci = 4 x 2 blocks of 32 x 32; a stage is two k-halves of 16 pixels, 8 MFMAs each
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < WNST - 1; ++q) {
+      issue_q(q);
+      issue_p(q);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (WNST - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    vec16 a0[4], b0[2], a1[4], b1[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a0[i] = tr_frag32(smem, wq * 4 + i, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b0[j] = tr_frag32(smem + WOPER, wp * 2 + j, 0, lane);
+    // H0(s): a1/b1 <- k-half 1 of stage s; DMA dy tile of stage s+3; 8 MFMAs on (a0, b0).  H1(s): a0/b0 <- k-half 0 of stage s+1; DMA x tile
+    // of stage s+3; 8 MFMAs on (a1, b1).  Same hazard argument as the 16x16x32 loop below (one barrier per stage, between the halves).
+    auto k_loop = [&](auto loads_first_tag) {
+      constexpr bool LOADS_FIRST = decltype(loads_first_tag)::value;
+      for (int s = 0; s < steps; ++s) {
+        const char* q = smem + ring(s) * WSTAGE;
+        const char* q1 = smem + ring(s + 1) * WSTAGE;
+        const int nslot = ring(s + WNST - 1);
+        auto load1 = [&]() {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a1[i] = tr_frag32(q, wq * 4 + i, 1, lane);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b1[j] = tr_frag32(q + WOPER, wp * 2 + j, 1, lane);
+        };
+        auto load0 = [&]() {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a0[i] = tr_frag32(q1, wq * 4 + i, 0, lane);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b0[j] = tr_frag32(q1 + WOPER, wp * 2 + j, 0, lane);
+        };
+        if constexpr (LOADS_FIRST) {
+          load1();
+          issue_q(nslot);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[i]), __builtin_bit_cast(bf16x8, b0[j]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!LOADS_FIRST) {
+          __builtin_amdgcn_sched_barrier(0);
+          load1();
+          issue_q(nslot);
+        }
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (WNST - 3) + 2) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LOADS_FIRST) {
+          load0();
+          issue_p(nslot);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1[i]), __builtin_bit_cast(bf16x8, b1[j]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!LOADS_FIRST) {
+          __builtin_amdgcn_sched_barrier(0);
+          load0();
+          issue_p(nslot);
+        }
+      }
+    };
+    if (wq == 0) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    float* out = ssel + ((size_t)split * g.ntaps + tap.widx) * g.Cout * g.Cin;
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wq * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co >= g.Cout) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ci = ci0 + wp * 64 + j * 32 + l31;
+          if (ci < g.Cin && (!(DC_WG256_PROBE & 8) || acc[i][j][r] == 123.f)) out[(size_t)co * g.Cin + ci] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   f32x4 acc[8][4];   // [co block][ci block]
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -262,7 +404,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(const Wgrad256Params pp_)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ci = ci0 + wp * 64 + j * 16 + fr;
-        if (ci < g.Cin) out[(size_t)co * g.Cin + ci] = acc[i][j][r];
+        if (ci < g.Cin && (!(DC_WG256_PROBE & 8) || acc[i][j][r] == 123.f)) out[(size_t)co * g.Cin + ci] = acc[i][j][r];
       }
     }
 }

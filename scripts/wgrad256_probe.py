@@ -1,5 +1,5 @@
 """What each part of the 256 x 256 weight-gradient kernel's K loop costs.  Diagnostic builds of wgrad256.hip (-DDC_WG256_PROBE=mask, one
-library per mask, built by hand as in the header of this file's history: hipcc -DDC_WG256_PROBE=m -c wgrad256.hip, linked with the other
+library per mask, built by hand as in the header of this file's history: hipcc -DDC_WG256_PROBE=m -c experiments/wgrad256_variants.hip (make experiments), linked with the other
 objects into libdeepcam_hip_wgprobe<m>.so) drop the LDS-DMA issues (1), the transposing LDS fragment reads (2) and / or the slab stores (8).
 Results are garbage by construction; only the times mean something.  Times include the slab reduction (dc_conv_wgrad = kernel + reduce).
     python scripts/wgrad256_probe.py"""
