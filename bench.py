@@ -158,7 +158,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (default: eager launches, which "
                     "measured faster once weight gradients moved to a side stream: 55.3 vs 59.5 ms at B=8)")
     ap.add_argument("--program", action="store_true", help="replay the step from the C-side launch list (TrainStep.enable_program: dc_program_run, "
-                    "one call per step, no Python between launches); single GPU only.  The GPU work is the same list of launches")
+                    "one call per step, no Python between launches).  The GPU work is the same list of launches.  With more than one rank it "
+                    "needs the library's own collective (DC_GRAD_COLLECTIVE=lib: dc_grad_allreduce_enqueue / _wait over RCCL)")
     a = ap.parse_args()
 
     # timing-experiment switches that make backward skip work must never produce a bench line
@@ -219,7 +220,7 @@ def main():
         step.enable_graph()
         graphed = True
     programmed = False
-    if world == 1 and a.program and not graphed:
+    if a.program and not graphed and (world == 1 or reducer.collective == "library"):
         step(x, y)
         step.enable_program()
         programmed = True
@@ -259,6 +260,7 @@ def main():
         waits = sorted(e0.elapsed_time(e1) for e0, e1 in comm_events[:a.steps])
         step.after_backward = inner_finish               # the roofline passes below run without the brackets
         comm = {"backend": dist.get_backend(), "world": dist.get_world_size(), "payload": reducer.payload,
+                "collective": reducer.collective if reducer.collective == "torch" else f"library ({reducer.comm.info()['transport']})",
                 "buckets": len(reducer.buckets), "bytes_per_step_per_rank": int(net.engine.layout.n_params * (2 if reducer.payload == "bf16" else 4)),
                 "buckets_launched_per_step": reducer.launched_last if hasattr(reducer, "launched_last") else None,
                 "exposed_wait_ms": {"median": round(waits[len(waits) // 2], 3), "max": round(waits[-1], 3)} if waits else None,

@@ -407,6 +407,32 @@ int dc_lamb_step(int ntensors, const int64_t* offsets_dev, long n, float* p, con
 int dc_grad_pack_bf16(long n, const float* g, void* out_bf16, void* stream);
 int dc_grad_unpack_bf16(long n, const void* in_bf16, float* g, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The gradient all-reduce itself, inside the library (csrc/comm.cpp; SURVEY section 8b: grad_allreduce_{enqueue,wait} over a raw RCCL
+ * communicator).  Replaces the reducer of apex / torch DistributedDataParallel: train_hdf5_ddp.py:227 (construction: one communicator per
+ * process) and :363 (loss.backward(): bucketed all-reduces overlapped with the rest of backward).
+ *   dc_comm_unique_id        rank 0: 128 bytes (ncclGetUniqueId) that the host program hands to every rank by any out-of-band channel
+ *   dc_comm_create           every rank: ncclCommInitRank on the current device + a communication stream of the library's own.
+ *                            world == 1 with id128 == NULL: no RCCL at all (enqueue / wait are no-ops)
+ *   dc_comm_adopt            wrap an ncclComm_t the caller already has (not destroyed by dc_comm_destroy)
+ *   dc_comm_create_callback  transport = a host function (tests: torch.distributed over gloo); sync_stream != 0: the compute stream is
+ *                            synchronised before every call back (device buffers)
+ *   dc_grad_allreduce_enqueue  the communication stream waits for everything enqueued on compute_stream so far, then sums
+ *                            buf[0 .. count) (DC_F32 or DC_BF16) across the ranks IN PLACE on it; returns at once
+ *   dc_grad_allreduce_wait   compute_stream waits for every collective enqueued so far (the optimizer goes behind it)
+ * enqueue / wait take word-sized arguments only, so dc_program_append records them like any kernel launch.
+ * ------------------------------------------------------------------------------------------------ */
+typedef int (*dc_allreduce_callback)(void* ctx, void* buf, size_t count, int dtype);
+int dc_comm_unique_id(void* id128);
+int dc_comm_create(const void* id128, int rank, int world, void** comm);
+int dc_comm_adopt(void* nccl_comm, int rank, int world, void** comm);
+int dc_comm_create_callback(dc_allreduce_callback fn, void* ctx, int rank, int world, int sync_stream, void** comm);
+int dc_comm_destroy(void* comm);
+/* transport: 0 none (single rank), 1 RCCL, 2 callback; enqueued: calls of dc_grad_allreduce_enqueue so far */
+int dc_comm_info(void* comm, int* rank, int* world, int* transport, long* enqueued);
+int dc_grad_allreduce_enqueue(void* comm, void* buf, size_t count, int dtype, void* compute_stream);
+int dc_grad_allreduce_wait(void* comm, void* compute_stream);
+
 #ifdef __cplusplus
 }
 #endif

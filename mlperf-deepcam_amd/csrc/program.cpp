@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/deepcam_hip.h"
@@ -133,11 +134,15 @@ extern "C" int dc_program_run(void* prog, int* failed_op) {
 
 // `to` waits for everything enqueued on `from` so far (hipEventRecord + hipStreamWaitEvent).  The events come from a pool that is reused
 // round robin: a wait refers to the record that preceded it, so an event may be recorded again as soon as its wait has been enqueued.
+// Thread-safe (the C ABI may be called from reader threads beside the main thread): the record + wait pair of one call runs under a mutex, so two
+// callers can neither pick the same pool slot nor re-record an event between another caller's record and its wait.
 extern "C" int dc_stream_fence(void* from_stream, void* to_stream) {
   constexpr int POOL = 64;
   static hipEvent_t pool[POOL];
   static bool made[POOL];
   static int next = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   const int k = next;
   next = (next + 1) % POOL;
   if (!made[k]) {

@@ -104,13 +104,93 @@ def plan_buckets(param_offsets: "Dict[str, tuple]", total: int, bucket_elems: in
     return buckets
 
 
+class LibraryComm:
+    """A communicator of the library's own (csrc/comm.cpp: dc_comm_*, dc_grad_allreduce_enqueue / _wait).  Two transports:
+    `rccl()` brings up an RCCL communicator from a unique id that rank 0 creates and torch.distributed (any backend) carries to the other
+    ranks; `over_torch()` hands every reduction back to torch.distributed through a host callback -- how the gloo tests (no RCCL between
+    CPU ranks, or between several ranks on one GPU) drive the very same entry points.  Both are driven by word-sized C calls only, so a
+    recorded launch list (TrainStep.enable_program) replays the collectives with the kernels."""
+
+    def __init__(self, handle, keep=()):
+        self.h = handle
+        self._keep = list(keep)
+
+    @classmethod
+    def rccl(cls, group=None) -> "LibraryComm":
+        import ctypes as C
+        from . import lib as L
+        rank, world = dist.get_rank(group) if dist.is_initialized() else 0, dist.get_world_size(group) if dist.is_initialized() else 1
+        box = [None]
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            L.call("dc_comm_unique_id", buf)
+            box[0] = bytes(buf)
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        h = C.c_void_p()
+        L.call("dc_comm_create", C.c_char_p(box[0]), rank, world, C.byref(h))
+        return cls(h)
+
+    @classmethod
+    def over_torch(cls, resolve, group=None, sync_stream: bool = True) -> "LibraryComm":
+        """resolve(ptr, count, dtype_code) -> the torch tensor (a view of the caller's arena) that starts at device / host address ptr."""
+        import ctypes as C
+        from . import lib as L
+        rank, world = dist.get_rank(group) if dist.is_initialized() else 0, dist.get_world_size(group) if dist.is_initialized() else 1
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+
+        def cb(_ctx, ptr, count, dtype_code):
+            try:
+                t = resolve(ptr, count, dtype_code)
+                if world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except Exception:       # an exception must not unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        fn = CB(cb)
+        h = C.c_void_p()
+        L.call("dc_comm_create_callback", C.cast(fn, C.c_void_p), None, rank, world, 1 if sync_stream else 0, C.byref(h))
+        return cls(h, keep=[fn])
+
+    def info(self) -> dict:
+        import ctypes as C
+        from . import lib as L
+        r, w, t, n = C.c_int(), C.c_int(), C.c_int(), C.c_long()
+        L.call("dc_comm_info", self.h, C.byref(r), C.byref(w), C.byref(t), C.byref(n))
+        return {"rank": r.value, "world": w.value, "transport": ("none", "rccl", "callback")[t.value], "enqueued": n.value}
+
+    def close(self) -> None:
+        if self.h:
+            from . import lib as L
+            L.call("dc_comm_destroy", self.h)
+            self.h = None
+
+
+class _Enqueued:
+    """stands in for torch's Work object on the library path: completion is a stream-side wait issued once by finish()"""
+
+    def wait(self):
+        return True
+
+
 class GradReducer:
     """payload: "fp32" all-reduces the arena ranges in place (zero copies); "bf16" rounds each bucket into a bf16 send buffer
     (dc_grad_pack_bf16), sums THAT across ranks and widens the result back into the fp32 arena (dc_grad_unpack_bf16): half the
     bytes on the xGMI links (112.9 MB instead of 225.8 MB per step) for two extra passes over the bucket."""
 
-    def __init__(self, engine, world: int, bucket_mb: float = 32.0, group=None, payload: Optional[str] = None):
+    def __init__(self, engine, world: int, bucket_mb: float = 32.0, group=None, payload: Optional[str] = None, collective: Optional[str] = None,
+                 comm: "Optional[LibraryComm]" = None):
+        """collective: "torch" (default) = torch.distributed's all_reduce on the process group's stream; "library" (or DC_GRAD_COLLECTIVE=lib)
+        = dc_grad_allreduce_enqueue / _wait of the HIP library over `comm` (default: an RCCL communicator of its own, LibraryComm.rccl):
+        every call of the step is then a C call and the step can be replayed from a recorded launch list at any world size."""
         self.eng, self.world, self.group = engine, world, group
+        self.collective = (collective or os.environ.get("DC_GRAD_COLLECTIVE", "torch")).lower()
+        self.collective = {"lib": "library"}.get(self.collective, self.collective)
+        if self.collective not in ("torch", "library"):
+            raise ValueError(f"gradient collective must be 'torch' or 'library', got {self.collective!r}")
+        self.comm = comm
         self.payload = (payload or os.environ.get("DC_GRAD_PAYLOAD", "fp32")).lower()
         if self.payload not in ("fp32", "bf16"):
             raise ValueError(f"gradient payload must be 'fp32' or 'bf16', got {self.payload!r}")
@@ -133,6 +213,21 @@ class GradReducer:
         self.hook(engine)
         self.launched = 0
         self.averaging_in_optimizer = False     # set by TrainStep.attach_reducer: the 1/world then rides in the optimizer kernel
+        if self.collective == "library" and (self.comm is None or isinstance(self.comm, str)):
+            # default: an RCCL communicator of the library's own; "callback" (or DC_GRAD_COLLECTIVE_TRANSPORT=callback): torch.distributed does
+            # the reduction inside a host callback (gloo tests)
+            transport = self.comm if isinstance(self.comm, str) else os.environ.get("DC_GRAD_COLLECTIVE_TRANSPORT", "rccl")
+            if transport == "callback":
+                self.comm = LibraryComm.over_torch(self._resolve, group, sync_stream=engine.grads.is_cuda)
+            else:
+                self.comm = LibraryComm.rccl(group)
+
+    def _resolve(self, ptr: int, count: int, dtype_code: int):
+        """callback transport: the arena view an address handed to dc_grad_allreduce_enqueue refers to"""
+        arena = self._send if dtype_code == 1 else self.eng.grads
+        off = (ptr - arena.data_ptr()) // arena.element_size()
+        assert 0 <= off and off + count <= arena.numel(), "address outside the gradient arena"
+        return arena[off:off + count]
 
     def hook(self, engine) -> None:
         """Report gradient readiness from this engine too.  Every engine that shares the arena (nn.DeepLabv3_plus builds one per
@@ -153,7 +248,15 @@ class GradReducer:
         if self.world <= 1:
             return None                          # a single rank has nothing to reduce
         g = self.eng.grads[b.lo:b.hi]
+        lib_path = self.collective == "library"
+        if lib_path:
+            import ctypes as C
+            from . import lib as L
+            st = L.stream_ptr() if g.is_cuda else None
         if self._send is None:
+            if lib_path:
+                L.call("dc_grad_allreduce_enqueue", self.comm.h, C.c_void_p(g.data_ptr()), b.hi - b.lo, L.DC_F32, st)
+                return _Enqueued()
             return dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         s = self._send[b.lo:b.hi]
         if g.is_cuda:
@@ -161,6 +264,9 @@ class GradReducer:
             L.call("dc_grad_pack_bf16", b.hi - b.lo, L.dptr(g), L.dptr(s), L.stream_ptr())
         else:                                   # host arenas exist only in the CPU tests of this class
             s.copy_(g)
+        if lib_path:
+            L.call("dc_grad_allreduce_enqueue", self.comm.h, C.c_void_p(s.data_ptr()), b.hi - b.lo, L.DC_BF16, st)
+            return _Enqueued()
         return dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _unpack(self, b: Bucket) -> None:
@@ -183,7 +289,12 @@ class GradReducer:
                 # so it covers both without stalling backward.
                 side = getattr(self.eng, "side", None) if getattr(self.eng, "use_side_stream", False) else None
                 if side is not None:
-                    side.wait_event(torch.cuda.current_stream().record_event())
+                    if self.collective == "library":       # a C call, so that a recorded launch list holds the fence too
+                        import ctypes as C
+                        from . import lib as L
+                        L.call("dc_stream_fence", L.stream_ptr(), C.c_void_p(side.cuda_stream))
+                    else:
+                        side.wait_event(torch.cuda.current_stream().record_event())
                     with torch.cuda.stream(side):
                         b.work = self._reduce(b)
                 else:
@@ -200,6 +311,9 @@ class GradReducer:
             raise RuntimeError("this reducer is attached to a fused TrainStep whose optimizer already applies 1/world; "
                                "finish(average=True) would average twice")
         missing = [b for b in self.buckets if b.remaining != 0]
+        if self.collective == "library" and any(b.work is not None for b in self.buckets):
+            from . import lib as L                   # the compute stream waits for every collective enqueued so far
+            L.call("dc_grad_allreduce_wait", self.comm.h, L.stream_ptr() if self.eng.grads.is_cuda else None)
         for b in self.buckets:                       # wait for what WAS launched even when the backward was incomplete
             if b.work is not None:
                 b.work.wait()

@@ -501,6 +501,11 @@ class Engine:
                 x.fused_bwd = (rslab2, wrows, x.grad_takes)       # (this layer's take_grad_mode call above was the last one so far)
             else:
                 res = None
+            # the BatchNorm's make_bwd runs after this one: if it finds that ANOTHER consumer wrote the gradient later (this layer was not the
+            # last writer after all), it cancels the fusion and this layer falls back to the plain fused data + weight gradient
+            fuse_state = {"res": res}
+            if res is not None:
+                x.fused_bwd_cancel = lambda: fuse_state.update(res=None)
             ready = [wname]
             if wrows > 0:
                 # the rows stay in this layer's own slab until the next dense weight-gradient launch folds them (dc_fold_slabs); the
@@ -512,6 +517,7 @@ class Engine:
                 L.call("dc_dwconv_wgrad", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, dy.ptr, dy.ld, ws, gw, ps, psh, prelu, self._st())
 
             def bwd():
+                res = fuse_state["res"]
                 if res is not None:
                     L.call("dc_dwconv_dgrad_wgrad_bnres", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
                            dx.ptr, dx.ld, src.ptr, src.ld, L.dptr(wslab), res["y"].ptr, res["y"].ld, L.dptr(res["mean"]), L.dptr(res["invstd"]),
@@ -617,8 +623,14 @@ class Engine:
 
             # set by the consumer (a depthwise conv for a lazy output, a dense conv / the head for a stored one): its make_bwd ran first
             fused = lz.fused_bwd if lazy else getattr(o, "fused_bwd", None)
-            if fused is not None and len(fused) > 2:
-                assert o.grad_takes == fused[2], f"{bname}: the consumer that takes the sums must be the last writer of the gradient"
+            if fused is not None and len(fused) > 2 and o.grad_takes != fused[2]:
+                # the consumer that was to take the sums is not the last writer of this gradient (its sums would miss the later addends):
+                # no fusion for this BatchNorm -- the consumer runs its plain kernel, the sums come from dc_bn_bwd_reduce below
+                cancel = getattr(o, "fused_bwd_cancel", None)
+                if cancel is None:
+                    raise L.DeepcamHipError(f"{bname}: a consumer took this BatchNorm's backward sums but is not the last writer of the gradient")
+                cancel()
+                fused = None
             rslab, rrows = (fused[0], fused[1]) if fused is not None else (bslab, brows)
 
             def bwd():

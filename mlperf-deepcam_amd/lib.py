@@ -128,6 +128,14 @@ _SIGS = {
     "dc_lamb_step": (I, [I, P, L, P, P, P, P, P, F, F, F, F, P, F, F, P, P]),
     "dc_grad_pack_bf16": (I, [L, P, P, P]),
     "dc_grad_unpack_bf16": (I, [L, P, P, P]),
+    "dc_comm_unique_id": (I, [P]),
+    "dc_comm_create": (I, [P, I, I, C.POINTER(P)]),
+    "dc_comm_adopt": (I, [P, I, I, C.POINTER(P)]),
+    "dc_comm_create_callback": (I, [P, P, I, I, I, C.POINTER(P)]),
+    "dc_comm_destroy": (I, [P]),
+    "dc_comm_info": (I, [P, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(L)]),
+    "dc_grad_allreduce_enqueue": (I, [P, P, SZ, I, P]),
+    "dc_grad_allreduce_wait": (I, [P, P]),
 }
 EXPORTS = sorted(_SIGS)
 

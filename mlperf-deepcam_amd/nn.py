@@ -497,6 +497,7 @@ class TrainStep:
         """Data parallelism for the fused step: the reducer's buckets are all-reduced (SUM) while backward runs, the step
         waits for them before the optimizer and the 1/world averaging rides in the optimizer kernel (no extra pass)."""
         self.after_backward = reducer.finish
+        self._reducer = reducer
         self.opt.grad_scale = 1.0 / reducer.world
         # one averaging mechanism per module: the autograd path (DistributedDataParallel -> finish(average=True)) is switched off
         reducer.averaging_in_optimizer = True
@@ -562,9 +563,13 @@ class TrainStep:
         """Record the whole step as a C-side launch list (lib.Program, dc_program_*: every library call of one step with its arguments,
         stream fences included) and replay it with ONE call per step: later calls copy the batch into static buffers, push the
         optimizer's scalars and run the list -- no Python between two launches.  The recording pass is a real step on whatever the
-        static buffers hold, as with enable_graph.  Single-process only: the gradient reducer's hooks are Python."""
-        if self.after_backward is not None or self.eng.on_grad_ready is not None:
-            raise L.DeepcamHipError("the recorded launch list is for the single-GPU step (the all-reduce hooks run in Python)")
+        static buffers hold, as with enable_graph.  With a gradient reducer attached the step can be recorded when the reducer's collective
+        is the library's own (GradReducer(collective="library"): dc_grad_allreduce_enqueue / _wait and the stream fences are C calls and
+        land in the list); torch.distributed's collectives are Python objects and cannot."""
+        red = getattr(self, "_reducer", None)
+        if (self.after_backward is not None or self.eng.on_grad_ready is not None) and getattr(red, "collective", None) != "library":
+            raise L.DeepcamHipError("the recorded launch list needs the library's own collective (GradReducer(collective='library')): "
+                                    "torch.distributed's all-reduce hooks run in Python")
         eng = self.eng
         self._gx = eng.x_static
         self._gy = torch.zeros((eng.B, eng.H, eng.W), dtype=torch.int64, device=eng.device)
@@ -577,6 +582,7 @@ class TrainStep:
         self.opt.step_count += 1
         self.opt.sync_scalars()
         self._program = L.Program()
+        self._program_stream = L.stream_ptr().value      # the recorded launches carry THIS stream; replay must run under the same one
         with self._program.recording():
             self.launch(self._gx, self._gy)
         eng.packed_version = -1
@@ -586,9 +592,20 @@ class TrainStep:
         self.opt.step_count += 1
         self.opt.sync_scalars()
         if getattr(self, "programmed", False):
+            # the batch copy and the optimizer's scalar hand-over above are enqueued on the CURRENT stream, the recorded launches on the stream
+            # of the recording pass: under another current stream the step would read a stale or half-copied batch
+            if L.stream_ptr().value != self._program_stream:
+                raise L.DeepcamHipError("TrainStep: the recorded launch list was recorded under another stream; call the step under that stream "
+                                        "or record again (enable_program)")
             self._gx.copy_(x, non_blocking=True)
             self._gy.copy_(labels.squeeze(1) if labels.dim() == 4 else labels, non_blocking=True)
-            self._program.run()
+            try:
+                self._program.run()
+            except L.DeepcamHipError:
+                # a list that failed half way may have forked the weight-gradient stream without joining it: close the fork before raising
+                if self.eng.use_side_stream:
+                    L.call("dc_stream_fence", C.c_void_p(self.eng.side.cuda_stream), L.stream_ptr())
+                raise
             self.eng.version[0] += 1
             return
         if getattr(self, "graphed", False):

@@ -34,7 +34,8 @@ def main():
             grads_for(ref, 1234 + r, dev, cw); torch.cuda.synchronize()
             total += ref.grads
         err = float((reduced.double() - total.double()).norm() / total.double().norm())
-        print(f"DIST_WORKER rel_err {err:.3e} launched {len(red.buckets)} buckets", flush=True)
+        how = f" collective {red.collective} transport {red.comm.info()['transport']}" if red.collective == "library" else ""
+        print(f"DIST_WORKER rel_err {err:.3e} launched {len(red.buckets)} buckets{how}", flush=True)
         assert err < 1e-6, err
     dist.barrier()
     dist.destroy_process_group()

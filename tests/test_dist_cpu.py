@@ -48,14 +48,18 @@ def test_bucket_plan_covers_arena_in_backward_order():
     assert 5 <= len(buckets) <= 10
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, collective="torch"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     ddist.init("env", backend="gloo")
     assert ddist.get_rank() == rank and ddist.get_size() == world
     lay = spec.Layout()
     eng = FakeEngine(lay)
     eng.params.fill_(float(rank + 1))
-    red = ddist.GradReducer(eng, world, bucket_mb=16.0)
+    # "library": the reductions go through dc_grad_allreduce_enqueue / _wait of libdeepcam_hip.so (csrc/comm.cpp) with the callback transport,
+    # i.e. the library calls back into torch.distributed over gloo -- the entry points the RCCL transport shares
+    red = ddist.GradReducer(eng, world, bucket_mb=16.0, collective=collective, comm="callback" if collective == "library" else None)
+    if collective == "library":
+        assert red.comm.info() == {"rank": rank, "world": world, "transport": "callback", "enqueued": 0}
     red.broadcast_parameters()
     assert float(eng.params[0]) == 1.0 and float(eng.params[-1]) == 1.0 and eng.changed == 1
     names = list(lay.params)
@@ -86,15 +90,19 @@ def _worker(rank, world, port, q):
         raise AssertionError("finish() accepted an incomplete backward")
     except RuntimeError as e:
         assert "never completed" in str(e)
+    if collective == "library":
+        assert red.comm.info()["enqueued"] >= 2 * len(red.buckets)
+        red.comm.close()
     q.put((rank, "ok"))
     dist.destroy_process_group()
 
 
-def test_grad_reducer_world2_gloo():
+@pytest.mark.parametrize("collective", ["torch", "library"])
+def test_grad_reducer_world2_gloo(collective):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, collective)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

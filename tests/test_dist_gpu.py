@@ -130,3 +130,34 @@ def test_bench_single_rank_through_torchrun_rccl():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["value"] > 0
+
+
+def test_library_collective_two_ranks_callback_transport():
+    """dc_grad_allreduce_enqueue / _wait (csrc/comm.cpp) in the reducer's place: same worker, same check (reduced gradients == sum of the two
+    ranks' gradients), the reductions travel through the library's entry points with the callback transport (gloo between two ranks on one GPU)."""
+    r = _torchrun([os.path.join(ROOT, "tests", "dist_worker.py")], 29629, extra_env={"DC_GRAD_COLLECTIVE": "lib", "DC_GRAD_COLLECTIVE_TRANSPORT": "callback"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "DIST_WORKER rel_err" in r.stdout
+
+
+def test_library_collective_rccl_single_rank():
+    """The library's RCCL transport with the one rank a one-GPU box allows: ncclGetUniqueId / ncclCommInitRank resolved at run time, in-place
+    ncclAllReduce of arena ranges on the library's communication stream behind the side stream, the wait in front of the optimizer."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29630", os.path.join(ROOT, "tests", "dist_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, DC_TEST_BACKEND="nccl", DC_GRAD_COLLECTIVE="lib"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "DIST_WORKER rel_err" in r.stdout and "transport rccl" in r.stdout
+
+
+def test_bench_two_ranks_replayed_from_the_launch_list():
+    """bench.py --program at world size 2: the recorded launch list holds the bucket all-reduces (dc_grad_allreduce_enqueue), their stream
+    fences and the wait in front of the optimizer, so the multi-GPU step is ONE C call per step (callback transport here: gloo on one GPU)."""
+    import json
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--local_batch_size", "2", "--program",
+                   "--height", "64", "--width", "96", "--no_cpu_baseline"], 29631,
+                  extra_env={"DC_GRAD_COLLECTIVE": "lib", "DC_GRAD_COLLECTIVE_TRANSPORT": "callback"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["launch_list_replay"] is True and out["comm"]["collective"] == "library (callback)" and out["value"] > 0
+    assert out["loss_last_step"] < 20
