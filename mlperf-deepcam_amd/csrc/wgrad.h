@@ -37,6 +37,7 @@ int launch_wgrad256(const WgradParams& p, hipStream_t st, int group = 1, const v
 // layer l's [splits][Co][Ci] slab or, with splits == 1, its gradient tensor
 constexpr int WG384_MAXL = 16;
 bool wgrad384_eligible(const GatherGeom& g, int ldx, int lddy, long M);
+bool wgrad384_is_tconv(const GatherGeom& g);
 void wgrad384_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group = 1);
 void wgrad384_set_slots(int n);
 void wgrad384_set_min_stages(int n);

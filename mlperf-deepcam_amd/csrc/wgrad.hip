@@ -553,6 +553,8 @@ static bool wgrad256_wins(const GatherGeom& g) {
 static bool wgrad384_wins(const GatherGeom& g) {
   if (g_wgrad384 == 0 || !wgrad384_eligible(g, 0, 0, 0)) return false;
   if (g_wgrad384 == 2) return true;
+  if (wgrad384_is_tconv(g))      // ConvTranspose2d: x is the 256-wide linear operand, [tap][dy channel] the gathered axis; "wgrad384" = 4: off
+    return g_wgrad384 != 3 && g_wgrad384 != 4 && g.Cout >= 64 && (long)cdiv(g.Cin, 256) * 256 * 3 <= (long)g.Cin * 4;
   if (g.ntaps > 1) {
     // 3 x 3 "same" convolutions: the x axis is [tap][ci] in quads of 64 channels, so any input width fills the 384-wide tiles to within
     // half a tile (304 -> 256: 45 quads = 7.5 tiles); the layer must fill the 256 output channels of a tile to three quarters

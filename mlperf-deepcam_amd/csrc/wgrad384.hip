@@ -105,11 +105,15 @@ __device__ inline T karg(size_t field_offset, int index) {
   return *(const T*)(ka + field_offset + sizeof(T) * index);
 }
 
-// TAPS = false: pointwise layers (one tap at (0, 0)); true: stride-1 "same" convolutions with several taps (3 x 3, dilated or not): the six
+// MODE 0: pointwise layers (one tap at (0, 0)).  MODE 1: stride-1 "same" convolutions with several taps (3 x 3, dilated or not): the six
 // quads of a workgroup's x tile are consecutive quads of the [tap][ci] axis, so a tile may straddle two taps; every x instruction carries its
-// tap's pixel offset, and a lane tracks the image position of its pixel row for the halo test.
-template <bool TAPS>
+// tap's pixel offset, and a lane tracks the image position of its pixel row for the halo test.  MODE 2: ConvTranspose2d(k 3, stride 2,
+// pad 1, output_padding 1): the pixel axis walks the INPUT pixels (n, iy, ix), the 256-wide linear operand is x (the kernel's "dy" role:
+// p.dy / p.lddy / p.Cout describe x) and the gathered operand of the [tap][channel] axis is dy at (2 iy + ty, 2 ix + tx), ty, tx in -1..1
+// (the kernel's "x" role); the slab keeps its [tap][dy channel][x channel] layout, so the tile is stored transposed.
+template <int MODE>
 __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
+  constexpr bool TAPS = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,7 +147,10 @@ __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
   const int drow = 8 * (wave & 3) + (lane >> 3);                     // pixel row of the stage (0 .. 31)
   const int dsub = ((lane & 7) >> 1) ^ ((drow >> 1) & 3);            // logical 16-channel chunk of the quad this lane's 16 bytes belong to
   const int dch = dsub * 16 + (lane & 1) * 8;                        // channel inside the quad
-  const unsigned lsrc_d = (unsigned)((drow * p.lddy + dch) * 2), lsrc_x = (unsigned)((drow * p.ldx + dch) * 2);
+  const unsigned lsrc_d = (unsigned)((drow * p.lddy + dch) * 2);
+  // MODE 2: signed and recomputed per stage (the gathered pixel is 4 m - 2 ox + tap offset)
+  typename std::conditional<MODE == 2, long, unsigned>::type lsrc_x = (unsigned)((drow * p.ldx + dch) * 2);
+  const int gw = MODE == 2 ? 2 * p.W : p.W, gh = MODE == 2 ? 2 * p.H : p.H;      // extents of the gathered image
   int dlim[2], xlim[3], tdy[3], tdx[3];
   long doff[2], xoff[3];
 #pragma unroll
@@ -160,11 +167,11 @@ __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
     const int tt = qok ? tap : 0;
     tdy[k] = TAPS ? karg<int>(__builtin_offsetof(Wg384Params, tdy), tt) : 0;
     tdx[k] = TAPS ? karg<int>(__builtin_offsetof(Wg384Params, tdx), tt) : 0;
-    xoff[k] = ((long)(tdy[k] * p.W + tdx[k]) * p.ldx + ciq * 64) * 2;
+    xoff[k] = ((long)(tdy[k] * gw + tdx[k]) * p.ldx + ciq * 64) * 2;
     xlim[k] = qok ? p.Cin - ciq * 64 : 0;
   }
-  const size_t dstep = (size_t)BP * p.lddy * 2, xstep = (size_t)BP * p.ldx * 2;
-  uintptr_t dcur = dbase + (size_t)mbeg * p.lddy * 2, xcur = xbase + (size_t)mbeg * p.ldx * 2;   // scalar: the stage the next DMAs belong to
+  const size_t dstep = (size_t)BP * p.lddy * 2, xstep = (size_t)(MODE == 2 ? 4 * BP : BP) * p.ldx * 2;
+  uintptr_t dcur = dbase + (size_t)mbeg * p.lddy * 2, xcur = xbase + (size_t)(MODE == 2 ? 4 : 1) * mbeg * p.ldx * 2;   // scalar: the stage the next DMAs belong to
   int rows_left = npix;                                                                         // pixels of the split from that stage on
   int oy = 0, ox = 0;                                                                           // TAPS: image position of this lane's pixel row
   if constexpr (TAPS) {
@@ -173,6 +180,7 @@ __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
     const int rem = m - n * (p.H * p.W);
     oy = fast_div(rem, p.div_w);
     ox = rem - oy * p.W;
+    if constexpr (MODE == 2) lsrc_x = ((long)(4 * drow - 2 * ox) * p.ldx + dch) * 2;
   }
   auto issue = [&](int i, int slot) {
     bool ok = drow < rows_left;
@@ -183,7 +191,8 @@ __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
     } else {
       const int k = i - 2;
       ok &= dch < xlim[k];
-      if constexpr (TAPS) ok &= ((unsigned)(oy + tdy[k]) < (unsigned)p.H) & ((unsigned)(ox + tdx[k]) < (unsigned)p.W);
+      if constexpr (MODE == 1) ok &= ((unsigned)(oy + tdy[k]) < (unsigned)gh) & ((unsigned)(ox + tdx[k]) < (unsigned)gw);
+      if constexpr (MODE == 2) ok &= ((unsigned)(2 * oy + tdy[k]) < (unsigned)gh) & ((unsigned)(2 * ox + tdx[k]) < (unsigned)gw);
       a = xcur + xoff[k] + lsrc_x;
     }
     __builtin_amdgcn_global_load_lds((gas_ptr)(ok ? a : zp), (lds_ptr)(smem + slot * STAGE + (8 * i + wave) * 1024), 16, 0, DC_WG384_AUX);
@@ -198,6 +207,7 @@ __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
         ox -= p.W;
         oy = oy + 1 == p.H ? 0 : oy + 1;
       }
+      if constexpr (MODE == 2) lsrc_x = ((long)(4 * drow - 2 * ox) * p.ldx + dch) * 2;
     }
   };
 
@@ -275,23 +285,40 @@ __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
   // write and the first read of an accumulator by a store are spelled out)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-  // ---- epilogue: acc[i][j][r] = dW of co0 + grp*64 + j*16 + fr and channel (i & 3)*16 + fg*4 + r of this wave's quad i >> 2
+  // ---- epilogue: acc[i][j][r] = dW of linear-operand channel co0 + grp*64 + j*16 + fr and channel (i & 3)*16 + fg*4 + r of this wave's quad i >> 2
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int q = q0 + wc * 3 + k;
     if (q >= nq) continue;                                      // (wave-uniform)
     const int tap = q / p.cq, ciq = q - tap * p.cq;
     const int plane = split * p.ntaps + (TAPS ? karg<int>(__builtin_offsetof(Wg384Params, twidx), tap) : 0);
-    float* out = obase + (size_t)plane * p.Cout * p.Cin + ciq * 64;
+    if constexpr (MODE != 2) {
+      float* out = obase + (size_t)plane * p.Cout * p.Cin + ciq * 64;
 #pragma unroll
-    for (int j = 0; j < NPB; ++j) {
-      const int co = co0 + grp * 64 + j * 16 + fr;
-      if (co >= p.Cout) continue;
-      float* orow = out + (size_t)co * p.Cin;
+      for (int j = 0; j < NPB; ++j) {
+        const int co = co0 + grp * 64 + j * 16 + fr;
+        if (co >= p.Cout) continue;
+        float* orow = out + (size_t)co * p.Cin;
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii) {
-        const int c = ii * 16 + fg * 4;
-        if (ciq * 64 + c < p.Cin) *reinterpret_cast<f32x4*>(orow + c) = acc[4 * k + ii][j];      // Cin % 8 == 0: all four or none
+        for (int ii = 0; ii < 4; ++ii) {
+          const int c = ii * 16 + fg * 4;
+          if (ciq * 64 + c < p.Cin) *reinterpret_cast<f32x4*>(orow + c) = acc[4 * k + ii][j];      // Cin % 8 == 0: all four or none
+        }
+      }
+    } else {
+      // transposed convolution: the slab plane is [dy channel (gathered, p.Cin of them)][x channel (linear, p.Cout of them)]
+      float* out = obase + (size_t)plane * p.Cout * p.Cin;
+#pragma unroll
+      for (int j = 0; j < NPB; ++j) {
+        const int cx = co0 + grp * 64 + j * 16 + fr;             // 16 consecutive x channels over the lanes fr: 64-byte runs
+        if (cx >= p.Cout) continue;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int cg = ciq * 64 + ii * 16 + fg * 4;
+          if (cg >= p.Cin) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[(size_t)(cg + r) * p.Cout + cx] = acc[4 * k + ii][j][r];
+        }
       }
     }
   }
@@ -299,9 +326,15 @@ __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
 
 }  // namespace
 
+// kFwd geometry of ConvTranspose2d(k 3, stride 2, pad 1, output_padding 1): four sub-pixel phases, nine taps, the produced image twice the gathered one
+bool wgrad384_is_tconv(const GatherGeom& g) {
+  return g.os == 2 && g.is == 1 && g.ntaps == 9 && g.Hout == 2 * g.Hin && g.Wout == 2 * g.Win;
+}
+
 bool wgrad384_eligible(const GatherGeom& g, int ldx, int lddy, long M) {
-  if (g.os != 1 || g.is != 1 || g.ntaps < 1 || g.ntaps > 9) return false;
   if (g.Cin % 8 != 0 || g.Cout % 8 != 0) return false;
+  if (wgrad384_is_tconv(g)) return g.Win >= BP && (size_t)4 * BP * (ldx > lddy ? ldx : lddy) * 2 + 4096 < (1ull << 31);
+  if (g.os != 1 || g.is != 1 || g.ntaps < 1 || g.ntaps > 9) return false;
   if ((size_t)BP * ldx * 2 + 2 * TCI >= (1ull << 32) || (size_t)BP * lddy * 2 + 2 * TCO >= (1ull << 32)) return false;
   if (g.ntaps == 1) return g.taps[0].dy == 0 && g.taps[0].dx == 0;
   // several taps: a "same" convolution (the kernel walks output pixels linearly and adds the tap's pixel offset) of rows at least a stage long
@@ -316,7 +349,10 @@ static int g_wgrad384_slots = 192;
 static int g_wgrad384_min_stages = 96;
 void wgrad384_set_slots(int n) { g_wgrad384_slots = n < 1 ? 1 : n; }
 void wgrad384_set_min_stages(int n) { g_wgrad384_min_stages = n < 4 ? 4 : n; }
-static long wgrad384_tiles(const GatherGeom& g) { return (long)cdiv((long)g.ntaps * cdiv(g.Cin, 64), 6) * cdiv(g.Cout, TCO); }
+static long wgrad384_tiles(const GatherGeom& g) {
+  if (wgrad384_is_tconv(g)) return (long)cdiv((long)g.ntaps * cdiv(g.Cout, 64), 6) * cdiv(g.Cin, TCO);     // gathered axis: [tap][dy channel]
+  return (long)cdiv((long)g.ntaps * cdiv(g.Cin, 64), 6) * cdiv(g.Cout, TCO);
+}
 void wgrad384_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group) {
   const long tiles = wgrad384_tiles(g) * group;
   long want = g_wgrad384_slots / tiles;
@@ -335,8 +371,9 @@ int launch_wgrad384(const WgradParams& w, hipStream_t st, int group, const void*
   static const void* zero_dev = nullptr;
   static hipError_t init_err = hipSuccess;
   DC_ONCE({
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad384_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad384_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad384_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad384_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad384_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void* zp = nullptr;
     init_err = hipGetSymbolAddress(&zp, HIP_SYMBOL(wg384_zero_page));
     zero_dev = zp;
@@ -361,8 +398,26 @@ int launch_wgrad384(const WgradParams& w, hipStream_t st, int group, const void*
     pp.out[l] = l < group ? (group == 1 && outs == nullptr ? w.slab : outs[l]) : nullptr;
   }
   const long blocks = wgrad384_tiles(g) * w.splits * group;
-  if (g.ntaps == 1) hipLaunchKernelGGL(wgrad384_kernel<false>, dim3((unsigned)blocks), dim3(512), lds, st, pp);
-  else hipLaunchKernelGGL(wgrad384_kernel<true>, dim3((unsigned)blocks), dim3(512), lds, st, pp);
+  if (wgrad384_is_tconv(g)) {
+    // ConvTranspose2d: the linear 256-wide operand is x, the gathered [tap][channel] operand dy (kernel comment, MODE 2); tap t of the kFwd
+    // geometry carries weight plane widx = 3 ky + kx and gathers dy at (2 iy - 1 + ky, 2 ix - 1 + kx)
+    pp.Cin = g.Cout; pp.Cout = g.Cin; pp.ldx = w.lddy; pp.lddy = w.ldx;
+    pp.cq = cdiv(g.Cout, 64); pp.H = g.Hin; pp.W = g.Win;
+    for (int t = 0; t < 9; ++t) {
+      const int widx = t < g.ntaps ? g.taps[t].widx : 0;
+      pp.tdy[t] = widx / 3 - 1;
+      pp.tdx[t] = widx % 3 - 1;
+    }
+    pp.div_hw = make_fastdiv(g.Hin * g.Win);
+    pp.div_w = make_fastdiv(g.Win);
+    for (int l = 0; l < WG384_MAXL; ++l) {
+      const void* t = pp.x[l];
+      pp.x[l] = pp.dy[l];
+      pp.dy[l] = t;
+    }
+    hipLaunchKernelGGL(wgrad384_kernel<2>, dim3((unsigned)blocks), dim3(512), lds, st, pp);
+  } else if (g.ntaps == 1) hipLaunchKernelGGL(wgrad384_kernel<0>, dim3((unsigned)blocks), dim3(512), lds, st, pp);
+  else hipLaunchKernelGGL(wgrad384_kernel<1>, dim3((unsigned)blocks), dim3(512), lds, st, pp);
   DC_CHECK_LAUNCH();
   return 0;
 }

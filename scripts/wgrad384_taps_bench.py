@@ -9,12 +9,15 @@ lib = L.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 CONFIGS = [("old kernels", {"wgrad384": 3}), ("384 taps", {}), ("384 taps slots 216", {"wgrad384_slots": 216}), ("384 taps slots 252", {"wgrad384_slots": 252}),
            ("384 taps slots 144", {"wgrad384_slots": 144})]
-for (k, dil, cin, cout, H, W) in [(3, 1, 256, 256, 192, 288), (3, 1, 304, 256, 192, 288), (3, 6, 2048, 256, 48, 72), (3, 18, 2048, 256, 48, 72)]:
+SHAPES = [(3, 1, 256, 256, 192, 288, 0), (3, 1, 304, 256, 192, 288, 0), (3, 6, 2048, 256, 48, 72, 0), (3, 18, 2048, 256, 48, 72, 0),
+          (3, 1, 256, 256, 192, 288, 1), (3, 1, 256, 256, 96, 144, 1), (3, 1, 256, 256, 48, 72, 1)]
+if len(sys.argv) > 2 and sys.argv[2] == "tconv": SHAPES = [s for s in SHAPES if s[6]]
+for (k, dil, cin, cout, H, W, tr) in SHAPES:
     N = B
     pad = dil * (k - 1) // 2
-    desc = L.ConvDesc(L.DC_BF16, k, 1, pad, dil, 0, cin, cout)
+    desc = L.ConvDesc(L.DC_BF16, k, 2 if tr else 1, 1 if tr else pad, dil, tr, cin, cout)
     x = torch.randn(N, H, W, r32(cin), device=dev).to(dt)
-    dy = torch.randn(N, H, W, r32(cout), device=dev).to(dt)
+    dy = torch.randn(N, (2 if tr else 1) * H, (2 if tr else 1) * W, r32(cout), device=dev).to(dt)
     gw = torch.zeros(cout * cin * k * k, device=dev)
     ref = None
     for label, opts in CONFIGS:
@@ -24,7 +27,7 @@ for (k, dil, cin, cout, H, W) in [(3, 1, 256, 256, 192, 288), (3, 1, 304, 256, 1
         L.call("dc_conv_wgrad_plan", C.byref(desc), N, H, W, 1, C.byref(splits), C.byref(sbytes))
         slab = torch.empty(sbytes.value // 4, device=dev)
         pa = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-        ent = (L.FoldEntry * 1)(L.FoldEntry(slab.data_ptr(), gw.data_ptr(), L.DC_FOLD_CONV, splits.value, k * k, cout, cin))
+        ent = (L.FoldEntry * 1)(L.FoldEntry(slab.data_ptr(), gw.data_ptr(), L.DC_FOLD_CONVT if tr else L.DC_FOLD_CONV, splits.value, k * k, cout, cin))
         def once():
             L.call("dc_conv_wgrad_partial", C.byref(desc), N, H, W, 1, pa([x]), r32(cin), pa([dy]), r32(cout), pa([slab]), splits.value, L.stream_ptr())
             L.call("dc_fold_slabs", ent, 1, L.stream_ptr())
@@ -38,5 +41,5 @@ for (k, dil, cin, cout, H, W) in [(3, 1, 256, 256, 192, 288), (3, 1, 304, 256, 1
         got = gw.clone()
         if ref is None: ref = got
         err = float((got - ref).abs().max() / ref.abs().max())
-        print(f"B={B} k{k} d{dil} {cin}->{cout} @{H}x{W} {label:20s} splits {splits.value:3d}: {us:8.1f} us  {2.0 * N * H * W * cin * cout * k * k / us / 1e6:7.1f} TF  rel.diff vs first {err:.1e}", flush=True)
+        print(f"B={B} k{k} d{dil}{'T' if tr else ''} {cin}->{cout} @{H}x{W} {label:20s} splits {splits.value:3d}: {us:8.1f} us  {2.0 * N * H * W * cin * cout * k * k / us / 1e6:7.1f} TF  rel.diff vs first {err:.1e}", flush=True)
 L.call("dc_reset_options")

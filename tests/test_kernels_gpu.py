@@ -616,6 +616,44 @@ def test_conv_wgrad_384_tile_kernel(case):
         assert_close(outs[2][l].cpu(), outs[0][l].cpu(), dtype, f32=1e-5, bf16=1e-5)
 
 
+TCONV384_CASES = [
+    # name, cin, cout, N, H, W, option overrides
+    ("256_256", 256, 256, 2, 9, 40, {"wgrad384_min_stages": 4}),
+    ("ragged_264_136", 264, 136, 1, 7, 33, {"wgrad384_min_stages": 4}),          # partial tiles on both axes, odd row length
+    ("one_row_stage", 256, 64, 2, 5, 32, {"wgrad384_min_stages": 4}),
+]
+
+
+@pytest.mark.parametrize("case", TCONV384_CASES, ids=[c[0] for c in TCONV384_CASES])
+def test_conv_transpose_wgrad_384_tile_kernel(case):
+    """ConvTranspose2d(k 3, stride 2, pad 1, output_padding 1) weight gradient on the 256 x 384 kernel (wgrad384.hip, MODE 2: x is the linear
+    operand, dy is gathered at stride 2) against autograd and against the 256 x 256 kernel."""
+    name, cin, cout, N, H, W, opts = case
+    dtype = torch.bfloat16
+    d = desc(dtype, 3, 2, 1, 1, 1, cin, cout)
+    x = q(rnd(N, cin, H, W, seed=50), dtype)
+    gy = q(rnd(N, cout, 2 * H, 2 * W, seed=51), dtype)
+    wr = torch.zeros((cin, cout, 3, 3), requires_grad=True)
+    ref = torch.autograd.grad(F.conv_transpose2d(x, wr, None, 2, 1, 1), wr, gy)[0]
+    xb, xv = to_nhwc(x, dtype, ld=cin + 16, off=8)
+    gb, gyv = to_nhwc(gy, dtype, ld=cout + 8)
+    lib = L.load()
+    outs = {}
+    for mode in (2, 0):
+        L.call("dc_set_option", b"wgrad384", mode)
+        L.call("dc_set_option", b"wgrad256", 2)
+        for kk, v in opts.items():
+            L.call("dc_set_option", kk.encode(), v)
+        wsb = lib.dc_conv_wgrad_workspace(C.byref(d), N, H, W)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev())
+        gw = torch.full((cin, cout, 3, 3), float("nan"), device=dev())
+        L.call("dc_conv_wgrad", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(gyv), cout + 8, vptr(ws), wsb, vptr(gw), S())
+        torch.cuda.synchronize()
+        outs[mode] = gw
+    assert_close(outs[2].cpu(), ref, dtype, f32=3e-4, bf16=1e-2)
+    assert_close(outs[2].cpu(), outs[0].cpu(), dtype, f32=1e-5, bf16=1e-5)
+
+
 FOLD_CASES = [
     # name, k, stride, pad, dil, transposed, cin, cout, N, H, W, layers
     ("pw728_x3", 1, 1, 0, 1, 0, 728, 728, 2, 24, 20, 3),
