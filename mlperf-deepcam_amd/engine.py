@@ -199,8 +199,9 @@ class Engine:
         wg = os.environ.get("DC_WGRAD_GROUP", "auto")
         # Round 5: the pointwise layers run on 256 x 384 tiles (csrc/wgrad384.hip), which take up to 16 layers per launch; groups of 3 / 4 / 6 / 12:
         # local batch 8 35.35 / 35.20 / 35.02 / 34.95 ms, batch 2 13.27 / - / 13.09 / 13.14, batch 4 20.51 / - / 20.40 / 20.34 (one job each,
-        # profiles/r05_ab_wgrad384.txt); the 256 x 256 kernel keeps at most four
-        self.wgrad_group = 6 if wg == "auto" else max(1, min(16, int(wg)))
+        # profiles/r05_ab_wgrad384.txt); the 256 x 256 kernel keeps at most four.  Twelve: equal in time to six, and the 728-channel layers are cut
+        # into 2 splits instead of 5 (4.7 MB of fp32 slab per layer written and read back by the fold instead of 11.8 MB)
+        self.wgrad_group = 12 if wg == "auto" else max(1, min(16, int(wg)))
         self._wg_recs: List[dict] = []
         # Weight-gradient partial sums stay in per-layer slabs and are folded by dc_fold_slabs (csrc/fold.hip): one fold per dense
         # weight-gradient launch, which also takes the rows that the depthwise data-gradient kernels since the previous fold have left.
