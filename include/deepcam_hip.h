@@ -268,6 +268,15 @@ int dc_bn_bwd_apply(int dtype, long M, int C, long count, const void* dout, int 
                     const void* out, int ldout, int relu, const float* gamma, const float* save_mean,
                     const float* save_invstd, const float* dgamma, const float* dbeta, void* dy, int lddy,
                     void* g_out, int ldg, const float* mscale, const float* mshift, void* stream);
+/* dc_bn_bwd_finalize + dc_bn_bwd_apply in ONE launch for a short slab (rows <= dc_bn_bwd_apply_fin_max_rows(): the slabs the persistent
+ * depthwise data-gradient kernels leave for the 728-channel layers have 42 rows): every block sums the slab rows of its own channels in
+ * dc_bn_bwd_finalize's order (same bits), the first row of blocks stores dgamma / dbeta.  One kernel and one dependent kernel boundary less per
+ * BatchNorm of the middle flow (autograd's batch_norm_backward at train_hdf5_ddp.py:363). */
+int dc_bn_bwd_apply_fin_max_rows(void);
+int dc_bn_bwd_apply_fin(int dtype, long M, int C, long count, const void* dout, int lddo, const void* y, int ldy,
+                        const void* out, int ldout, int relu, const float* gamma, const float* save_mean,
+                        const float* save_invstd, const float* slab, int rows, float* dgamma, float* dbeta, void* dy, int lddy,
+                        void* g_out, int ldg, const float* mscale, const float* mshift, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Entry stem: Conv2d(16->32, k3, s2, p1) reading the caller's NCHW fp32 batch directly

@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, int AP
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                            T* __restrict__ dy, int lddy, T* __restrict__ gout, int ldg,
-                                                           const float* __restrict__ mscale, const float* __restrict__ mshift) {
+                                                           const float* __restrict__ mscale, const float* __restrict__ mshift,
+                                                           const float* __restrict__ fin_slab, int fin_rows, float* dgamma_out, float* dbeta_out) {
   constexpr int KPV = Elem<T>::kPerVec;
   constexpr int RL = 256 / CGW;   // row lanes
   constexpr int CW = CGW * KPV;   // channels per block: 128..512
@@ -228,10 +229,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, int AP
     const int c = blockIdx.x * CW + i;
     float a = 0.f, b = 0.f, d = 0.f, m = 0.f, s1 = 0.f, s2 = 0.f;
     if (c < C) {
+      float dg, db;
+      if (fin_slab != nullptr) {
+        // dc_bn_bwd_apply_fin: the finalize of a SHORT slab (at most FIN_RL rows) done here, by every block for its own channels, in
+        // bn_bwd_finalize_kernel's order (rows in sequence, fp64) and rounded to fp32 as that kernel stores them: same bits, one launch
+        // and one dependent kernel boundary less per BatchNorm.  The row blocks of a channel block all compute the same numbers; block
+        // row 0 stores the parameter gradients.
+        double sb = 0.0, sg = 0.0;
+        const float* s0 = fin_slab + c;
+        const float* s1 = fin_slab + (size_t)fin_rows * C + c;
+#pragma unroll 16
+        for (int r = 0; r < fin_rows; ++r) {
+          sb += (double)s0[(size_t)r * C];
+          sg += (double)s1[(size_t)r * C];
+        }
+        db = (float)sb;
+        dg = (float)sg;
+        if (blockIdx.y == 0) {
+          dbeta_out[c] = db;
+          dgamma_out[c] = dg;
+        }
+      } else {
+        dg = dgamma[c];
+        db = dbeta[c];
+      }
       const float is = invstd[c];
       a = gamma[c] * is;
-      b = -a * is * dgamma[c] * inv_count;
-      d = -a * dbeta[c] * inv_count;
+      b = -a * is * dg * inv_count;
+      d = -a * db * inv_count;
       m = mean[c];
       if (relu == 2) {
         s1 = mscale[c];
@@ -423,10 +448,11 @@ extern "C" int dc_bn_bwd_finalize(int C, float* slab, int rows, float* dgamma, f
   return 0;
 }
 
-extern "C" int dc_bn_bwd_apply(int dtype, long M, int C, long count, const void* dout, int lddo, const void* y, int ldy,
-                               const void* out, int ldout, int relu, const float* gamma, const float* save_mean,
-                               const float* save_invstd, const float* dgamma, const float* dbeta, void* dy, int lddy,
-                               void* g_out, int ldg, const float* mscale, const float* mshift, void* stream) {
+static int bn_bwd_apply_impl(int dtype, long M, int C, long count, const void* dout, int lddo, const void* y, int ldy,
+                             const void* out, int ldout, int relu, const float* gamma, const float* save_mean,
+                             const float* save_invstd, const float* dgamma, const float* dbeta, void* dy, int lddy,
+                             void* g_out, int ldg, const float* mscale, const float* mshift, void* stream,
+                             const float* fin_slab, int fin_rows, float* dgamma_out, float* dbeta_out) {
   if (int e = dc_check_view(dout, lddo, C, dtype, "dc_bn_bwd_apply dout")) return e;
   if (int e = dc_check_view(y, ldy, C, dtype, "dc_bn_bwd_apply y")) return e;
   if (int e = dc_check_view(dy, lddy, C, dtype, "dc_bn_bwd_apply dy")) return e;
@@ -435,7 +461,7 @@ extern "C" int dc_bn_bwd_apply(int dtype, long M, int C, long count, const void*
   DC_REQUIRE(relu != 2 || (mscale && mshift), "dc_bn_bwd_apply: relu == 2 needs the forward scale / shift vectors");
   if (g_out)
     if (int e = dc_check_view(g_out, ldg, C, dtype, "dc_bn_bwd_apply g_out")) return e;
-  DC_REQUIRE(gamma && save_mean && save_invstd && dgamma && dbeta && M > 0 && count > 0, "dc_bn_bwd_apply: bad argument");
+  DC_REQUIRE(gamma && save_mean && save_invstd && ((dgamma && dbeta) || fin_slab) && M > 0 && count > 0, "dc_bn_bwd_apply: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   // a block as narrow as the tensor (see narrow_cg); the rows per block grow with the row lanes so that every thread has its four rows
@@ -444,10 +470,29 @@ extern "C" int dc_bn_bwd_apply(int dtype, long M, int C, long count, const void*
   DC_REQUIRE(cdiv(M, APPLY_ROWS) <= 65535, "dc_bn_bwd_apply: too many rows for one launch");
   const dim3 blocks(cdiv(C / kpv, cgw), cdiv(M, APPLY_ROWS));
   const float inv = 1.0f / (float)count;
-#define BN_BA(TT, W) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, W>), blocks, dim3(256), 0, st, M, C, APPLY_ROWS, inv, (const TT*)dout, lddo, (const TT*)y, ldy, (const TT*)out, ldout, relu, gamma, save_mean, save_invstd, dgamma, dbeta, (TT*)dy, lddy, (TT*)g_out, ldg, mscale, mshift)
+#define BN_BA(TT, W) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, W>), blocks, dim3(256), 0, st, M, C, APPLY_ROWS, inv, (const TT*)dout, lddo, (const TT*)y, ldy, (const TT*)out, ldout, relu, gamma, save_mean, save_invstd, dgamma, dbeta, (TT*)dy, lddy, (TT*)g_out, ldg, mscale, mshift, fin_slab, fin_rows, dgamma_out, dbeta_out)
   if (dtype == DC_BF16) { if (cgw == 64) BN_BA(bf16, 64); else if (cgw == 32) BN_BA(bf16, 32); else if (cgw == 16) BN_BA(bf16, 16); else if (cgw == 8) BN_BA(bf16, 8); else BN_BA(bf16, 4); }
   else                  { if (cgw == 64) BN_BA(float, 64); else if (cgw == 32) BN_BA(float, 32); else if (cgw == 16) BN_BA(float, 16); else if (cgw == 8) BN_BA(float, 8); else BN_BA(float, 4); }
 #undef BN_BA
   DC_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int dc_bn_bwd_apply(int dtype, long M, int C, long count, const void* dout, int lddo, const void* y, int ldy,
+                               const void* out, int ldout, int relu, const float* gamma, const float* save_mean,
+                               const float* save_invstd, const float* dgamma, const float* dbeta, void* dy, int lddy,
+                               void* g_out, int ldg, const float* mscale, const float* mshift, void* stream) {
+  return bn_bwd_apply_impl(dtype, M, C, count, dout, lddo, y, ldy, out, ldout, relu, gamma, save_mean, save_invstd, dgamma, dbeta, dy, lddy, g_out, ldg,
+                           mscale, mshift, stream, nullptr, 0, nullptr, nullptr);
+}
+
+extern "C" int dc_bn_bwd_apply_fin_max_rows(void) { return FIN_RL; }
+
+extern "C" int dc_bn_bwd_apply_fin(int dtype, long M, int C, long count, const void* dout, int lddo, const void* y, int ldy,
+                                   const void* out, int ldout, int relu, const float* gamma, const float* save_mean,
+                                   const float* save_invstd, const float* slab, int rows, float* dgamma, float* dbeta, void* dy, int lddy,
+                                   void* g_out, int ldg, const float* mscale, const float* mshift, void* stream) {
+  DC_REQUIRE(slab != nullptr && rows > 0 && rows <= FIN_RL && dgamma && dbeta, "dc_bn_bwd_apply_fin: needs a slab of at most dc_bn_bwd_apply_fin_max_rows() rows");
+  return bn_bwd_apply_impl(dtype, M, C, count, dout, lddo, y, ldy, out, ldout, relu, gamma, save_mean, save_invstd, nullptr, nullptr, dy, lddy, g_out, ldg,
+                           mscale, mshift, stream, slab, rows, dgamma, dbeta);
 }

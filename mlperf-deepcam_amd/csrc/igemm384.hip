@@ -95,7 +95,10 @@ struct Cfg {
   static constexpr int NCB = TN / 16 / GC;                // channel blocks per wave: 12 / 6
   static constexpr int TM = GP * NPB * 16;                // pixels per workgroup: 256 / 128
   static constexpr int RB = K64 ? 128 : 64;               // bytes of K per row and stage
-  static constexpr int NSTG = K64 ? 2 : NST;              // ring stages
+#ifndef DC_PW384_GP2_STAGES
+#define DC_PW384_GP2_STAGES 3
+#endif
+  static constexpr int NSTG = K64 ? 2 : (GP == 2 ? DC_PW384_GP2_STAGES : NST);   // ring stages (128 x 384: 32 KiB each, four fit)
   static constexpr int STAGE = (TN + TM) * RB;            // 40 / 32 KiB (80 KiB: K64)
   static constexpr int NI = STAGE / 1024;                 // LDS-DMA instructions per stage
   static constexpr int IPW = NI / 8;                      // per wave: 5 / 4 (10: K64)
@@ -230,19 +233,19 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
   if constexpr (!K64) {
     // ---- prologue: stages 0 and 1 in flight, stage 0 landed, first fragments requested -------------------------------------
 #pragma unroll
-    for (int q = 0; q < NST - 1; ++q)
+    for (int q = 0; q < K::NSTG - 1; ++q)
 #pragma unroll
       for (int i = 0; i < K::IPW; ++i) issue(i, q);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * K::IPW) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((K::NSTG - 2) * K::IPW) : "memory");
     __builtin_amdgcn_s_barrier();
     lds_read16<0>(fa[0], lds0 + a_off);
     lds_read16<BLK>(fa[1], lds0 + a_off);
     static_for<0, NPB>([&](auto jc) { lds_read16<decltype(jc)::value * BLK>(fb[decltype(jc)::value], lds0 + b_off); });
     // outstanding LDS reads at the top of every step, oldest first: fa[0], fa[1], fb[0] .. fb[NPB-1]
     for (int s = 0; s < kchunks; ++s) {
-      const uint32_t cur = lds0 + (s % NST) * K::STAGE, nxt = lds0 + ((s + 1) % NST) * K::STAGE;
-      // stage s+2 is issued during step s; stage s+1 (issued during step s-1) must have landed at the end of it
-      step(cur + a_off, nxt + a_off, nxt + b_off, true, s + NST - 1, std::integral_constant<int, (NST - 2) * K::IPW>{});
+      const uint32_t cur = lds0 + (s % K::NSTG) * K::STAGE, nxt = lds0 + ((s + 1) % K::NSTG) * K::STAGE;
+      // stage s + NSTG - 1 is issued during step s; stage s+1 must have landed at the end of it
+      step(cur + a_off, nxt + a_off, nxt + b_off, true, s + K::NSTG - 1, std::integral_constant<int, (K::NSTG - 2) * K::IPW>{});
     }
   } else {
     // ---- 64-deep stages, ring of two: stage s+1 is issued during the FIRST 32-deep half of stage s (its ring slot was released by the

@@ -192,6 +192,7 @@ class Engine:
         # the backward sums of a block-output BatchNorm (relu(bn(y) + residual)) taken by the next block's first depthwise data gradient,
         # the last writer of that output's gradient (dc_dwconv_dgrad_wgrad_bnres) instead of a dc_bn_bwd_reduce pass over three tensors
         self.fuse_bn_res = os.environ.get("DC_FUSE_BN_RES", "1") != "0"
+        self.fuse_bn_bwd_fin = os.environ.get("DC_FUSE_BN_BWD_FIN", "1") != "0"    # dc_bn_bwd_finalize inside dc_bn_bwd_apply for short slabs
         # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
         # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 40.31 -> 40.10 (round 3; 1 / 2 / 3 / 4 layers:
         # 40.31 / 40.28 / 40.10 / 40.18) -- the fp32 split slabs (256 KiB per workgroup whatever the batch) are a third of a 728-channel
@@ -633,11 +634,22 @@ class Engine:
                 cancel()
                 fused = None
             rslab, rrows = (fused[0], fused[1]) if fused is not None else (bslab, brows)
+            # a short slab (the 42 rows the persistent depthwise data gradient leaves on the 728-channel layers) of a SMALL tensor: the apply
+            # kernel sums it itself (dc_bn_bwd_apply_fin, same bits): one launch and one dependent boundary less per BatchNorm of the middle
+            # flow.  Every 32-row block repeats the sum for its channels, so it pays only while the grid is small: local batch 2 12.47 ->
+            # 12.38 ms, batch 4 19.80 -> 19.83, batch 8 33.47 -> 33.88 (2 592 blocks re-reading 86 KB each): on below 8 192 pixels
+            fin_in_apply = (self.fuse_bn_bwd_fin and apply_by is None and rrows <= lib.dc_bn_bwd_apply_fin_max_rows() and M <= 8192
+                            and os.environ.get("DC_DEBUG_SKIP_BN_FINALIZE", "") not in ("bwd", "both"))     # (the timing switch is read later)
 
             def bwd():
                 if fused is None:
                     L.call("dc_bn_bwd_reduce", bdt, M, Cc, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, L.dptr(mean),
                            L.dptr(invstd), L.dptr(bslab), L.dptr(scale), L.dptr(shift), self._st())
+                if fin_in_apply:
+                    L.call("dc_bn_bwd_apply_fin", bdt, M, Cc, M, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, gam, L.dptr(mean),
+                           L.dptr(invstd), L.dptr(rslab), rrows, dgam, dbet, dy.ptr, dy.ld, g_out.ptr if g_out is not None else None,
+                           g_out.ld if g_out is not None else 0, L.dptr(scale), L.dptr(shift), self._st())
+                    return
                 if self._debug_skip_finalize not in ("bwd", "both"):
                     L.call("dc_bn_bwd_finalize", Cc, L.dptr(rslab), rrows, dgam, dbet, self._st())
                 if apply_by is not None:

@@ -100,6 +100,8 @@ _SIGS = {
     "dc_bn_bwd_reduce": (I, [I, L, I, P, I, P, I, P, I, I, P, P, P, P, P, P]),
     "dc_bn_bwd_finalize": (I, [I, P, I, P, P, P]),
     "dc_bn_bwd_apply": (I, [I, L, I, L, P, I, P, I, P, I, I, P, P, P, P, P, P, I, P, I, P, P, P]),
+    "dc_bn_bwd_apply_fin_max_rows": (I, []),
+    "dc_bn_bwd_apply_fin": (I, [I, L, I, L, P, I, P, I, P, I, I, P, P, P, P, I, P, P, P, I, P, I, P, P, P]),
     "dc_stem_stat_rows": (I, [I, I, I]),
     "dc_stem_fwd": (I, [I, I, I, I, I, P, P, P, I, P, P]),
     "dc_stem_wgrad_workspace": (SZ, [I, I, I, I]),

@@ -1241,6 +1241,19 @@ def test_batchnorm_train_fwd_bwd(shape, dtype, relu, use_res):
     L.call("dc_bn_bwd_apply", dt, M, Cc, M, vptr(gov), Cc, vptr(yv), Cc + 8, vptr(ov), Cc + 16, relu, vptr(g_d), vptr(smean),
            vptr(sinv), vptr(dgamma), vptr(dbeta), vptr(dyv), Cc, vptr(gv), Cc, None, None, S())
     torch.cuda.synchronize()
+    # the finalize of a short slab inside the apply kernel (dc_bn_bwd_apply_fin): same bits as the two calls
+    if rows <= L.load().dc_bn_bwd_apply_fin_max_rows():
+        dgamma2, dbeta2 = torch.full((Cc,), float("nan"), device=dev()), torch.full((Cc,), float("nan"), device=dev())
+        _, dyv2 = empty_nhwc(N, H, W, Cc, dtype)
+        _, gv2 = empty_nhwc(N, H, W, Cc, dtype)
+        L.call("dc_bn_bwd_apply_fin", dt, M, Cc, M, vptr(gov), Cc, vptr(yv), Cc + 8, vptr(ov), Cc + 16, relu, vptr(g_d), vptr(smean),
+               vptr(sinv), vptr(slab2), rows, vptr(dgamma2), vptr(dbeta2), vptr(dyv2), Cc, vptr(gv2), Cc, None, None, S())
+        torch.cuda.synchronize()
+        assert torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta)
+        assert torch.equal(dyv2.float(), dyv.float()) and torch.equal(gv2.float(), gv.float())
+    with pytest.raises(L.DeepcamHipError):
+        L.call("dc_bn_bwd_apply_fin", dt, M, Cc, M, vptr(gov), Cc, vptr(yv), Cc + 8, vptr(ov), Cc + 16, relu, vptr(g_d), vptr(smean),
+               vptr(sinv), vptr(slab2), 65, vptr(dgamma), vptr(dbeta), vptr(dyv), Cc, vptr(gv), Cc, None, None, S())
     # with bf16 storage the ReLU mask is taken from the ROUNDED output; compare against a reference using that mask
     if M > 2:  # (a 2-sample BN has |xhat| == 1: dgamma/dy are cancellation-dominated, checked loosely below)
         assert_close(dgamma.cpu(), grads[1], dtype, f32=5e-4, bf16=2e-2)
