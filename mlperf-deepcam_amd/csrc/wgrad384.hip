@@ -381,6 +381,9 @@ int launch_wgrad384(const WgradParams& w, hipStream_t st, int group, const void*
   if (init_err != hipSuccess) return dc_set_error(init_err, __FILE__, __LINE__);
   if (group < 1 || group > WG384_MAXL) return dc_fail("launch_wgrad384: group size out of range", __FILE__, __LINE__);
   const GatherGeom& g = w.g;
+  // (the planner decides eligibility before the row strides are known: the kernel's 32-bit lane offsets hold for these)
+  if (!wgrad384_eligible(g, w.ldx, w.lddy, w.M) || w.ldx < g.Cin || w.lddy < g.Cout)
+    return dc_fail("launch_wgrad384: geometry or row strides outside what the kernel serves", __FILE__, __LINE__);
   Wg384Params pp;
   pp.zero_page = zero_dev;
   pp.Cin = g.Cin; pp.Cout = g.Cout; pp.ldx = w.ldx; pp.lddy = w.lddy;
