@@ -144,9 +144,10 @@ size_t dc_conv_wgrad_workspace(const dc_conv_desc* d, int N, int Hi, int Wi);
 int dc_conv_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* dy,
                   int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream);
 
-/* The same for `count` (<= 4) layers of ONE geometry in one launch: xs / dys / grad_ws are host arrays of `count` device
- * pointers (same ldx / lddy).  Replaces the per-layer conv_backward_weight calls autograd makes for the three pointwise
- * convs of a middle-flow Block (deeplab_xception.py:69-122, 211-226): the layers share the launch, so each is cut into fewer,
+/* The same for `count` layers of ONE geometry in one launch (count <= 16 where the 256 x 384 kernel serves the layer -- pointwise layers,
+ * stride-1 3 x 3 layers, transposed convolutions: csrc/wgrad384.hip --, <= 4 on the 256 x 256 kernel): xs / dys / grad_ws are host arrays of
+ * `count` device pointers (same ldx / lddy).  Replaces the per-layer conv_backward_weight calls autograd makes for the pointwise
+ * convs of the middle-flow Blocks (deeplab_xception.py:69-122, 211-226): the layers share the launch, so each is cut into fewer,
  * longer pixel splits.  Results are bit-identical run to run (fixed-order reduction); layers the grouped kernel does not serve
  * are computed by `count` plain dc_conv_wgrad calls. */
 size_t dc_conv_wgrad_group_workspace(const dc_conv_desc* d, int N, int Hi, int Wi, int count);
