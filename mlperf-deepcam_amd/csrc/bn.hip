@@ -191,6 +191,62 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(long M, int C, const T* _
   }
 }
 
+// The same pass in bn_bwd_apply_kernel's thread layout (round 5): CGW channel groups x (256 / CGW) row lanes per block, APPLY_ROWS rows per block, a
+// thread's channels never change, so scale / shift live in registers and four rows are in flight per thread.  The grid-stride kernel above
+// divides a 64-bit element index by the channel-group count and re-loads sixteen coefficients for every 16 bytes it moves (5.0 TB/s on the
+// 728-channel block outputs where this layout's backward twin reaches 5.9); same arithmetic, same bits.
+template <typename T, int CGW>
+__global__ __launch_bounds__(256) void bn_apply_rows_kernel(long M, int C, int APPLY_ROWS, const T* __restrict__ y, int ldy,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const T* __restrict__ res, int ldr, int relu, T* __restrict__ out, int ldo) {
+  constexpr int KPV = Elem<T>::kPerVec;
+  constexpr int RL = 256 / CGW;
+  const int cgl = threadIdx.x % CGW, rl = threadIdx.x / CGW;
+  const int c0 = (blockIdx.x * CGW + cgl) * KPV;
+  if (c0 >= C) return;
+  float sc[KPV], sh[KPV];
+#pragma unroll
+  for (int e = 0; e < KPV; ++e) {
+    sc[e] = scale[c0 + e];
+    sh[e] = shift[c0 + e];
+  }
+  const long rbeg = (long)blockIdx.y * APPLY_ROWS;
+  const long rend = rbeg + APPLY_ROWS < M ? rbeg + APPLY_ROWS : M;
+  constexpr int UR = 4;
+  for (long r0 = rbeg + rl; r0 < rend; r0 += RL * UR) {
+    vec16 vy[UR], vr[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const long r = r0 + RL * u;
+      const long rr = r < rend ? r : rbeg;
+      vy[u] = ldg16(y + (size_t)rr * ldy + c0);
+      if (res != nullptr) vr[u] = ldg16(res + (size_t)rr * ldr + c0);
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const long r = r0 + RL * u;
+      if (r >= rend) break;
+      float x[KPV];
+      unpack(vy[u], x, T());
+#pragma unroll
+      for (int e = 0; e < KPV; ++e) x[e] = fmaf(x[e], sc[e], sh[e]);
+      if (res != nullptr) {
+        float q[KPV];
+        unpack(vr[u], q, T());
+#pragma unroll
+        for (int e = 0; e < KPV; ++e) x[e] += q[e];
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < KPV; ++e) x[e] = fmaxf(x[e], 0.f);
+      }
+      vec16 v;
+      pack(v, x, T());
+      stg16(out + (size_t)r * ldo + c0, v);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, const float* __restrict__ slab, int rows, int parts, float* dgamma,
                                                               float* dbeta) {
   __shared__ double red[2][FIN_RL][FIN_CH];
@@ -207,6 +263,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, const float
 // coefficients are computed once and live in registers -- the earlier grid-stride version re-loaded five vectors per element
 // and ran at 3.2 TB/s where a copy reaches 4.9.
 static int g_bn_cgw = 32, g_bn_rows = 32;
+static int g_bn_apply_rows = 1;     // dc_bn_apply on bn_apply_rows_kernel (0: the grid-stride kernel; "bn_apply_rows")
 template <typename T, int CGW>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, int APPLY_ROWS, float inv_count, const T* __restrict__ dout,
                                                            int lddo, const T* __restrict__ y, int ldy,
@@ -351,6 +408,7 @@ using namespace dc;
 extern "C" int dc_bn_set_option(const char* name, int value) {
   if (strcmp(name, "bn_cgw") == 0 && (value == 16 || value == 32 || value == 64)) { g_bn_cgw = value; return 0; }
   if (strcmp(name, "bn_rows") == 0 && value >= 16 && value % 16 == 0) { g_bn_rows = value; return 0; }
+  if (strcmp(name, "bn_apply_rows") == 0) { g_bn_apply_rows = value != 0; return 0; }
   return -1;
 }
 
@@ -417,6 +475,20 @@ extern "C" int dc_bn_apply(int dtype, long M, int C, const void* y, int ldy, con
   DC_REQUIRE(scale && shift && M > 0, "dc_bn_apply: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const int kpv = dtype == DC_BF16 ? 8 : 4;
+  if (g_bn_apply_rows) {
+    // bn_bwd_apply's block shape (a block as narrow as the tensor, rows per block growing with the row lanes)
+    const int cgw = narrow_cg(C / kpv, g_bn_cgw);
+    const int APPLY_ROWS = g_bn_rows * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
+    if (cdiv(M, APPLY_ROWS) <= 65535) {
+      const dim3 blocks2(cdiv(C / kpv, cgw), cdiv(M, APPLY_ROWS));
+#define BN_AR(TT, W) hipLaunchKernelGGL((bn_apply_rows_kernel<TT, W>), blocks2, dim3(256), 0, st, M, C, APPLY_ROWS, (const TT*)y, ldy, scale, shift, (const TT*)residual, ldr, relu, (TT*)out, ldo)
+      if (dtype == DC_BF16) { if (cgw == 64) BN_AR(bf16, 64); else if (cgw == 32) BN_AR(bf16, 32); else if (cgw == 16) BN_AR(bf16, 16); else if (cgw == 8) BN_AR(bf16, 8); else BN_AR(bf16, 4); }
+      else                  { if (cgw == 64) BN_AR(float, 64); else if (cgw == 32) BN_AR(float, 32); else if (cgw == 16) BN_AR(float, 16); else if (cgw == 8) BN_AR(float, 8); else BN_AR(float, 4); }
+#undef BN_AR
+      DC_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   const int blocks = ew_blocks(M * (C / kpv));
   if (dtype == DC_BF16)
     hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(blocks), dim3(256), 0, st, M, C, (const bf16*)y, ldy, scale, shift, (const bf16*)residual, ldr, relu, (bf16*)out, ldo);

@@ -1225,7 +1225,14 @@ def test_batchnorm_train_fwd_bwd(shape, dtype, relu, use_res):
     _, ov = empty_nhwc(N, H, W, Cc, dtype, ld=Cc + 16, off=8)
     L.call("dc_bn_apply", dt, M, Cc, vptr(yv), Cc + 8, vptr(scale), vptr(shift), vptr(resv) if use_res else None, Cc, relu,
            vptr(ov), Cc + 16, S())
+    # the row-layout kernel (default) and the grid-stride kernel do the same arithmetic: same bits, pad channels untouched
+    ob2, ov2 = empty_nhwc(N, H, W, Cc, dtype, ld=Cc + 16, off=8)
+    L.call("dc_set_option", b"bn_apply_rows", 0)
+    L.call("dc_bn_apply", dt, M, Cc, vptr(yv), Cc + 8, vptr(scale), vptr(shift), vptr(resv) if use_res else None, Cc, relu,
+           vptr(ov2), Cc + 16, S())
+    L.call("dc_set_option", b"bn_apply_rows", 1)
     torch.cuda.synchronize()
+    assert torch.equal(ov.float(), ov2.float()) and torch.isnan(ob2[..., :8].float()).all() and torch.isnan(ob2[..., 8 + Cc:].float()).all()
     assert int(nbt) == 1
     np.testing.assert_allclose(rm_d.cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(rv_d.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-5)
