@@ -145,6 +145,7 @@ class Engine:
             assert share_from.layout.n_params == lay.n_params and share_from.device == self.device
             self.params, self.grads, self.buffers, self.nbt = share_from.params, share_from.grads, share_from.buffers, share_from.nbt
             self.version = share_from.version
+            self.grads_live = share_from.grads_live
         else:
             host = torch.empty(lay.n_params, dtype=torch.float32)
             if layout is None:
@@ -160,6 +161,9 @@ class Engine:
             self.buffers = hb.to(self.device)
             self.nbt = torch.zeros(len(lay.nbt), dtype=torch.int64, device=self.device)
             self.version = [0]          # bumped whenever the master weights change (optimizer step, load_state_dict)
+            # [True] between a loss.backward() through the module and the next optimizer.zero_grad() / step(): a second backward in that
+            # window OVERWRITES the gradients (the engine never accumulates), which nn._NetFn.backward then says out loud
+            self.grads_live = [False]
         self.packed_version = -1
         self._keep: List[torch.Tensor] = []
         # Fusing the BatchNorm(+ReLU) into the consuming depthwise conv is implemented and tested, but measured slower at B=8

@@ -135,6 +135,14 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         eng = ctx.eng
+        if eng.grads_live[0] and not getattr(ctx.module, "_warned_no_accumulation", False):
+            # the reference's loop calls optimizer.zero_grad() before every backward (train_hdf5_ddp.py:358-364); a caller that relies on
+            # p.grad accumulating over several backward calls would silently train on the LAST micro-batch only
+            import warnings
+            warnings.warn("loss.backward() was called again without optimizer.zero_grad() / step() in between: this engine OVERWRITES the "
+                          "gradients (every backward writes each parameter's gradient exactly once), it does not accumulate them", RuntimeWarning)
+            ctx.module._warned_no_accumulation = True
+        eng.grads_live[0] = True
         _ops.OPS.net_backward(dlogits, _ops.engine_handle(eng))
         red = ctx.module._ddp_reducer
         if red is not None:
@@ -298,7 +306,9 @@ class ArenaOptimizer:
         self.state = {}
 
     def zero_grad(self, set_to_none: bool = True):
-        # every backward overwrites the whole gradient arena (each parameter exactly once): nothing to clear
+        # every backward overwrites the whole gradient arena (each parameter exactly once): nothing to clear.  (Gradient ACCUMULATION over
+        # several backward calls is not supported: _NetFn.backward warns when a second backward arrives without a zero_grad() / step().)
+        self.engine.grads_live[0] = False
         return None
 
     def sync_scalars(self) -> None:
@@ -337,6 +347,7 @@ class ArenaOptimizer:
         self.step_count += 1
         self.sync_scalars()
         self.launch()
+        self.engine.grads_live[0] = False
 
     # -- torch.optim.Adam-compatible serialisation
     def state_dict(self):

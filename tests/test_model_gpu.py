@@ -348,6 +348,30 @@ def test_program_slots_and_errors():
         bad.run()
 
 
+def test_second_backward_without_zero_grad_warns():
+    """The engine overwrites gradients, it never accumulates them (INTEGRATION level 1): a loss.backward() that arrives without
+    an optimizer.zero_grad() / step() since the previous one says so (once per module) instead of silently training on the last micro-batch."""
+    import warnings
+    B, H, W = 2, 64, 96
+    x, y = make_inputs(B, H, W)
+    dev = torch.device("cuda", 0)
+    net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=torch.bfloat16, seed=333)
+    net.materialize(B, H, W)
+    net.train()
+    opt = dnn.make_optimizer("AdamW", net, 1e-3, 1e-8, 1e-2)
+    cw = olm.class_weights(-0.125)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for _ in range(2):                               # the reference's order: no warning
+            opt.zero_grad()
+            dnn.fp_loss(net(x.to(dev)), y.to(dev), cw).backward()
+            opt.step()
+        assert not [w for w in rec if "does not accumulate" in str(w.message)]
+        dnn.fp_loss(net(x.to(dev)), y.to(dev), cw).backward()
+        dnn.fp_loss(net(x.to(dev)), y.to(dev), cw).backward()      # a second backward in the same window
+        assert len([w for w in rec if "does not accumulate" in str(w.message)]) == 1
+
+
 def test_steps_enqueued_ahead_match_synchronised_steps():
     """The host may enqueue steps far ahead of the GPU (bench.py does): the optimizer's device scalars (lr, step count) must be
     the ones of THEIR step.  Six steps enqueued back to back == six steps with a device synchronisation after each."""
