@@ -4,6 +4,18 @@
 
 namespace dc {
 
+// K stride (elements) of a packed weight row: rows of 64 and more elements start on a 128-byte boundary (728 -> 768), so that a 128-byte K piece of a
+// row is ONE L2 line (scripts/fill_bench.hip: the LDS-DMA fill of a tile reads 15.3 TB/s from line-aligned rows, 12.6 from rows on 64-byte
+// boundaries, 10.9 from rows on 16-byte boundaries); shorter rows keep 64-byte boundaries.  The pad is never read.  DC_WLD_ALIGN=32: the stride up to round 4.
+#ifndef DC_WLD_ALIGN
+#define DC_WLD_ALIGN 64
+#endif
+__host__ __device__ inline int weight_ld(int c) {
+  const int a = c < 64 ? 32 : DC_WLD_ALIGN;
+  return (c + a - 1) / a * a;
+}
+
+
 // Optional epilogue of a data-gradient launch whose output is the gradient w.r.t. a BatchNorm(+ReLU) output: the BatchNorm's
 // backward sums (sum g, sum g * xhat; g = the stored gradient masked by the ReLU, recomputed as y * mscale + mshift > 0) are taken
 // from the values on their way out, into the statistics slab, instead of a separate pass over dx and y (bn.hip, colred MODE 1).
@@ -25,7 +37,7 @@ struct IgemmParams {
   float* slab;
   GatherGeom g;
   int N, ldx, ldy;
-  int ldw;     // K stride of a packed weight row: Cin rounded up to 32 elements, so every row starts on a 64-byte boundary
+  int ldw;     // K stride of a packed weight row: weight_ld(Cin)
   int M;       // END of this launch's pixel range (per phase); N*Qh*Qw when the launch covers the layer
   int m_beg;   // first pixel of this launch's range (a multiple of 256): the mixed plan of run_gather cuts a layer into a
                // 256-tile launch over [0, m_beg') and a 128-tile launch over [m_beg', M)

@@ -593,7 +593,7 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   DC_REQUIRE(!(slab != nullptr && accumulate), "dc_conv: statistics and accumulate are exclusive");
   p.x = in; p.w = w; p.y = out; p.bias = bias; p.slab = slab;
   p.N = N; p.ldx = ldin; p.ldy = ldout;
-  p.ldw = (p.g.Cin + 31) / 32 * 32;
+  p.ldw = weight_ld(p.g.Cin);
   const long M = (long)N * p.g.Qh * p.g.Qw;
   DC_REQUIRE(M < (1L << 31) - BM, "dc_conv: too many pixels for 32-bit indexing");
   p.M = (int)M;
@@ -652,7 +652,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ master, T* __restr
       co = (int)(r / cin);
     }
     const float v = master[i];
-    const int ldf = (cin + 31) / 32 * 32, ldb = (cout + 31) / 32 * 32;   // padded K strides (the pad is never read)
+    const int ldf = weight_ld(cin), ldb = weight_ld(cout);   // padded K strides (the pad is never read)
     if (wf) Elem<T>::store(wf + ((size_t)t * cout + co) * ldf + ci, v);
     if (wb) Elem<T>::store(wb + ((size_t)t * cin + ci) * ldb + co, v);
   }
@@ -683,9 +683,9 @@ __device__ inline void pack_store_run<bf16>(bf16* dst, float v0, float v1) { *re
 template <typename T, int TAPS>
 __device__ inline void pack_dense_tile(const PackEntry& e, int tile, float* lds) {
   const int A = e.kind == 1 ? e.cin : e.cout, B = e.kind == 1 ? e.cout : e.cin;
-  T* P = reinterpret_cast<T*>(e.kind == 1 ? e.wb : e.wf);   // [t][a][b], row stride r32(B)
-  T* Q = reinterpret_cast<T*>(e.kind == 1 ? e.wf : e.wb);   // [t][b][a], row stride r32(A)
-  const int ldp = (B + 31) / 32 * 32, ldq = (A + 31) / 32 * 32;
+  T* P = reinterpret_cast<T*>(e.kind == 1 ? e.wb : e.wf);   // [t][a][b], row stride weight_ld(B)
+  T* Q = reinterpret_cast<T*>(e.kind == 1 ? e.wf : e.wb);   // [t][b][a], row stride weight_ld(A)
+  const int ldp = weight_ld(B), ldq = weight_ld(A);
   constexpr int TS = TAPS == 1 ? 64 : 32;       // tile edge
   constexpr int ROWF = TS * TAPS + 1;           // padded LDS row (floats): odd stride -> conflict-free column reads
   const int ntb = (B + TS - 1) / TS;
@@ -733,9 +733,9 @@ __device__ inline void pack_dense_tile(const PackEntry& e, int tile, float* lds)
 // generic pass ran at 1.7 TB/s).  Same conversions (pack2_bf16), same bits.  Needs A and B to be multiples of 8.
 __device__ inline void pack_pointwise_tile_bf16(const PackEntry& e, int tile, float* lds) {
   const int A = e.kind == 1 ? e.cin : e.cout, B = e.kind == 1 ? e.cout : e.cin;
-  bf16* P = reinterpret_cast<bf16*>(e.kind == 1 ? e.wb : e.wf);   // [a][b], row stride r32(B)
-  bf16* Q = reinterpret_cast<bf16*>(e.kind == 1 ? e.wf : e.wb);   // [b][a], row stride r32(A)
-  const int ldp = (B + 31) / 32 * 32, ldq = (A + 31) / 32 * 32;
+  bf16* P = reinterpret_cast<bf16*>(e.kind == 1 ? e.wb : e.wf);   // [a][b], row stride weight_ld(B)
+  bf16* Q = reinterpret_cast<bf16*>(e.kind == 1 ? e.wf : e.wb);   // [b][a], row stride weight_ld(A)
+  const int ldp = weight_ld(B), ldq = weight_ld(A);
   constexpr int TS = 64, ROWF = TS + 1;
   const int ntb = (B + TS - 1) / TS;
   const int a0 = (tile / ntb) * TS, b0 = (tile % ntb) * TS;
@@ -990,7 +990,7 @@ extern "C" int dc_conv_fwd_dilated_group(const dc_conv_desc* d, int N, int Hi, i
   p.x = x; p.w = wfs[0]; p.y = ys[0]; p.bias = nullptr; p.slab = stat_slabs ? stat_slabs[0] : nullptr;
   p.bst = BnBwdEpi{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
   p.N = N; p.ldx = ldx; p.ldy = ldy;
-  p.ldw = (p.g.Cin + 31) / 32 * 32;
+  p.ldw = weight_ld(p.g.Cin);
   p.M = (int)M; p.m_beg = 0; p.phase_fast = 0; p.zero_page = nullptr;
   p.mtiles = cdiv(M, BM);
   p.accumulate = 0;
@@ -1036,8 +1036,8 @@ extern "C" int dc_conv_dgrad_bnstats(const dc_conv_desc* d, int N, int Hi, int W
 extern "C" int dc_conv_packed_elems(const dc_conv_desc* d, size_t* wf_elems, size_t* wb_elems) {
   DC_REQUIRE(d != nullptr, "dc_conv_packed_elems: null descriptor");
   const size_t k = d->transposed ? 3 : d->k;
-  if (wf_elems) *wf_elems = k * k * d->cout * (size_t)((d->cin + 31) / 32 * 32);
-  if (wb_elems) *wb_elems = k * k * d->cin * (size_t)((d->cout + 31) / 32 * 32);
+  if (wf_elems) *wf_elems = k * k * d->cout * (size_t)weight_ld(d->cin);
+  if (wb_elems) *wb_elems = k * k * d->cin * (size_t)weight_ld(d->cout);
   return 0;
 }
 

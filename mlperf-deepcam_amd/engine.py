@@ -39,9 +39,12 @@ class Act:
         self.eng, self.name, self.N, self.H, self.W, self.C = eng, name, N, H, W, Cc
         self.parent, self.off = parent, off
         if parent is None:
-            # pixel stride rounded up to 32 elements: every pixel row then starts on a 64-byte boundary (728 -> 736), which
-            # the LDS-DMA loaders of the GEMM kernels reward with 15-20 %; the pad channels are never read or written
-            self.ld = Cc if Cc < 64 else (Cc + 31) // 32 * 32
+            # pixel stride rounded up to 64 elements: every pixel row of a bf16 tensor then starts on a 128-byte boundary (728 -> 768), so a
+            # 128-byte K piece of a row is ONE L2 line for the LDS-DMA loaders of the GEMM kernels (scripts/fill_bench.hip: 15.3 TB/s from
+            # line-aligned rows, 12.6 from 64-byte boundaries (736, the stride up to round 4), 10.9 from 728); the pad channels are never
+            # read or written.  DC_ACT_ALIGN=32: the previous stride
+            al = eng.act_align
+            self.ld = Cc if Cc < 64 else (Cc + al - 1) // al * al
             self.buf = torch.empty((N, H, W, self.ld), dtype=dtype or eng.dtype, device=eng.device)
             eng.act_bytes += self.buf.numel() * self.buf.element_size()
             eng.saved[name] = self.buf
@@ -135,6 +138,8 @@ class Engine:
         self._builder = builder
         lay = self.layout
         self.act_bytes = 0
+        self.act_align = int(os.environ.get("DC_ACT_ALIGN", "64"))      # pixel stride of the activation tensors in elements (Act)
+        assert self.act_align in (32, 64, 128), "DC_ACT_ALIGN: 32, 64 or 128"
         # name -> tensor of everything forward leaves behind for backward (activations, BatchNorm coefficient vectors): lets a
         # test put two engines on ONE linearisation point (tests/test_model_gpu.py::test_backward_parity_at_shared_activations)
         self.saved: Dict[str, torch.Tensor] = {}

@@ -310,7 +310,9 @@ void oob_test() {
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 27648, C = argc > 2 ? atoi(argv[2]) : 728;
-  const int ld = (C + 63) / 64 * 64;
+  // row stride in elements (third argument): the default pads rows to whole 128-byte lines; 728 / 736 are the strides the 728-channel
+  // activations / weight images of the engine had before round 5's padding experiment
+  const int ld = argc > 3 ? atoi(argv[3]) : (C + 63) / 64 * 64;
   __bf16 *x, *w;
   float* out;
   unsigned long long* cyc;

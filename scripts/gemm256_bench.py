@@ -16,7 +16,7 @@ for (k, s, p, d, tr, cin, cout, N, H, W) in shapes:
     kk = 9 if tr else k * k
     Ho, Wo = C.c_int(), C.c_int(); L.call("dc_conv_out_hw", C.byref(desc), H, W, C.byref(Ho), C.byref(Wo)); Ho, Wo = Ho.value, Wo.value
     x = torch.randn(N, H, W, r32(cin), device=dev).to(dt)
-    wf = (torch.randn(kk * cout * r32(cin), device=dev) * 0.05).to(dt)
+    wf = (torch.randn(kk * cout * ((cin + 63) // 64 * 64), device=dev) * 0.05).to(dt)
     rows = lib.dc_conv_stat_rows(C.byref(desc), N, H, W)
     outs, res = [], []
     for mode in (0, 2):

@@ -8,7 +8,7 @@ shapes = [(1,1,0,1,0,728,728,8,48,72), (1,1,0,1,0,768,768,8,48,72), (1,1,0,1,0,7
 def run(kind, k,s,p,d,tr,cin,cout,N,H,W, reps=20):
     desc = L.ConvDesc(L.DC_BF16, k,s,p,d,tr,cin,cout)
     x = torch.randn(N,H,W,cin, device=dev).to(dt); kk = k*k
-    wf = torch.randn(kk*cout*((cin+31)//32*32), device=dev).to(dt) * 0.05
+    wf = torch.randn(kk*cout*((cin+63)//64*64), device=dev).to(dt) * 0.05
     y = torch.empty(N,H,W,cout, device=dev, dtype=dt)
     rows = L.load().dc_conv_stat_rows(C.byref(desc), N,H,W); slab = torch.empty(2*rows*cout, device=dev)
     wsb = L.load().dc_conv_wgrad_workspace(C.byref(desc), N,H,W); ws = torch.empty(max(wsb,16), dtype=torch.uint8, device=dev)

@@ -20,7 +20,7 @@ for tag, pw, k, pad, cin, cout, N, H, W in shapes:
     L.call("dc_set_option", b"pw384", pw)
     desc = L.ConvDesc(L.DC_BF16, k, 1, pad, 1, 0, cin, cout)
     x = torch.randn(N, H, W, r32(cin), device=dev).to(dt)
-    wf = (torch.randn(k * k * cout * r32(cin), device=dev) * 0.05).to(dt)
+    wf = (torch.randn(k * k * cout * ((cin + 63) // 64 * 64), device=dev) * 0.05).to(dt)
     rows = lib.dc_conv_stat_rows(C.byref(desc), N, H, W)
     y = torch.zeros(N, H, W, r32(cout), device=dev, dtype=dt); slab = torch.zeros(2 * rows * cout, device=dev)
     for _ in range(6):

@@ -11,7 +11,7 @@ cin, cout, k, H, W, N = a[0] or 728, a[1] or 728, a[2] or 1, a[3] or 48, a[4] or
 dev = torch.device("cuda", 0); dt = torch.bfloat16
 ld, ldo = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
 desc = L.ConvDesc(L.DC_BF16, k, 1, k // 2, 1, 0, cin, cout)
-x = torch.randn(N, H, W, ld, device=dev).to(dt); wf = (torch.randn(k * k * cout * ld, device=dev) * 0.05).to(dt)
+x = torch.randn(N, H, W, ld, device=dev).to(dt); wf = (torch.randn(k * k * cout * ((cin + 63) // 64 * 64), device=dev) * 0.05).to(dt)
 y = torch.empty(N, H, W, ldo, device=dev, dtype=dt)
 lib = L.load()
 rows = lib.dc_conv_stat_rows(C.byref(desc), N, H, W); slab = torch.empty(2 * rows * cout, device=dev)

@@ -13,7 +13,7 @@ lib = L.load()
 for (cin, cout, N, H, W) in shapes:
     desc = L.ConvDesc(L.DC_BF16, 1, 1, 0, 1, 0, cin, cout)
     x = torch.randn(N, H, W, r32(cin), device=dev).to(dt)
-    wf = (torch.randn(cout * r32(cin), device=dev) * 0.05).to(dt)
+    wf = (torch.randn(cout * ((cin + 63) // 64 * 64), device=dev) * 0.05).to(dt)
     rows = lib.dc_conv_stat_rows(C.byref(desc), N, H, W)
     outs, res = [], []
     for mode in (0, 2, 3, 4, 5):

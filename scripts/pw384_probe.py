@@ -13,7 +13,7 @@ out = []
 for (cin, cout, N, H, W, mode) in [(728, 728, 2, 48, 72, 2), (728, 728, 8, 48, 72, 2), (2912, 728, 8, 48, 72, 2), (728, 728, 4, 48, 72, 3)]:
     desc = L.ConvDesc(L.DC_BF16, 1, 1, 0, 1, 0, cin, cout)
     x = torch.randn(N, H, W, r32(cin), device=dev).to(dt)
-    wf = (torch.randn(cout * r32(cin), device=dev) * 0.05).to(dt)
+    wf = (torch.randn(cout * ((cin + 63) // 64 * 64), device=dev) * 0.05).to(dt)
     rows = lib.dc_conv_stat_rows(C.byref(desc), N, H, W)
     y = torch.zeros(N, H, W, r32(cout), device=dev, dtype=dt); slab = torch.zeros(2 * rows * cout, device=dev)
     L.call("dc_set_option", b"pw384", mode)

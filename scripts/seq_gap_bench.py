@@ -16,7 +16,7 @@ xs = [torch.randn(N, H, W, ld, device=dev).to(torch.bfloat16) for _ in range(NB)
 ds = [torch.empty_like(x) for x in xs]
 ys = [torch.empty_like(x) for x in xs]
 desc = L.ConvDesc(dt, 1, 1, 0, 1, 0, Cc, Cc)
-wf = (torch.randn(Cc * ld, device=dev) * 0.05).to(torch.bfloat16)
+wf = (torch.randn(Cc * ((Cc + 63) // 64 * 64), device=dev) * 0.05).to(torch.bfloat16)
 rows = lib.dc_conv_stat_rows(C.byref(desc), N, H, W)
 slab = torch.zeros(2 * rows * Cc, device=dev)
 wp = torch.randn(9 * Cc, device=dev) * 0.2

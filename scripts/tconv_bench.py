@@ -9,7 +9,7 @@ for (H, W) in [(192, 288), (96, 144), (48, 72)]:
     N, cin, cout = 8, 256, 256
     desc = L.ConvDesc(L.DC_BF16, 3, 2, 1, 1, 1, cin, cout)
     x = torch.randn(N, H, W, cin, device=dev).to(dt)
-    wf = (torch.randn(9 * cout * cin, device=dev) * 0.05).to(dt)
+    wf = (torch.randn(9 * cout * ((cin + 63) // 64 * 64), device=dev) * 0.05).to(dt)
     rows = lib.dc_conv_stat_rows(C.byref(desc), N, H, W)
     res, outs = [], []
     for pf in (0, 1, 0, 1):
