@@ -279,6 +279,20 @@ int dc_bn_bwd_apply_fin(int dtype, long M, int C, long count, const void* dout, 
                         const float* save_invstd, const float* slab, int rows, float* dgamma, float* dbeta, void* dy, int lddy,
                         void* g_out, int ldg, const float* mscale, const float* mshift, void* stream);
 
+/* dc_bn_bwd_apply of a BatchNorm + dc_conv_dgrad + the weight gradient of the pointwise (1x1, stride 1) conv in front of it in ONE pass over
+ * (dout, y, x): dy = the BatchNorm's input gradient (relu 2: dout masked by y * mscale + mshift > 0; relu 0: no mask) is formed in registers,
+ * rounded to bf16 as dc_bn_bwd_apply stores it, and feeds both products from LDS; it is never written.  dx [M][Cin] = dy . W (wb: the packed
+ * data-gradient operand of dc_conv_pack_weights); wslab [rows][Cout][Cin] fp32 = one partial weight gradient per workgroup, rows =
+ * dc_pw_bn_bwd_rows(...) (0: shape not served -- bf16, Cout 128, Cin 64 or 128, at least 65 536 pixels: the entry flow's first block, whose 453 MB
+ * tensors make all three passes HBM-bound), summed by dc_fold_slabs (DC_FOLD_CONV, splits = rows, taps = 1).  dgamma / dbeta: the finished
+ * parameter gradients (dc_bn_bwd_finalize).  Replaces autograd's batch_norm_backward + conv2d backward of SeparableConv2d_same.pointwise
+ * (deeplab_xception.py:62-66, 84-101; train_hdf5_ddp.py:363). */
+int dc_pw_bn_bwd_rows(int dtype, int Cin, int Cout, long M);
+int dc_pw_bn_bwd(int dtype, long M, int Cin, int Cout, long count, const void* dout, int lddo, const void* y, int ldy, int relu,
+                 const float* gamma, const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta,
+                 const float* mscale, const float* mshift, const void* x, int ldx, const void* wb, void* dx, int lddx, float* wslab,
+                 void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Entry stem: Conv2d(16->32, k3, s2, p1) reading the caller's NCHW fp32 batch directly
  * (deeplab_xception.py:145,197).  Output NHWC `dtype`.  Also writes the BN partial-statistics slab.

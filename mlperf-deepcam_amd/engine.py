@@ -202,6 +202,8 @@ class Engine:
         # the last writer of that output's gradient (dc_dwconv_dgrad_wgrad_bnres) instead of a dc_bn_bwd_reduce pass over three tensors
         self.fuse_bn_res = os.environ.get("DC_FUSE_BN_RES", "1") != "0"
         self.fuse_bn_bwd_fin = os.environ.get("DC_FUSE_BN_BWD_FIN", "1") != "0"    # dc_bn_bwd_finalize inside dc_bn_bwd_apply for short slabs
+        # BatchNorm backward apply + pointwise data gradient + pointwise weight gradient of the entry flow's thin layers in one pass (dc_pw_bn_bwd)
+        self.fuse_pw_bn_bwd = os.environ.get("DC_FUSE_PW_BN_BWD", "1") != "0"
         # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
         # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 40.31 -> 40.10 (round 3; 1 / 2 / 3 / 4 layers:
         # 40.31 / 40.28 / 40.10 / 40.18) -- the fp32 split slabs (256 KiB per workgroup whatever the batch) are a third of a 728-channel
@@ -324,11 +326,14 @@ class Engine:
     # ------------------------------------------------------------------------------------------------ op builders
     def _conv(self, x: Act, wname: str, cout: int, k: int = 1, stride: int = 1, pad: int = 0, dil: int = 1,
               transposed: bool = False, out: Act = None, stats: bool = True, bias: str = None, name: str = None,
-              need_dx: bool = True, f32: bool = False, fwd_group: list = None, sole_consumer: bool = False):
+              need_dx: bool = True, f32: bool = False, fwd_group: list = None, sole_consumer: bool = False, bn_fuse: bool = False):
         """Dense conv (implicit GEMM).  Returns (y, slab, rows).  fwd_group: a list that collects (dilation, wf, y, slab) instead
         of this layer's own forward launch (the caller then launches the members together: _dilated_group_fwd).
         sole_consumer: x is a stored BatchNorm(+ReLU) output that feeds this conv and nothing else; its BatchNorm's backward sums
-        are then taken in this layer's data-gradient epilogue (dc_conv_dgrad_bnstats) instead of a pass of their own."""
+        are then taken in this layer's data-gradient epilogue (dc_conv_dgrad_bnstats) instead of a pass of their own.
+        bn_fuse: this is the pointwise conv of a separable conv (x, a depthwise output, has no other consumer) and y feeds one BatchNorm: where
+        the library serves the shape (dc_pw_bn_bwd_rows: the entry flow's first block), that BatchNorm's backward apply, this layer's data
+        gradient and its weight gradient are ONE pass over (dout, y, x) -- y's gradient is never stored (dc_pw_bn_bwd)."""
         lib = L.load()
         dt, tdtype = (L.DC_F32, torch.float32) if f32 else (self.dt, self.dtype)
         d = L.ConvDesc(dt, 3 if transposed else k, stride, pad, dil, 1 if transposed else 0, x.C, cout)
@@ -342,6 +347,12 @@ class Engine:
         wb = torch.empty(nwb.value, dtype=tdtype, device=self.device) if need_dx else None
         rows = lib.dc_conv_stat_rows(C.byref(d), x.N, x.H, x.W) if stats else 0
         slab = self._f32(2 * rows * cout) if stats else None
+        y.pw_fuse = None
+        if (bn_fuse and self.fuse_pw_bn_bwd and k == 1 and stride == 1 and not transposed and bias is None and not f32 and need_dx
+                and out is None and x.parent is None):
+            frows = lib.dc_pw_bn_bwd_rows(dt, x.C, cout, x.M)
+            if frows > 0:
+                y.pw_fuse = {"rows": frows, "taken": False}      # the BatchNorm's make_bwd (which runs first) takes it or leaves it
         N, H, W = x.N, x.H, x.W
         pw, gw = self.pptr(wname), self.gptr(wname)
         pb = self.pptr(bias) if bias else None
@@ -365,6 +376,24 @@ class Engine:
             self.fwd_eval.append(lambda: fwd(False))
 
         def make_bwd():
+            pwf = y.pw_fuse
+            if pwf is not None and pwf["taken"]:
+                # the BatchNorm behind this layer left its backward apply to this layer: one pass writes dx and this layer's weight-gradient rows,
+                # which stay in their slab until the next dense weight-gradient launch folds them (as the depthwise rows do); the BatchNorm's
+                # parameter gradients are read by that pass, so they are reported ready here, not by the BatchNorm's own step
+                mode = x.take_grad_mode()
+                assert mode == 0, f"{wname}: the fused backward pass writes the input gradient first"
+                dx, do = x.grad, pwf["do"]
+                frows = pwf["rows"]
+                fslab = self._f32(frows * cout * x.C)
+                ready = [wname] + pwf["names"]
+                self._fold_seq.append(("dw", L.FoldEntry(fslab.data_ptr(), gw.value, L.DC_FOLD_CONV, frows, 1, cout, x.C), wname, ready))
+
+                def bwd_fused():
+                    L.call("dc_pw_bn_bwd", dt, y.M, x.C, cout, y.M, do.ptr, do.ld, y.ptr, y.ld, pwf["relu"], pwf["gam"], L.dptr(pwf["mean"]),
+                           L.dptr(pwf["invstd"]), pwf["dgam"], pwf["dbet"], L.dptr(pwf["scale"]), L.dptr(pwf["shift"]), x.ptr, x.ld, L.dptr(wb),
+                           dx.ptr, dx.ld, L.dptr(fslab), self._st())
+                return bwd_fused, ready
             dy = y.grad
             mode = x.take_grad_mode() if need_dx else 0
             dx = x.grad if need_dx else None
@@ -619,7 +648,6 @@ class Engine:
             apply_by = getattr(lz, "apply_by", None) if lazy else None      # the consumer writes dy itself (the head, two passes)
             do = None if apply_by is not None else (lz.grad if lazy else o.grad)
             assert y.take_grad_mode() == 0, "a conv output feeds exactly one BatchNorm"
-            dy = y.grad
             g_out = None
             if residual is not None:
                 assert residual.take_grad_mode() == 0, f"{bname}: residual gradient must be first written here"
@@ -631,6 +659,12 @@ class Engine:
             mrelu = (2 if relu else 0) if from_y else relu_i
             optr = (lambda: None) if from_y else (lambda: o.ptr)
             old_ = 0 if from_y else o.ld
+            # the producing pointwise conv applies this BatchNorm's backward itself, in one pass with its own two gradients (_conv: bn_fuse)
+            pwf = getattr(y, "pw_fuse", None) if (lazy and apply_by is None and residual is None and mrelu in (0, 2)) else None
+            if pwf is not None:
+                pwf.update(taken=True, do=do, gam=gam, mean=mean, invstd=invstd, dgam=dgam, dbet=dbet, scale=scale, shift=shift, relu=mrelu,
+                           names=[bname + ".weight", bname + ".bias"])
+            dy = None if pwf is not None else y.grad
 
             # set by the consumer (a depthwise conv for a lazy output, a dense conv / the head for a stored one): its make_bwd ran first
             fused = lz.fused_bwd if lazy else getattr(o, "fused_bwd", None)
@@ -647,7 +681,7 @@ class Engine:
             # kernel sums it itself (dc_bn_bwd_apply_fin, same bits): one launch and one dependent boundary less per BatchNorm of the middle
             # flow.  Every 32-row block repeats the sum for its channels, so it pays only while the grid is small: local batch 2 12.47 ->
             # 12.38 ms, batch 4 19.80 -> 19.83, batch 8 33.47 -> 33.88 (2 592 blocks re-reading 86 KB each): on below 8 192 pixels
-            fin_in_apply = (self.fuse_bn_bwd_fin and apply_by is None and rrows <= lib.dc_bn_bwd_apply_fin_max_rows() and M <= 8192
+            fin_in_apply = (self.fuse_bn_bwd_fin and apply_by is None and pwf is None and rrows <= lib.dc_bn_bwd_apply_fin_max_rows() and M <= 8192
                             and os.environ.get("DC_DEBUG_SKIP_BN_FINALIZE", "") not in ("bwd", "both"))     # (the timing switch is read later)
 
             def bwd():
@@ -661,13 +695,15 @@ class Engine:
                     return
                 if self._debug_skip_finalize not in ("bwd", "both"):
                     L.call("dc_bn_bwd_finalize", Cc, L.dptr(rslab), rrows, dgam, dbet, self._st())
+                if pwf is not None:
+                    return
                 if apply_by is not None:
                     apply_by(gam, dgam, dbet, dy)
                     return
                 L.call("dc_bn_bwd_apply", bdt, M, Cc, M, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, gam, L.dptr(mean),
                        L.dptr(invstd), dgam, dbet, dy.ptr, dy.ld, g_out.ptr if g_out is not None else None,
                        g_out.ld if g_out is not None else 0, L.dptr(scale), L.dptr(shift), self._st())
-            return bwd, [bname + ".weight", bname + ".bias"]
+            return bwd, ([] if pwf is not None else [bname + ".weight", bname + ".bias"])
 
         self.bwd.append(make_bwd)
         return lz if lazy else o
@@ -676,7 +712,8 @@ class Engine:
         """depthwise 3x3 -> pointwise 1x1 [-> BN (+residual) (+ReLU)].  lazy: the BN output feeds only the next
         depthwise conv and is fused into it instead of being stored."""
         d = self._dw(x, s.prefix + ".conv1.weight", s.stride, s.dil, s.prefix + ".dw")
-        y, slab, rows = self._conv(d, s.prefix + ".pointwise.weight", s.cout, stats=bool(s.bn), name=s.prefix + ".pw")
+        y, slab, rows = self._conv(d, s.prefix + ".pointwise.weight", s.cout, stats=bool(s.bn), name=s.prefix + ".pw",
+                                   bn_fuse=bool(s.bn) and residual is None)
         if not s.bn:
             return y
         relu = s.relu_after if relu_override is None else relu_override

@@ -23,7 +23,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 // ROWB: bytes of K per row per stage.  A "stage" is 32 KiB (ROWB 64) or 64 KiB (ROWB 128) of operands; the ring holds 128 KiB.
 // DMA: 0 none, 1 LDS-DMA (global_load_lds, 64-bit per-lane address), 2 global_load_dwordx4 + ds_write_b128, 3 LDS-DMA as
 // buffer_load ... offen lds (resource descriptor + 32-bit per-lane offset + scalar K offset).  NMFMA: MFMAs per wave per 32-deep K step (32 = the real kernel).
-template <int ROWB, int DMA, int NMFMA, int READS>
+template <int ROWB, int DMA, int NMFMA, int READS, int WL = 0>
 __global__ __launch_bounds__(512) void fill_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ w, int M, int C, int ld, int ntn,
                                                    float* __restrict__ out, unsigned long long* __restrict__ cyc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -48,7 +48,8 @@ __global__ __launch_bounds__(512) void fill_kernel(const __bf16* __restrict__ x,
     if (i < IPW / 2) {
       int ch = nt * 256 + r;
       if (ch >= C) ch = C - 1;
-      src[i] = w + (size_t)ch * ld + lslot * 8;
+      // WL = 1: weights stage-major, [K / KPS][C][KPS]: the rows of one stage are contiguous (a wave-instruction reads 1 KiB in one piece)
+      src[i] = WL ? w + (size_t)ch * KPS + lslot * 8 : w + (size_t)ch * ld + lslot * 8;
       voff[i] = (unsigned)(((size_t)ch * ld + lslot * 8) * 2);
     } else {
       int m = mt * 256 + r;
@@ -71,13 +72,15 @@ __global__ __launch_bounds__(512) void fill_kernel(const __bf16* __restrict__ x,
     fa[i] = (__bf16)(0.001f * (lane + i));
     fb[i] = (__bf16)(0.002f * (lane - i));
   }
+  const int steps_ = (C + KPS - 1) / KPS;
   auto issue = [&](int s, int i) {
     if constexpr (DMA == 0) return;
     int k = s * KPS;
     if (k + KPS > ld) k = ld - KPS;                // stay inside the row (timing only)
     char* dst = smem + (s % NSTAGE) * STAGE + (i * 8 + wave) * 1024;
     if constexpr (DMA == 1) {
-      __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + k), (lds_ptr)dst, 16, 0, 0);
+      const size_t adv = (WL && i < IPW / 2) ? (size_t)(s < steps_ ? s : steps_ - 1) * C * KPS : (size_t)k;
+      __builtin_amdgcn_global_load_lds((gas_ptr)(src[i] + adv), (lds_ptr)dst, 16, 0, 0);
     } else if constexpr (DMA == 3) {
 #if defined(__HIP_DEVICE_COMPILE__)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(i < IPW / 2 ? rw : rx, (lds_ptr)dst, 16, voff[i], k * 2, 0, 0);
@@ -132,11 +135,11 @@ __global__ __launch_bounds__(512) void fill_kernel(const __bf16* __restrict__ x,
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int ROWB, int DMA, int NMFMA, int READS>
+template <int ROWB, int DMA, int NMFMA, int READS, int WL = 0>
 void run(const char* name, const __bf16* x, const __bf16* w, int M, int C, int ld, float* out, unsigned long long* cyc, int nwg_override) {
   const int ntn = (C + 255) / 256, ntm = (M + 255) / 256;
   const int nwg = nwg_override > 0 ? nwg_override : ntn * ntm;
-  auto k = fill_kernel<ROWB, DMA, NMFMA, READS>;
+  auto k = fill_kernel<ROWB, DMA, NMFMA, READS, WL>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 256));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -338,6 +341,10 @@ int main(int argc, char** argv) {
     run<128, 3, 32, 0>("buffer LDS-DMA + MFMA, 128-byte rows", x, w, M, C, ld, out, cyc, nwg);
     run<64, 1, 32, 0>("LDS-DMA + MFMA, 64-byte rows", x, w, M, C, ld, out, cyc, nwg);
     run<128, 1, 32, 0>("LDS-DMA + MFMA, 128-byte rows", x, w, M, C, ld, out, cyc, nwg);
+    run<128, 1, 0, 0, 1>("LDS-DMA only, 128-byte rows, weights stage-major", x, w, M, C, ld, out, cyc, nwg);
+    run<128, 1, 32, 0, 1>("LDS-DMA + MFMA, 128-byte rows, weights stage-major", x, w, M, C, ld, out, cyc, nwg);
+    run<64, 1, 0, 0, 1>("LDS-DMA only, 64-byte rows, weights stage-major", x, w, M, C, ld, out, cyc, nwg);
+    run<64, 1, 32, 0, 1>("LDS-DMA + MFMA, 64-byte rows, weights stage-major", x, w, M, C, ld, out, cyc, nwg);
     run<64, 1, 32, 6>("LDS-DMA + MFMA + 12 ds_read, 64-byte rows", x, w, M, C, ld, out, cyc, nwg);
     run<128, 1, 32, 6>("LDS-DMA + MFMA + 12 ds_read, 128-byte rows", x, w, M, C, ld, out, cyc, nwg);
   }

@@ -1718,3 +1718,55 @@ def test_lamb_is_bit_reproducible():
         assert torch.isfinite(p).all()
         outs.append(p)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+PW_BN_BWD_CASES = [("b1_sep2", 128, 2, 192, 192, 2), ("b1_sep1", 64, 2, 192, 192, 2), ("ragged_nomask", 128, 1, 257, 257, 0),
+                   ("ragged64", 64, 1, 257, 259, 2)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cin,N,H,W,relu", PW_BN_BWD_CASES, ids=[c[0] for c in PW_BN_BWD_CASES])
+def test_pointwise_bn_backward_in_one_pass(name, cin, N, H, W, relu):
+    """dc_pw_bn_bwd (BatchNorm backward apply + pointwise data gradient + pointwise weight gradient over ONE read of dout, y, x; dy never stored)
+    against the three passes it replaces: dx bit for bit (same dy bits, same MFMA K order), the weight gradient against fp64 sums of the stored dy."""
+    dtype, dt, cout = torch.bfloat16, L.DC_BF16, 128
+    lib = L.load()
+    M = N * H * W
+    rows = lib.dc_pw_bn_bwd_rows(dt, cin, cout, M)
+    assert rows > 0 and lib.dc_pw_bn_bwd_rows(dt, 96, cout, M) == 0 and lib.dc_pw_bn_bwd_rows(dt, cin, cout, 1000) == 0
+    g = torch.Generator().manual_seed(5)
+    ydev = (torch.randn(N, H, W, cout + 8, generator=g) * 1.5).to(dtype).to(dev())          # pad channels hold finite garbage
+    dodev = (torch.randn(N, H, W, cout, generator=g) * 0.7).to(dtype).to(dev())
+    xdev = torch.randn(N, H, W, cin + 16, generator=g).to(dtype).to(dev())
+    yv, xv = ydev[..., :cout], xdev[..., 8:8 + cin]
+    w = rnd(cout, cin, 1, 1, seed=6, scale=0.1).to(dev())
+    d = L.ConvDesc(dt, 1, 1, 0, 1, 0, cin, cout)
+    nwf, nwb = C.c_size_t(), C.c_size_t()
+    L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
+    wf, wb = torch.zeros(nwf.value, dtype=dtype, device=dev()), torch.zeros(nwb.value, dtype=dtype, device=dev())
+    L.call("dc_conv_pack_weights", C.byref(d), vptr(w), vptr(wf), vptr(wb), S())
+    gamma = (rnd(cout, seed=7).abs() + 0.4).to(dev())
+    mean, invstd = rnd(cout, seed=8, scale=0.2).to(dev()), (torch.rand(cout, generator=g) + 0.5).to(dev())
+    sc, sh = (gamma * invstd).contiguous(), rnd(cout, seed=9, scale=0.3).to(dev())
+    dg, db = (rnd(cout, seed=10) * M * 0.01).to(dev()), (rnd(cout, seed=11) * M * 0.01).to(dev())
+    # the three passes
+    _, dyv = empty_nhwc(N, H, W, cout, dtype)
+    L.call("dc_bn_bwd_apply", dt, M, cout, M, vptr(dodev), cout, vptr(yv), cout + 8, None, 0, relu, vptr(gamma), vptr(mean), vptr(invstd), vptr(dg),
+           vptr(db), vptr(dyv), cout, None, 0, vptr(sc), vptr(sh), S())
+    _, dx_ref = empty_nhwc(N, H, W, cin, dtype)
+    L.call("dc_conv_dgrad", C.byref(d), N, H, W, vptr(dyv), cout, vptr(wb), vptr(dx_ref), cin, 0, S())
+    torch.cuda.synchronize()
+    gw_ref = (dyv.reshape(M, cout).double().t() @ xv.reshape(M, cin).double())
+    # one pass
+    dxb, dx = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8)
+    slab = torch.full((rows, cout, cin), float("nan"), device=dev())
+    gw = torch.full((cout, cin, 1, 1), float("nan"), device=dev())
+    L.call("dc_pw_bn_bwd", dt, M, cin, cout, M, vptr(dodev), cout, vptr(yv), cout + 8, relu, vptr(gamma), vptr(mean), vptr(invstd), vptr(dg), vptr(db),
+           vptr(sc), vptr(sh), vptr(xv), cin + 16, vptr(wb), vptr(dx), cin + 8, vptr(slab), S())
+    ents = [L.FoldEntry(slab.data_ptr(), gw.data_ptr(), L.DC_FOLD_CONV, rows, 1, cout, cin)]
+    L.call("dc_fold_slabs", (L.FoldEntry * 1)(*ents), 1, S())
+    torch.cuda.synchronize()
+    assert torch.isnan(dxb[..., cin:].float()).all()                          # pad channels untouched
+    assert torch.equal(dx.float(), dx_ref.float()), name
+    err = (gw.reshape(cout, cin).double() - gw_ref).abs().max().item()
+    assert err <= 2e-5 * gw_ref.abs().max().item() + 1e-3, (name, err, gw_ref.abs().max().item())
