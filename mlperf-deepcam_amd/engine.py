@@ -660,7 +660,7 @@ class Engine:
             optr = (lambda: None) if from_y else (lambda: o.ptr)
             old_ = 0 if from_y else o.ld
             # the producing pointwise conv applies this BatchNorm's backward itself, in one pass with its own two gradients (_conv: bn_fuse)
-            pwf = getattr(y, "pw_fuse", None) if (lazy and apply_by is None and residual is None and mrelu in (0, 2)) else None
+            pwf = getattr(y, "pw_fuse", None) if (apply_by is None and residual is None and mrelu in (0, 2)) else None
             if pwf is not None:
                 pwf.update(taken=True, do=do, gam=gam, mean=mean, invstd=invstd, dgam=dgam, dbet=dbet, scale=scale, shift=shift, relu=mrelu,
                            names=[bname + ".weight", bname + ".bias"])
