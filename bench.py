@@ -79,7 +79,9 @@ class KernelTimer:
               (dc_conv_fwd + dc_conv_dgrad: dense conv forward and data gradient; the library's planner picks the tile shape per layer)
        wgrad  dc::wgrad384_kernel / dc::wgrad256_kernel / dc::wgrad_dma_kernel<T>  (dc_conv_wgrad_partial: dense conv weight gradient, split-K
               partial sums; a grouped call is ONE launch of the kernel for up to sixteen layers and counts as one) + dc::fold_kernel (dc_fold_slabs: the
-              fixed-order sum of those slabs, which also folds the depthwise layers' rows; its time counts, it adds no launch or flop)"""
+              fixed-order sum of those slabs, which also folds the depthwise layers' rows; its time counts, it adds no launch or flop)
+       Not in either family (neither its time nor its flop): dc::pw_bn_bwd_kernel (dc_pw_bn_bwd), the HBM-bound pass that does the BatchNorm backward
+       apply, the data gradient and the weight gradient of the entry flow's two thin pointwise layers at once."""
 
     FAMILY = {"dc_conv_fwd": "igemm", "dc_conv_dgrad": "igemm", "dc_conv_dgrad_bnstats": "igemm", "dc_conv_wgrad": "wgrad",
               "dc_conv_wgrad_group": "wgrad", "dc_conv_wgrad_partial": "wgrad"}
