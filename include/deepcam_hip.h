@@ -93,9 +93,11 @@ int dc_conv_out_hw(const dc_conv_desc* d, int Hi, int Wi, int* Ho, int* Wo);
 
 /* Pack the fp32 master weight (PyTorch layout: [cout][cin][k][k], or [cin][cout][k][k] when transposed)
  * into the two GEMM operand layouts, both in `dtype`:  wf[tap][cout][cin'] (forward) and
- * wb[tap][cin][cout'] (data gradient), where the K extent of a row (cin', cout') is rounded up to 32 elements so that
- * every row starts on a 64-byte boundary (worth 15-20 % on the 728-channel GEMMs).  dc_conv_packed_elems gives the
- * element counts to allocate.  Either output may be NULL. */
+ * wb[tap][cin][cout'] (data gradient), where the K extent of a row (cin', cout') is rounded up to 64 elements (32 below 64
+ * channels) so that every bf16 row starts on a 128-byte boundary: a 128-byte K piece of a row is then ONE L2 line for the
+ * LDS-DMA loaders (728 -> 768; 64-byte boundaries -- 736 -- filled 18 % slower, profiles/r05_fill_bench_align.txt).
+ * dc_conv_packed_elems gives the element counts to allocate (and thereby the strides: wf_elems / (taps * cout)).  Either
+ * output may be NULL. */
 int dc_conv_packed_elems(const dc_conv_desc* d, size_t* wf_elems, size_t* wb_elems);
 int dc_conv_pack_weights(const dc_conv_desc* d, const float* master, void* wf, void* wb, void* stream);
 
