@@ -126,6 +126,15 @@ int dc_conv_fwd_f32out(const dc_conv_desc* d, int N, int Hi, int Wi, const void*
  * bit-identical to `count` dc_conv_fwd calls (which is what runs when the fused kernel does not serve the dtype). */
 int dc_conv_fwd_dilated_group(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const int* dils, const void* x, int ldx,
                               const void* const* wfs, void* const* ys, int ldy, float* const* stat_slabs, void* stream);
+/* The same launch with a caller-owned workspace: where dc_conv_fwd_dilated_group_workspace(...) > 0 (the launch would leave more than half of
+ * the chip idle under a long K loop -- local batch 2: 81 tiles of 576 K steps) and `ws` holds that many bytes, every tile's K loop is split over
+ * several workgroups (fp32 partial tiles in ws) and a second kernel sums the splits in a fixed order, stores the outputs and takes the
+ * BatchNorm sums: another order of the K sum than the unsplit launch (not its bits), deterministic.  SURVEY section 2.3 K3: "needs split-K
+ * to fill 256 CUs".  ws NULL or too small: the unsplit launch. */
+size_t dc_conv_fwd_dilated_group_workspace(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const int* dils);
+int dc_conv_fwd_dilated_group_ws(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const int* dils, const void* x, int ldx,
+                                 const void* const* wfs, void* const* ys, int ldy, float* const* stat_slabs, void* ws, size_t ws_bytes,
+                                 void* stream);
 
 /* dx = conv_backward_data(dy, w).  Hi, Wi are the FORWARD input extents (= extents of dx). */
 int dc_conv_dgrad(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb,

@@ -55,6 +55,11 @@ struct IgemmParams {
   const void* gw[MAXGROUP - 1];
   void* gy[MAXGROUP - 1];
   float* gslab[MAXGROUP - 1];
+  // 256-tile kernel, split-K launch (few pixels, long K: the atrous ASPP branches at local batch 2 are 81 tiles of 576 K steps): `ksplit` > 1
+  // workgroups share a tile, each walks a contiguous range of the K loop's channel-chunk groups and leaves its fp32 accumulators in
+  // kslab[split][tile][256 px][256 ch]; igemm256_splitk_fold sums the splits in a fixed order, stores y and takes the BatchNorm sums.
+  int ksplit;
+  float* kslab;
 };
 // OUT32: the epilogue stores fp32 regardless of T (used by the classifier head, whose logits must not be rounded to bf16)
 
@@ -69,6 +74,10 @@ int launch_igemm256p(const IgemmParams& p, int workgroups, hipStream_t st);
 inline long igemm256_tiles(const IgemmParams& p) {
   return (long)((p.g.Cout + 255) / 256) * ((p.M - p.m_beg + 255) / 256) * p.g.os * p.g.os * (p.ngroup > 1 ? p.ngroup : 1);
 }
+// split-K plan of a 256-tile launch: splits (1 = none) and the bytes of the partial-sum slab; launch + fold of a planned launch
+int igemm256_splitk_plan(const IgemmParams& p, size_t* slab_bytes);
+int launch_igemm256_splitk(const IgemmParams& p, int splits, void* ws, hipStream_t st);
+void igemm256_set_splitk(int v);
 
 // igemm384.hip: pointwise layers on a (32*npb) x 384 tile, one wave per SIMD (npb = 8 or 4 pixel blocks per wave)
 bool pw384_eligible(const IgemmParams& p);

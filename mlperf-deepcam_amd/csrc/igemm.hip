@@ -601,6 +601,7 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   p.phase_fast = 0;
   p.zero_page = nullptr;
   p.ngroup = 0;
+  p.ksplit = 0; p.kslab = nullptr;
   p.bst = BnBwdEpi{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
   if (bst != nullptr) {
     DC_REQUIRE(slab != nullptr && !accumulate && !out32 && bias == nullptr, "dc_conv_dgrad_bnstats: needs a slab, no bias, no accumulate");
@@ -888,6 +889,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm256p_min") == 0) { g_igemm256p_min = value; return 0; }
   if (name != nullptr && strcmp(name, "pw384_k64") == 0) { g_pw384_k64 = value; return 0; }
   if (name != nullptr && strcmp(name, "pw192") == 0) { g_pw192 = value; return 0; }
+  if (name != nullptr && strcmp(name, "igemm256_splitk") == 0) { igemm256_set_splitk(value); return 0; }
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "thin_tile") == 0) { thin_set_tile(value); return 0; }
   if (name != nullptr && strcmp(name, "igemm256_rel") == 0) { g_rel256 = value; return 0; }
@@ -960,15 +962,21 @@ extern "C" int dc_conv_fwd(const dc_conv_desc* d, int N, int Hi, int Wi, const v
 // atrous branches of the ASPP head read the same encoder output and are 108 tiles each at local batch 8 (27 at batch 2) on 256
 // CUs; together they fill the chip.  Per output element the arithmetic is that of dc_conv_fwd (same tile, same K order): the
 // results are bit-identical to `count` separate calls, which is also the fallback when the kernel does not serve the layer.
-extern "C" int dc_conv_fwd_dilated_group(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const int* dils, const void* x,
-                                         int ldx, const void* const* wfs, void* const* ys, int ldy, float* const* stat_slabs,
-                                         void* stream) {
-  DC_REQUIRE(d != nullptr && dils != nullptr && wfs != nullptr && ys != nullptr, "dc_conv_fwd_dilated_group: null argument");
+// With a workspace of dc_conv_fwd_dilated_group_workspace(...) bytes (> 0 where the launch would leave more than half of the chip idle under a
+// long K loop: local batch 2, 81 tiles of 576 K steps) the launch is cut along K: `splits` workgroups per tile leave fp32 partial tiles in
+// the workspace and a second kernel sums them in the order of the splits, stores the outputs and takes the BatchNorm sums.  The results are
+// then those of another order of the K sum (not the bits of the unsplit launch).
+static int dilated_group_impl(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const int* dils, const void* x, int ldx,
+                              const void* const* wfs, void* const* ys, int ldy, float* const* stat_slabs, void* ws, size_t ws_bytes,
+                              size_t* want_bytes, void* stream) {
+  DC_REQUIRE(d != nullptr && dils != nullptr && (want_bytes != nullptr || (wfs != nullptr && ys != nullptr)), "dc_conv_fwd_dilated_group: null argument");
   DC_REQUIRE(count >= 1 && count <= IgemmParams::MAXGROUP, "dc_conv_fwd_dilated_group: count must be 1..4");
   DC_REQUIRE(!d->transposed && d->k == 3 && d->stride == 1, "dc_conv_fwd_dilated_group: 3x3, stride 1 convolutions only");
-  for (int b = 0; b < count; ++b) DC_REQUIRE(dils[b] >= 1 && wfs[b] != nullptr && ys[b] != nullptr, "dc_conv_fwd_dilated_group: bad member");
+  if (want_bytes != nullptr) *want_bytes = 0;
+  for (int b = 0; b < count; ++b) DC_REQUIRE(dils[b] >= 1 && (want_bytes != nullptr || (wfs[b] != nullptr && ys[b] != nullptr)), "dc_conv_fwd_dilated_group: bad member");
   const bool fused = count > 1 && d->dtype == DC_BF16 && g_igemm256 != 0;
   if (!fused) {
+    if (want_bytes != nullptr) return 0;
     for (int b = 0; b < count; ++b) {
       dc_conv_desc db = *d;
       db.dil = db.pad = dils[b];
@@ -980,14 +988,17 @@ extern "C" int dc_conv_fwd_dilated_group(const dc_conv_desc* d, int N, int Hi, i
   du.dil = du.pad = 1;                      // unit-dilation tap table; the kernel scales the offsets per member
   IgemmParams p;
   if (!build_geom(du, Hi, Wi, kFwd, &p.g)) return dc_fail("dc_conv_fwd_dilated_group: unsupported geometry", __FILE__, __LINE__);
-  if (int e = check_view(x, ldx, p.g.Cin, d->dtype, "dc_conv_fwd_dilated_group input")) return e;
-  for (int b = 0; b < count; ++b) {
-    if (int e = check_view(ys[b], ldy, p.g.Cout, d->dtype, "dc_conv_fwd_dilated_group output")) return e;
-    DC_REQUIRE(((uintptr_t)wfs[b] & 15) == 0, "dc_conv_fwd_dilated_group: weights unaligned");
+  if (want_bytes == nullptr) {
+    if (int e = check_view(x, ldx, p.g.Cin, d->dtype, "dc_conv_fwd_dilated_group input")) return e;
+    for (int b = 0; b < count; ++b) {
+      if (int e = check_view(ys[b], ldy, p.g.Cout, d->dtype, "dc_conv_fwd_dilated_group output")) return e;
+      DC_REQUIRE(((uintptr_t)wfs[b] & 15) == 0, "dc_conv_fwd_dilated_group: weights unaligned");
+    }
   }
   const long M = (long)N * p.g.Qh * p.g.Qw;
   DC_REQUIRE(N > 0 && M < (1L << 31) - BM, "dc_conv_fwd_dilated_group: bad pixel count");
-  p.x = x; p.w = wfs[0]; p.y = ys[0]; p.bias = nullptr; p.slab = stat_slabs ? stat_slabs[0] : nullptr;
+  p.x = x; p.w = wfs ? wfs[0] : nullptr; p.y = ys ? ys[0] : nullptr; p.bias = nullptr; p.slab = stat_slabs ? stat_slabs[0] : nullptr;
+  p.ksplit = 0; p.kslab = nullptr;
   p.bst = BnBwdEpi{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
   p.N = N; p.ldx = ldx; p.ldy = ldy;
   p.ldw = weight_ld(p.g.Cin);
@@ -995,6 +1006,12 @@ extern "C" int dc_conv_fwd_dilated_group(const dc_conv_desc* d, int N, int Hi, i
   p.mtiles = cdiv(M, BM);
   p.accumulate = 0;
   p.ngroup = count;
+  size_t need = 0;
+  const int splits = igemm256_splitk_plan(p, &need);
+  if (want_bytes != nullptr) {
+    *want_bytes = need;
+    return 0;
+  }
   for (int b = 0; b < IgemmParams::MAXGROUP; ++b) p.gdil[b] = b < count ? dils[b] : 1;
   for (int b = 1; b < IgemmParams::MAXGROUP; ++b) {
     p.gw[b - 1] = b < count ? wfs[b] : nullptr;
@@ -1003,7 +1020,29 @@ extern "C" int dc_conv_fwd_dilated_group(const dc_conv_desc* d, int N, int Hi, i
   }
   if (stat_slabs)
     for (int b = 0; b < count; ++b) DC_REQUIRE(stat_slabs[b] != nullptr, "dc_conv_fwd_dilated_group: statistics for all members or none");
+  if (splits > 1 && ws != nullptr && ws_bytes >= need) {
+    DC_REQUIRE(((uintptr_t)ws & 15) == 0, "dc_conv_fwd_dilated_group_ws: workspace unaligned");
+    return launch_igemm256_splitk(p, splits, ws, (hipStream_t)stream);
+  }
   return launch_igemm256(p, (hipStream_t)stream);
+}
+
+extern "C" int dc_conv_fwd_dilated_group(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const int* dils, const void* x,
+                                         int ldx, const void* const* wfs, void* const* ys, int ldy, float* const* stat_slabs,
+                                         void* stream) {
+  return dilated_group_impl(d, N, Hi, Wi, count, dils, x, ldx, wfs, ys, ldy, stat_slabs, nullptr, 0, nullptr, stream);
+}
+
+extern "C" size_t dc_conv_fwd_dilated_group_workspace(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const int* dils) {
+  size_t need = 0;
+  if (dilated_group_impl(d, N, Hi, Wi, count, dils, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, &need, nullptr) != 0) return 0;
+  return need;
+}
+
+extern "C" int dc_conv_fwd_dilated_group_ws(const dc_conv_desc* d, int N, int Hi, int Wi, int count, const int* dils, const void* x,
+                                            int ldx, const void* const* wfs, void* const* ys, int ldy, float* const* stat_slabs,
+                                            void* ws, size_t ws_bytes, void* stream) {
+  return dilated_group_impl(d, N, Hi, Wi, count, dils, x, ldx, wfs, ys, ldy, stat_slabs, ws, ws_bytes, nullptr, stream);
 }
 
 extern "C" int dc_conv_fwd_f32out(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,

@@ -82,7 +82,13 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
   const int mt256 = (p.M - p.m_beg + TM - 1) / TM;
   const int nwg = gridDim.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + xslot;
+  int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + xslot;
+  // split-K launch: the splits of the tile grid are the slowest index (neighbours keep sharing their operand rows as without splits)
+  const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
+  const int tiles_per_split = nwg / nsplit;
+  const int split = tile / tiles_per_split;
+  tile -= split * tiles_per_split;
+  const int tile_lin = tile;
   const int ntile_n = tile % ntn;
   int rest = tile / ntn;
   // grouped launch: the members of one pixel tile are neighbours in the tile order (they read the same input rows through one
@@ -120,8 +126,13 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
     s_tap[3 * tid + 2] = tp.widx;
   }
   __syncthreads();
-  const int kchunks = (g.Cin + BK - 1) / BK;
-  const int steps = ntap * kchunks;
+  const int kchunks_all = (g.Cin + BK - 1) / BK;
+  // split-K: this workgroup's share of the channel-chunk groups (KG chunks each; the K loop's outermost level)
+  constexpr int KG = 4;
+  const int ngk = (kchunks_all + KG - 1) / KG;
+  const int kfirst = nsplit > 1 ? (ngk * split / nsplit) * KG : 0;
+  const int kchunks = nsplit > 1 ? min(kchunks_all, (ngk * (split + 1) / nsplit) * KG) : kchunks_all;      // END chunk of this workgroup's range
+  const int steps = ntap * (kchunks - kfirst);
   if (steps == 0 && p.accumulate) return;   // a phase without taps contributes zeros
 
   // ---- per-thread DMA bookkeeping: 2 rows of each operand (instruction j of wave w fills rows (8j + w)*16 .. +15) -------
@@ -197,15 +208,14 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
   const int fr = lane & 15, fg = lane >> 4;
 
   // ---- prologue: stages 0..2 in flight, stage 0 landed ---------------------------------------------------------------
-  int itap = 0, ikc = 0;   // (tap, K chunk) of the next stage to issue
+  int itap = 0, ikc = kfirst;   // (tap, K chunk) of the next stage to issue
   // K order: groups of KG channel chunks OUTER, taps in the middle, the group's chunks inner.  With the taps outermost, a workgroup
   // swept its 256 pixels x ALL channels once per tap; the CUs of an XCD together pull more than its 4 MiB L2 through per sweep, so
   // each of the 9 taps of a 3 x 3 layer fetched the (shifted) input again from the fabric: 3.5 x the tensor on the 192 x 288 decoder
   // convolutions, 7 x on the atrous ASPP ones (FETCH_SIZE per launch, scripts/fetch_by_grid.py).  Taps innermost (every step another
   // tap) brings that down to 1.0-1.3 x but recomputes the per-tap row pointers and bounds every step: 9-24 % slower.  Groups of four
   // chunks (256 bytes per pixel; ~2.6 MB per XCD and tap sweep) keep the nine sweeps of a group in L2 and change tap every 4th step.
-  constexpr int KG = 4;
-  int kbeg = 0, kend = kchunks < KG ? kchunks : KG;
+  int kbeg = kfirst, kend = kchunks < kfirst + KG ? kchunks : kfirst + KG;
   auto advance = [&]() {
     if (++ikc == kend) {
       ikc = kbeg;
@@ -328,6 +338,22 @@ __global__ __launch_bounds__(512) void igemm256_kernel(const IgemmParams p) {
 #endif
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the zero-page fills of the last three slots
   __builtin_amdgcn_s_barrier();
+
+  // ---- split-K: the fp32 partial tile goes to this split's slab as it sits in the accumulators (64 contiguous bytes per pixel and
+  // instruction); igemm256_splitk_fold_kernel does what the epilogue below does for an unsplit launch
+  if (nsplit > 1) {
+    float* part = p.kslab + ((size_t)split * tiles_per_split + tile_lin) * (TM * TN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int chl = wc * 64 + i * 16 + fg * 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int prow = grp * 128 + j * 16 + fr;
+        *reinterpret_cast<f32x4*>(part + prow * TN + chl) = acc[i][j];
+      }
+    }
+    return;
+  }
 
   // ---- epilogue ------------------------------------------------------------------------------------
   char* ct = smem;
@@ -490,6 +516,91 @@ static int g_phase_fast = 1;     // tile order of multi-phase (transposed / stri
 void igemm256_set_phase_fast(int v) { g_phase_fast = v ? 1 : 0; }
 int igemm256_phase_fast_enabled() { return g_phase_fast; }
 
+
+// Sum of the split-K partial tiles of one 128-pixel half of one tile, in the order of the splits: y (bf16) and the BatchNorm partial sums of
+// the STORED values, one slab row per half as the kernel's own epilogue leaves them.  256 threads = 64 channel groups of 4 x 4 row lanes.
+struct SplitKFoldArgs {
+  const float* kslab;
+  int nsplit, tiles_per_split, ntn, ngroup, mt256, mtiles, M, Cout, ldy;
+  void* y[IgemmParams::MAXGROUP];
+  float* slab[IgemmParams::MAXGROUP];
+};
+
+__global__ __launch_bounds__(256) void igemm256_splitk_fold_kernel(const SplitKFoldArgs a) {
+  __shared__ float red[2][4][TN];
+  const int half = blockIdx.x & 1;
+  const int tile_lin = blockIdx.x >> 1;
+  const int ntile_n = tile_lin % a.ntn;
+  int rest = tile_lin / a.ntn;
+  const int member = rest % a.ngroup;
+  const int mtile = rest / a.ngroup;
+  bf16* yg = nullptr;
+  float* sl = nullptr;
+#pragma unroll
+  for (int b = 0; b < IgemmParams::MAXGROUP; ++b)
+    if (member == b) {
+      yg = reinterpret_cast<bf16*>(a.y[b]);
+      sl = a.slab[b];
+    }
+  const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int ch = ntile_n * TN + cg * 4;
+  const bool chok = ch < a.Cout;                      // Cout % 8 == 0: all four channels or none
+  const size_t tstride = (size_t)a.tiles_per_split * (TM * TN);
+  const float* base = a.kslab + (size_t)tile_lin * (TM * TN) + (size_t)(half * 128) * TN + cg * 4;
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = rl; r < 128; r += 4) {
+    const int m = mtile * TM + half * 128 + r;
+    if (m >= a.M || !chok) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)r * TN);
+    for (int s = 1; s < a.nsplit; ++s) v += *reinterpret_cast<const f32x4*>(base + s * tstride + (size_t)r * TN);
+    uint2 o;
+    o.x = pack2_bf16(v[0], v[1]);
+    o.y = pack2_bf16(v[2], v[3]);
+    *reinterpret_cast<uint2*>(yg + (size_t)m * a.ldy + ch) = o;
+    if (sl != nullptr) {
+      const float f[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16), __uint_as_float(o.y & 0xffff0000u)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ssum[e] += f[e];
+        ssq[e] = fmaf(f[e], f[e], ssq[e]);
+      }
+    }
+  }
+  if (sl == nullptr) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[0][rl][cg * 4 + e] = ssum[e];
+    red[1][rl][cg * 4 + e] = ssq[e];
+  }
+  __syncthreads();
+  const int mt128 = mtile * 2 + half;
+  for (int i = threadIdx.x; i < 2 * TN; i += 256) {
+    const int c = i % TN, which = i / TN;
+    if (ntile_n * TN + c < a.Cout && mt128 < a.mtiles)
+      sl[((size_t)which * a.mtiles + mt128) * a.Cout + ntile_n * TN + c] = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
+  }
+}
+
+static int g_splitk = 1;         // tuning switch "igemm256_splitk": 0 = never split the K loop of a 256-tile launch
+void igemm256_set_splitk(int v) { g_splitk = v; }
+
+// A launch that leaves more than half of the chip idle and has a long K loop is cut along K: as many splits as fit one round, at least two
+// channel-chunk groups (2 x 4 chunks x taps K steps) each, at most eight.  Plain stride-1 launches only (no sub-pixel phases, no bias, no
+// accumulation, no BatchNorm-backward epilogue: the fold kernel does the plain epilogue).
+int igemm256_splitk_plan(const IgemmParams& p, size_t* slab_bytes) {
+  if (slab_bytes) *slab_bytes = 0;
+  if (!g_splitk || p.g.os != 1 || p.m_beg != 0 || p.bias != nullptr || p.accumulate || p.bst.y != nullptr || (p.g.Cout & 7)) return 1;
+  const long tiles = igemm256_tiles(p);
+  if (tiles < 1 || tiles > 128) return 1;
+  const int ngk = ((p.g.Cin + BK - 1) / BK + 3) / 4;
+  int s = (int)(256 / tiles);
+  if (s > ngk / 2) s = ngk / 2;
+  if (s > 8) s = 8;
+  if (s < 2) return 1;
+  if (slab_bytes) *slab_bytes = (size_t)s * tiles * TM * TN * sizeof(float);
+  return s;
+}
+
 int launch_igemm256(const IgemmParams& p_in, hipStream_t st) {
   const size_t lds = (size_t)MAIN_BYTES + 128;
   static const void* zero_dev = nullptr;
@@ -504,7 +615,24 @@ int launch_igemm256(const IgemmParams& p_in, hipStream_t st) {
   IgemmParams p = p_in;
   p.zero_page = zero_dev;
   p.phase_fast = g_phase_fast;
-  hipLaunchKernelGGL(igemm256_kernel, dim3((unsigned)igemm256_tiles(p)), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(igemm256_kernel, dim3((unsigned)(igemm256_tiles(p) * (p.ksplit > 1 ? p.ksplit : 1))), dim3(512), lds, st, p);
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_igemm256_splitk(const IgemmParams& p_in, int splits, void* ws, hipStream_t st) {
+  IgemmParams p = p_in;
+  p.ksplit = splits;
+  p.kslab = reinterpret_cast<float*>(ws);
+  if (int e = launch_igemm256(p, st)) return e;
+  SplitKFoldArgs a;
+  a.kslab = p.kslab; a.nsplit = splits; a.tiles_per_split = (int)igemm256_tiles(p); a.ntn = (p.g.Cout + TN - 1) / TN;
+  a.ngroup = p.ngroup > 1 ? p.ngroup : 1; a.mt256 = (p.M + TM - 1) / TM; a.mtiles = p.mtiles; a.M = p.M; a.Cout = p.g.Cout; a.ldy = p.ldy;
+  for (int b = 0; b < IgemmParams::MAXGROUP; ++b) {
+    a.y[b] = b == 0 ? p.y : p.gy[b - 1];
+    a.slab[b] = b == 0 ? p.slab : p.gslab[b - 1];
+  }
+  hipLaunchKernelGGL(igemm256_splitk_fold_kernel, dim3((unsigned)(2 * a.tiles_per_split)), dim3(256), 0, st, a);
   DC_CHECK_LAUNCH();
   return 0;
 }

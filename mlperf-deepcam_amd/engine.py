@@ -480,9 +480,19 @@ class Engine:
         wfs = (C.c_void_p * cnt)(*[m[1].data_ptr() for m in members])
         slabs = (C.c_void_p * cnt)(*[m[3].data_ptr() for m in members])
         N, H, W = x.N, x.H, x.W
+        # few pixels under a long K loop (local batch 2: 81 tiles of 576 K steps on 256 CUs): the library cuts the launch along K when it is
+        # given room for the partial tiles (dc_conv_fwd_dilated_group_ws)
+        wsb = L.load().dc_conv_fwd_dilated_group_workspace(C.byref(d0), N, H, W, cnt, dils) if self.dt == L.DC_BF16 else 0
+        kws = torch.empty(wsb, dtype=torch.uint8, device=self.device) if wsb > 0 else None
+        if kws is not None:
+            self._keep.append(kws)
 
         def fwd(train: bool):
             ys = (C.c_void_p * cnt)(*[m[2].ptr.value for m in members])
+            if kws is not None:
+                L.call("dc_conv_fwd_dilated_group_ws", C.byref(d0), N, H, W, cnt, dils, x.ptr, x.ld, wfs, ys, y0.ld, slabs if train else None,
+                       L.dptr(kws), wsb, self._st())
+                return
             L.call("dc_conv_fwd_dilated_group", C.byref(d0), N, H, W, cnt, dils, x.ptr, x.ld, wfs, ys, y0.ld, slabs if train else None,
                    self._st())
 

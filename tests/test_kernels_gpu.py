@@ -509,6 +509,34 @@ def test_dilated_group_is_bit_identical_to_single_launches(shape, dtype):
     assert all(torch.equal(ys[b], singles[b][0]) for b in range(3))
     with pytest.raises(L.DeepcamHipError):
         L.call("dc_conv_fwd_dilated_group", C.byref(d0), N, H, W, 5, (C.c_int * 5)(1, 2, 3, 4, 5), vptr(xv), cin + 32, None, None, cout, None, S())
+    # split-K form (dc_conv_fwd_dilated_group_ws): offered where the launch is 81 tiles of 576 K steps; another order of the K sum, so the
+    # outputs agree to a rounding of the stored value and the sums to fp32 accuracy
+    wsb = L.load().dc_conv_fwd_dilated_group_workspace(C.byref(d0), N, H, W, 3, (C.c_int * 3)(*dils))
+    if dtype != torch.bfloat16 or cin < 2048:
+        assert wsb == 0
+        return
+    assert wsb == 3 * 81 * 256 * 256 * 4
+    ws = torch.full((wsb // 4,), float("nan"), device=dev())
+    for with_stats in (True, False):
+        cat.fill_(float("nan"))
+        gs2 = [torch.full((2, rows, cout), float("nan"), device=dev()) for _ in dils]
+        L.call("dc_conv_fwd_dilated_group_ws", C.byref(d0), N, H, W, 3, (C.c_int * 3)(*dils), vptr(xv), cin + 32,
+               (C.c_void_p * 3)(*[t.data_ptr() for t in wfs]), (C.c_void_p * 3)(*[t.data_ptr() for t in ys]), 3 * cout + 8,
+               (C.c_void_p * 3)(*[t.data_ptr() for t in gs2]) if with_stats else None, vptr(ws), wsb, S())
+        torch.cuda.synchronize()
+        assert torch.isnan(cat[..., 3 * cout:].float()).all()
+        for b in range(3):
+            ref, got = singles[b][0].float(), ys[b].float()
+            assert (got - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item(), f"member {b}"
+            assert (got != ref).float().mean().item() < 0.2, f"member {b}: more than a rounding apart"
+            if with_stats:
+                assert torch.allclose(gs2[b], singles[b][1], rtol=2e-3, atol=2e-2), f"member {b}: statistics"
+    # too small a workspace: the unsplit launch, bit for bit
+    cat.fill_(float("nan"))
+    L.call("dc_conv_fwd_dilated_group_ws", C.byref(d0), N, H, W, 3, (C.c_int * 3)(*dils), vptr(xv), cin + 32,
+           (C.c_void_p * 3)(*[t.data_ptr() for t in wfs]), (C.c_void_p * 3)(*[t.data_ptr() for t in ys]), 3 * cout + 8, None, vptr(ws), wsb - 16, S())
+    torch.cuda.synchronize()
+    assert all(torch.equal(ys[b], singles[b][0]) for b in range(3))
 
 
 GROUP_CASES = [
