@@ -60,6 +60,10 @@ struct IgemmParams {
   // kslab[split][tile][256 px][256 ch]; igemm256_splitk_fold sums the splits in a fixed order, stores y and takes the BatchNorm sums.
   int ksplit;
   float* kslab;
+  // 128-tile kernel: a 1 x 1 stride-2 data gradient written first-hand (the shortcut convs of the entry flow): only phase (0, 0) has a tap, and a
+  // launch over that phase alone also stores the zeros of the other three beside its values -- contiguous output rows instead of every other
+  // 128-byte line of every other image row (which wrote 56 MB in 165 us)
+  int zfill;
 };
 // OUT32: the epilogue stores fp32 regardless of T (used by the classifier head, whose logits must not be rounded to bf16)
 

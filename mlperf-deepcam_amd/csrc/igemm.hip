@@ -112,9 +112,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + xslot;
   const int ntile_n = tile % ntn;
   const int rest = tile / ntn;
-  const int mtl = (p.M - p.m_beg + BM - 1) / BM;   // pixel tiles of this launch
-  const int mtile = rest % mtl;
-  const int phase = rest / mtl;
+  // Sub-pixel phases fastest: the phases of a strided / transposed layer have K loops of different length (a 1 x 1 stride-2 data gradient:
+  // 1 / 0 / 0 / 0 taps), and every XCD is dealt a CONTIGUOUS run of tiles -- with the phase as the slowest index all the tiles that do
+  // work sat on two of the eight XCDs (block 1's shortcut data gradient at local batch 8: 178 us for 340 MB)
+  const int nph = p.zfill ? 1 : g.os * g.os;     // (zfill: the launch covers phase (0, 0) only)
+  const int phase = rest % nph;
+  const int mtile = rest / nph;
   const int n0 = ntile_n * BN;
   const int m0 = p.m_beg + mtile * BM;
   const int py = phase / g.os, px = phase % g.os;
@@ -416,6 +419,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         unpack(v, f, TO());
       }
       stg16(dst, v);
+      if (p.zfill) {     // the three tap-less phases of this pixel: its right, lower and lower-right neighbours
+        stg16(dst + p.ldy, zero16());
+        stg16(dst + (size_t)g.Wout * p.ldy, zero16());
+        stg16(dst + (size_t)(g.Wout + 1) * p.ldy, zero16());
+      }
 #pragma unroll
       for (int e = 0; e < KPVO; ++e) {
         ssum[e] += f[e];
@@ -510,7 +518,7 @@ static int launch_igemm2(const IgemmParams& p, hipStream_t st) {
   constexpr size_t RING = (size_t)2 * StageCfg<MODE>::NSTAGE * BM * StageCfg<MODE>::ROWB;
   const size_t lds = (RING > (size_t)BM * CROW ? RING : (size_t)BM * CROW) + 128;
   DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, OUT32, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid(cdiv(p.g.Cout, BN) * cdiv(p.M - p.m_beg, BM) * p.g.os * p.g.os);
+  dim3 grid(cdiv(p.g.Cout, BN) * cdiv(p.M - p.m_beg, BM) * (p.zfill ? 1 : p.g.os * p.g.os));
   hipLaunchKernelGGL((igemm_kernel<T, OUT32, MODE>), grid, dim3(256), lds, st, p);
   DC_CHECK_LAUNCH();
   return 0;
@@ -539,6 +547,7 @@ static int g_igemm256p_wgs = 0;      // its workgroups ("igemm256p_wgs"); 0: few
 static int g_igemm256p_min = 257;    // fewest tiles it is used for ("igemm256p_min")
 static int g_pw384 = 1;
 static int g_pw192 = 1;             // 128 x 192 tiles for one-round launches of few pixels ("pw192")
+static int g_zfill = 1;             // 1 x 1 stride-2 data gradients written first-hand: one launch over phase (0, 0) stores all four phases ("igemm_zfill")
 static int g_pw384_k64 = 1;         // 256 x 384 tiles with 128-byte K rows where the planner picks that tile ("pw384_k64")
 static int pw384_plan(const IgemmParams& p) {
   if (g_pw384 == 0 || !pw384_eligible(p)) return 0;
@@ -602,6 +611,7 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   p.zero_page = nullptr;
   p.ngroup = 0;
   p.ksplit = 0; p.kslab = nullptr;
+  p.zfill = 0;
   p.bst = BnBwdEpi{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
   if (bst != nullptr) {
     DC_REQUIRE(slab != nullptr && !accumulate && !out32 && bias == nullptr, "dc_conv_dgrad_bnstats: needs a slab, no bias, no accumulate");
@@ -630,6 +640,9 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
       return launch_igemm256(p, st);
     }
   }
+  // every tap in phase (0, 0) of a 2 x 2 phase grid, written first-hand, nothing riding along: one launch over that phase stores all four
+  if (g_zfill && p.g.os == 2 && p.g.ntaps > 0 && p.g.phase_beg[1] == p.g.ntaps && !accumulate && slab == nullptr && bias == nullptr && bst == nullptr && !out32)
+    p.zfill = 1;
   if (d->dtype == DC_BF16) return out32 ? launch_igemm<bf16, true>(p, st) : launch_igemm<bf16, false>(p, st);
   return launch_igemm<float, false>(p, st);
 }
@@ -889,6 +902,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm256p_min") == 0) { g_igemm256p_min = value; return 0; }
   if (name != nullptr && strcmp(name, "pw384_k64") == 0) { g_pw384_k64 = value; return 0; }
   if (name != nullptr && strcmp(name, "pw192") == 0) { g_pw192 = value; return 0; }
+  if (name != nullptr && strcmp(name, "igemm_zfill") == 0) { g_zfill = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_splitk") == 0) { igemm256_set_splitk(value); return 0; }
   if (name != nullptr && strcmp(name, "thin_fwd") == 0) { g_thin_fwd = value != 0; return 0; }
   if (name != nullptr && strcmp(name, "thin_tile") == 0) { thin_set_tile(value); return 0; }
@@ -998,7 +1012,7 @@ static int dilated_group_impl(const dc_conv_desc* d, int N, int Hi, int Wi, int 
   const long M = (long)N * p.g.Qh * p.g.Qw;
   DC_REQUIRE(N > 0 && M < (1L << 31) - BM, "dc_conv_fwd_dilated_group: bad pixel count");
   p.x = x; p.w = wfs ? wfs[0] : nullptr; p.y = ys ? ys[0] : nullptr; p.bias = nullptr; p.slab = stat_slabs ? stat_slabs[0] : nullptr;
-  p.ksplit = 0; p.kslab = nullptr;
+  p.ksplit = 0; p.kslab = nullptr; p.zfill = 0;
   p.bst = BnBwdEpi{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
   p.N = N; p.ldx = ldx; p.ldy = ldy;
   p.ldw = weight_ld(p.g.Cin);
