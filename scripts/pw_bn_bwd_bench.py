@@ -14,8 +14,8 @@ def timed(fn, reps=10):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for (cin, H, W) in ((128, 384, 576), (64, 384, 576)):
-    cout = 128; M = N * H * W
+for (cin, cout, H, W) in ((128, 128, 384, 576), (64, 128, 384, 576), (256, 256, 192, 288), (128, 256, 192, 288)):
+    M = N * H * W
     y = torch.randn(M, cout, device=dev).to(dt); do = torch.randn(M, cout, device=dev).to(dt); x = torch.randn(M, cin, device=dev).to(dt)
     dy = torch.empty(M, cout, device=dev, dtype=dt); dx = torch.empty(M, cin, device=dev, dtype=dt); dx2 = torch.empty_like(dx)
     w = torch.randn(cout, cin, 1, 1, device=dev) * 0.1

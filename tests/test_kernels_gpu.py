@@ -1748,16 +1748,17 @@ def test_lamb_is_bit_reproducible():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-PW_BN_BWD_CASES = [("b1_sep2", 128, 2, 192, 192, 2), ("b1_sep1", 64, 2, 192, 192, 2), ("ragged_nomask", 128, 1, 257, 257, 0),
-                   ("ragged64", 64, 1, 257, 259, 2)]
+PW_BN_BWD_CASES = [("b1_sep2", 128, 128, 2, 192, 192, 2), ("b1_sep1", 64, 128, 2, 192, 192, 2), ("ragged_nomask", 128, 128, 1, 257, 257, 0),
+                   ("ragged64", 64, 128, 1, 257, 259, 2), ("b2_sep2", 256, 256, 2, 192, 192, 2), ("b2_sep1", 128, 256, 2, 192, 192, 2),
+                   ("ragged256_nomask", 256, 256, 1, 257, 257, 0), ("ragged128_256", 128, 256, 1, 259, 257, 2)]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,cin,N,H,W,relu", PW_BN_BWD_CASES, ids=[c[0] for c in PW_BN_BWD_CASES])
-def test_pointwise_bn_backward_in_one_pass(name, cin, N, H, W, relu):
+@pytest.mark.parametrize("name,cin,cout,N,H,W,relu", PW_BN_BWD_CASES, ids=[c[0] for c in PW_BN_BWD_CASES])
+def test_pointwise_bn_backward_in_one_pass(name, cin, cout, N, H, W, relu):
     """dc_pw_bn_bwd (BatchNorm backward apply + pointwise data gradient + pointwise weight gradient over ONE read of dout, y, x; dy never stored)
     against the three passes it replaces: dx bit for bit (same dy bits, same MFMA K order), the weight gradient against fp64 sums of the stored dy."""
-    dtype, dt, cout = torch.bfloat16, L.DC_BF16, 128
+    dtype, dt = torch.bfloat16, L.DC_BF16
     lib = L.load()
     M = N * H * W
     rows = lib.dc_pw_bn_bwd_rows(dt, cin, cout, M)

@@ -522,7 +522,8 @@ def _shared_point_engines(B, H, W):
     torch.cuda.synchronize()
     # (the bf16 engine never stores the output gradient of the entry flow's thin pointwise convs: dc_pw_bn_bwd forms it in registers)
     extra = set(e32.saved) - set(e16.saved)
-    assert set(e16.saved) <= set(e32.saved) and all(k.startswith("dxception_features.block1.") and k.endswith(".pw") for k in extra), extra
+    assert set(e16.saved) <= set(e32.saved) and all(k.startswith(("dxception_features.block1.", "dxception_features.block2.")) and k.endswith(".pw")
+                                                    for k in extra), extra
     for k, t in e16.saved.items():
         assert e32.saved[k].shape == t.shape, k
         e32.saved[k].copy_(t)
