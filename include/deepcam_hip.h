@@ -294,7 +294,7 @@ int dc_bn_bwd_apply_fin(int dtype, long M, int C, long count, const void* dout, 
  * (dout, y, x): dy = the BatchNorm's input gradient (relu 2: dout masked by y * mscale + mshift > 0; relu 0: no mask) is formed in registers,
  * rounded to bf16 as dc_bn_bwd_apply stores it, and feeds both products from LDS; it is never written.  dx [M][Cin] = dy . W (wb: the packed
  * data-gradient operand of dc_conv_pack_weights); wslab [rows][Cout][Cin] fp32 = one partial weight gradient per workgroup, rows =
- * dc_pw_bn_bwd_rows(...) (0: shape not served -- bf16, Cout 128, Cin 64 or 128, at least 65 536 pixels: the entry flow's first block, whose 453 MB
+ * dc_pw_bn_bwd_rows(...) (0: shape not served -- bf16, Cout 128 with Cin 64 / 128 or Cout 256 with Cin 128 / 256, at least 65 536 pixels: the entry flow's first two blocks, whose 226 - 453 MB
  * tensors make all three passes HBM-bound), summed by dc_fold_slabs (DC_FOLD_CONV, splits = rows, taps = 1).  dgamma / dbeta: the finished
  * parameter gradients (dc_bn_bwd_finalize).  Replaces autograd's batch_norm_backward + conv2d backward of SeparableConv2d_same.pointwise
  * (deeplab_xception.py:62-66, 84-101; train_hdf5_ddp.py:363). */
