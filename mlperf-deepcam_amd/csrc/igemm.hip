@@ -887,6 +887,7 @@ extern "C" int dc_wgrad_set_384_fill(int pct);
 extern "C" int dc_wgrad_set_384_min_stages(int n);
 extern "C" int dc_head_set_fused(int v);
 extern "C" int dc_head_set_dgrad_fused(int v);
+extern "C" int dc_head_set_wgrad_fused(int v);
 extern "C" int dc_dw_set_option(const char* name, int value);
 extern "C" int dc_bn_set_option(const char* name, int value);
 extern "C" int dc_set_option(const char* name, int value) {
@@ -923,6 +924,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "wgrad384_min_stages") == 0) return dc_wgrad_set_384_min_stages(value);
   if (name != nullptr && strcmp(name, "head_fused") == 0) return dc_head_set_fused(value);
   if (name != nullptr && strcmp(name, "head_dgrad_fused") == 0) return dc_head_set_dgrad_fused(value);
+  if (name != nullptr && strcmp(name, "head_wgrad_fused") == 0) return dc_head_set_wgrad_fused(value);
   if (name != nullptr && dc_dw_set_option(name, value) == 0) return 0;
   if (name != nullptr && dc_bn_set_option(name, value) == 0) return 0;
   return dc_fail("dc_set_option: unknown option", __FILE__, __LINE__);
@@ -937,7 +939,7 @@ static const struct { const char* name; int value; } kOptionDefaults[] = {
     {"igemm256_phase_fast", 1}, {"wgrad_target_blocks", 768},
     {"wgrad_mode", 1}, {"wgrad_min_steps", 16}, {"wgrad256", 1}, {"wgrad256_pad", 115}, {"thin_wgrad", 1}, {"wgrad256_slots", 192}, {"wgrad256_min_stages", 96},
     {"wgrad384", 1}, {"wgrad384_slots", 192}, {"wgrad384_fill", 66}, {"wgrad384_min_stages", 96}, {"head_fused", 1},
-    {"head_dgrad_fused", 1}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_pipe", 1}, {"bn_cgw", 32}, {"bn_rows", 32}, {"bn_apply_rows", 1},
+    {"head_dgrad_fused", 1}, {"head_wgrad_fused", 1}, {"igemm256_splitk", 1}, {"igemm_zfill", 1}, {"pw_bn_bwd", 3}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_pipe", 1}, {"bn_cgw", 32}, {"bn_rows", 32}, {"bn_apply_rows", 1},
 };
 
 extern "C" int dc_reset_options(void) {

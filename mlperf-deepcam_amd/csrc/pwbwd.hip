@@ -456,7 +456,7 @@ using namespace dc;
 extern "C" int dc_pw_bn_bwd_rows(int dtype, int Cin, int Cout, long M) {
   if (!g_pw_bn_bwd || dtype != DC_BF16 || M < 65536 || M >= (1L << 31)) return 0;
   if (Cout == 256 && (Cin == 128 || Cin == 256)) return (g_pw_bn_bwd & 2) ? pwbwd256_pairs(M) : 0;
-  if (Cout != PB_CO || (Cin != 64 && Cin != 128)) return 0;
+  if (Cout != PB_CO || (Cin != 64 && Cin != 128) || !(g_pw_bn_bwd & 1)) return 0;
   return pwbwd_grid(Cin, M);
 }
 

@@ -2,6 +2,7 @@
 //   stem  Conv2d(16->32, k3, s2, p1) that reads the caller's NCHW fp32 batch in place (no layout pass) and writes NHWC
 //   head  ConvTranspose2d(256->3, k3, s2, p1, op1) that reads NHWC and writes the NCHW fp32 logits of the reference API
 #include "common.h"
+#include "lds_tr_image.h"
 #include "wgrad.h"
 
 namespace dc {
@@ -780,7 +781,7 @@ extern "C" int dc_conv_dgrad_bnstats(const dc_conv_desc* d, int N, int Hi, int W
 // the sums without storing dx, and -- once dc_bn_bwd_finalize has made dgamma / dbeta of them -- MODE HD_APPLY forms the same dx again
 // (one MFMA step from the 64-byte gathered gradient row) and writes dy = gamma*invstd*(g - dbeta/count - xhat*dgamma/count) directly,
 // element for element the arithmetic of bn_bwd_apply_kernel on the rounded dx (bn.hip): 2.9 GB of traffic for the pair instead of 4.6.
-enum { HD_STORE = 0, HD_SUMS = 1, HD_APPLY = 2 };
+enum { HD_STORE = 0, HD_SUMS = 1, HD_APPLY = 2, HD_SUMS_WG = 3 };
 struct HeadDgradBst {
   const bf16* y;
   int ldy;
@@ -796,6 +797,8 @@ struct HeadDgradBst {
   const float* dgamma;
   const float* dbeta;
   float inv_count;
+  // HD_SUMS_WG only: one partial weight gradient [32 products][256 channels] per workgroup
+  float* wslab;
 };
 
 __device__ inline float head_row_sum16(float v) {      // sum over the 16 lanes of a DPP row (the 16 pixels of a group)
@@ -811,8 +814,23 @@ __device__ inline uint32_t head_swap_rows16(uint32_t v) { return (uint32_t)__bui
 template <int MODE>
 __global__ __launch_bounds__(256) void head_dgrad_kernel(const bf16* __restrict__ dP, const bf16* __restrict__ wb, bf16* __restrict__ dx,
                                                          int lddx, long M, const HeadDgradBst b) {
-  constexpr int CIN = 256, GPB = 4;                     // pixel groups (of 16) requested together
-  constexpr bool BST = true, SUMS = MODE != HD_APPLY, APPLY = MODE == HD_APPLY;
+  constexpr int CIN = 256, GPB = MODE == HD_SUMS_WG ? 2 : 4;     // pixel groups (of 16) requested together (the weight-gradient form has 32 more accumulator registers to keep)
+  constexpr bool BST = true, SUMS = MODE != HD_APPLY, APPLY = MODE == HD_APPLY, WG = MODE == HD_SUMS_WG;
+  // HD_SUMS_WG: the head's WEIGHT gradient dW[product k][channel c] = sum over pixels of dP[px][k] * act(y)[px][c] rides on the statistics pass,
+  // which already has dP and y of every pixel in registers (the separate pass re-read the 906 MB BatchNorm input at local batch 8).  Per 32
+  // pixels a wave writes its dP fragment and the activation of its 64 channels (act = relu(y * mscale + mshift) rounded to bf16: the head's
+  // forward input, bit for bit) into a wave-private LDS image and takes both MFMA operands out of it through transposing reads: 8 MFMAs,
+  // 32 accumulator registers for the wave's whole life, one slab row per workgroup at the end.
+  extern __shared__ __attribute__((aligned(16))) char hd_smem[];
+  char* const dpimg = hd_smem + (threadIdx.x >> 6) * (2 * TRI_QUAD);
+  char* const actimg = dpimg + TRI_QUAD;
+  [[maybe_unused]] f32x4 wacc[2][4];
+  if constexpr (WG) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const bool odd = fg & 1;
@@ -833,8 +851,8 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const bf16* __restrict_
         const int c = cpair(p) + e;
         mu[p][e] = b.mean[c];
         is[p][e] = b.invstd[c];
-        ms[p][e] = b.relu ? b.mscale[c] : 0.f;
-        mh[p][e] = b.relu ? b.mshift[c] : 0.f;
+        ms[p][e] = (b.relu || WG) ? b.mscale[c] : 0.f;       // (the weight-gradient form needs the activation itself, not only its mask)
+        mh[p][e] = (b.relu || WG) ? b.mshift[c] : 0.f;
         if constexpr (APPLY) {      // the coefficients of bn_bwd_apply_kernel, expression for expression
           const float inv = is[p][e];
           const float ca = b.gamma[c] * inv;
@@ -866,6 +884,41 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const bf16* __restrict_
         if constexpr (BST) {
 #pragma unroll
           for (int p = 0; p < 2; ++p) yv[u][p] = ok[u] ? ldg16(b.y + (size_t)px * b.ldy + cpair(p)) : zero16();
+        }
+      }
+      if constexpr (WG) {
+        // two 32-pixel stages (groups 0, 1 and 2, 3 of this request): image rows 16 (u & 1) + fr
+#pragma unroll
+        for (int st2 = 0; st2 < GPB / 2; ++st2) {
+#pragma unroll
+          for (int uu = 0; uu < 2; ++uu) {
+            const int u = 2 * st2 + uu;
+            const int r = 16 * uu + fr;
+            *reinterpret_cast<vec16*>(dpimg + tri_slot(r, fg)) = fb[u];             // (zeros past the last pixel)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              float yf[8];
+              unpack(yv[u][p], yf, bf16());
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float t = fmaf(yf[e], ms[p][e], mh[p][e]);
+                yf[e] = b.relu ? fmaxf(t, 0.f) : t;
+              }
+              vec16 v;
+              pack(v, yf, bf16());
+              if (!ok[u]) v = zero16();
+              *reinterpret_cast<vec16*>(actimg + tri_slot(r, (2 * p + (odd ? 1 : 0)) * 2 + (fg >> 1))) = v;
+            }
+          }
+          bf16x8 ka[2];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) ka[kb] = tri_frag(dpimg + tri_base(lane) + ((kb ^ tri_key(lane)) << 5));
+#pragma unroll
+          for (int cbk = 0; cbk < 4; ++cbk) {
+            const bf16x8 cbf = tri_frag(actimg + tri_base(lane) + ((cbk ^ tri_key(lane)) << 5));
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) wacc[kb][cbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kb], cbf, wacc[kb][cbk], 0, 0, 0);
+          }
         }
       }
 #pragma unroll
@@ -934,10 +987,22 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const bf16* __restrict_
         }
     }
   }
+  if constexpr (WG) {
+    // wacc[kb][cbk][r] = dW of product 16 kb + 4 fg + r and channel 64 wave + 16 cbk + fr
+    float* out = b.wslab + (size_t)blockIdx.x * (HEAD_NP * CIN);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int cbk = 0; cbk < 4; ++cbk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(16 * kb + 4 * fg + r) * CIN + 64 * wave + 16 * cbk + fr] = wacc[kb][cbk][r];
+  }
 }
 
 static int g_head_dgrad_fused = 1;   // "head_dgrad_fused": 0 = the head's data gradient on the tiled GEMM kernels (A/B, tests)
 extern "C" int dc_head_set_dgrad_fused(int v) { g_head_dgrad_fused = v ? 1 : 0; return 0; }
+static int g_head_wgrad_fused = 1;   // "head_wgrad_fused": the head's weight gradient rides on the statistics pass of the two-pass backward (parts = 3)
+extern "C" int dc_head_set_wgrad_fused(int v) { g_head_wgrad_fused = v ? 1 : 0; return 0; }
 
 // bn_y != nullptr: x is act(bn(bn_y)) and the data gradient also leaves that BatchNorm's backward sums in bn_slab
 static int head_bwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* x, int ldx, const float* dlogits_nchw,
@@ -978,7 +1043,9 @@ static int head_bwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* 
     }
     DC_CHECK_LAUNCH();
   }
-  if (parts & 2) {
+  // the statistics pass without a stored dx (dc_head_bwd_bnin, two-pass form) asked for both parts at once: the weight gradient rides on it
+  const bool wg_rides = streaming && g_head_wgrad_fused && x == nullptr && dx == nullptr && parts == 3 && bn_relu >= 0 && P >= 256;
+  if ((parts & 2) && !wg_rides) {
     if (x != nullptr) {
       if (int e = dc_conv_wgrad(&d, N, Hi, Wi, x, ldx, ws.dP, HEAD_NP, ws.slabs, ws.slab_bytes, ws.tmp, stream)) return e;
     } else {
@@ -994,7 +1061,23 @@ static int head_bwd_impl(int dtype, int N, int Cin, int Hi, int Wi, const void* 
     const int grid = chunks < 2048 ? chunks : 2048;
     if (int e = dc_check_view(bn_y, bn_ldy, Cin, dtype, "dc_head_bwd bn_y")) return e;
     DC_REQUIRE(bn_mean && bn_invstd && (!bn_relu || (bn_mscale && bn_mshift)), "dc_head_bwd: missing BatchNorm vectors");
-    const HeadDgradBst b{(const bf16*)bn_y, bn_ldy, bn_mean, bn_invstd, bn_mscale, bn_mshift, bn_relu, bn_slab, chunks, nullptr, nullptr, nullptr, 0.f};
+    HeadDgradBst b{(const bf16*)bn_y, bn_ldy, bn_mean, bn_invstd, bn_mscale, bn_mshift, bn_relu, bn_slab, chunks, nullptr, nullptr, nullptr, 0.f, nullptr};
+    if (wg_rides) {
+      // one slab row (32 x 256 floats) per workgroup in the product image's space of the workspace (unused by the fused forward): at most
+      // chunks / 2 rows of 32 KiB fit its M x 128 bytes
+      int g2 = chunks / 2 < 512 ? chunks / 2 : 512;        // (252 registers: two workgroups per CU, one round)
+      if (g2 < 1) g2 = 1;
+      b.wslab = ws.P;
+      static_assert(HEAD_NP == 32, "product image");
+      DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_dgrad_kernel<HD_SUMS_WG>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * TRI_QUAD));
+      hipLaunchKernelGGL(head_dgrad_kernel<HD_SUMS_WG>, dim3(g2), dim3(256), 4 * 2 * TRI_QUAD, st, (const bf16*)ws.dP, (const bf16*)ws.wb, (bf16*)nullptr, 0, (long)P, b);
+      DC_CHECK_LAUNCH();
+      const long nw = (long)HEAD_NP * Cin;
+      hipLaunchKernelGGL(slab_rows_reduce_kernel, dim3(cdiv(nw, 8)), dim3(256), 0, st, (const float*)ws.P, ws.tmp, g2, nw);
+      hipLaunchKernelGGL(head_wfinish_kernel, dim3(cdiv(Cin * HEAD_NC * 9, 256)), dim3(256), 0, st, (const float*)ws.tmp, grad_w, Cin);
+      DC_CHECK_LAUNCH();
+      return 0;
+    }
     if (dx != nullptr)
       hipLaunchKernelGGL(head_dgrad_kernel<HD_STORE>, dim3(grid), dim3(256), 0, st, (const bf16*)ws.dP, (const bf16*)ws.wb, (bf16*)dx, lddx, (long)P, b);
     else

@@ -204,6 +204,7 @@ class Engine:
         self.fuse_bn_bwd_fin = os.environ.get("DC_FUSE_BN_BWD_FIN", "1") != "0"    # dc_bn_bwd_finalize inside dc_bn_bwd_apply for short slabs
         # BatchNorm backward apply + pointwise data gradient + pointwise weight gradient of the entry flow's thin layers in one pass (dc_pw_bn_bwd)
         self.fuse_pw_bn_bwd = os.environ.get("DC_FUSE_PW_BN_BWD", "1") != "0"
+        self.fuse_head_wgrad = os.environ.get("DC_FUSE_HEAD_WGRAD", "1") != "0"     # the head's weight gradient inside its statistics pass
         # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
         # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 40.31 -> 40.10 (round 3; 1 / 2 / 3 / 4 layers:
         # 40.31 / 40.28 / 40.10 / 40.18) -- the fp32 split slabs (256 KiB per workgroup whatever the batch) are a third of a 728-channel
@@ -988,6 +989,11 @@ class Engine:
                                L.dptr(self.dlogits), self.pptr(wl), da.ptr if da is not None else None, da.ld if da is not None else 0,
                                self.gptr(wl), hptr, L.dptr(a.mean), L.dptr(a.invstd),
                                L.dptr(sslab) if sslab is not None else None, parts, self._st())
+                    if two_pass and self.fuse_head_wgrad:
+                        # the statistics pass (dx is not stored) has dP and y of every pixel in registers: the weight gradient rides on it
+                        # instead of re-reading the 906 MB BatchNorm input in a pass of its own
+                        call(3)
+                        return
                     call(1)
                     self._on_side(lambda ws_: call(2))
                     return

@@ -1623,6 +1623,19 @@ def test_head_on_unstored_batchnorm_output(shape, relu):
     with pytest.raises(L.DeepcamHipError, match="dx may be NULL only"):
         L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, vptr(yv), Cin + 16, vptr(scale), vptr(shift), relu, vptr(ref_dl), vptr(wd), None, 0,
                vptr(gw), wsp, vptr(mean), vptr(invstd), None, 1, S())
+    # both parts in ONE call without a dx: the weight gradient rides on the statistics pass (no second read of the BatchNorm input); same sums bit
+    # for bit, the weight gradient to the rounding of another pixel order; with the switch off: the two passes one after the other
+    for switch in (1, 0):
+        L.call("dc_set_option", b"head_wgrad_fused", switch)
+        slab3 = torch.full((2, rows, Cin), float("nan"), device=dev())
+        gw3 = torch.full((Cin, 3, 3, 3), float("nan"), device=dev())
+        L.call("dc_head_bwd_bnin", dt, N, Cin, H, W, vptr(yv), Cin + 16, vptr(scale), vptr(shift), relu, vptr(ref_dl), vptr(wd), None, 0,
+               vptr(gw3), wsp, vptr(mean), vptr(invstd), vptr(slab3), 3, S())
+        torch.cuda.synchronize()
+        assert torch.equal(slab3, ref_slab), switch
+        assert not torch.isnan(gw3).any()
+        assert (gw3 - ref_gw).abs().max().item() <= 1e-5 * ref_gw.abs().max().item(), switch
+    L.call("dc_set_option", b"head_wgrad_fused", 1)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
