@@ -331,6 +331,9 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const ThinFwdArgs a) {
       const int which = tid / COUT, ch = tid % COUT;
       const float s = (red[(0 * 2 + which) * COUT + ch] + red[(1 * 2 + which) * COUT + ch]) + (red[(2 * 2 + which) * COUT + ch] + red[(3 * 2 + which) * COUT + ch]);
       a.slab[((size_t)which * a.slab_rows + blockIdx.x) * COUT + ch] = s;
+      // the slab has one row per 128 pixels of the layer, this persistent grid fewer workgroups: the rows nobody owns are zeros (two
+      // hipMemsetAsync launches per call did this before: 4 x 5 us on every step's forward chain)
+      for (int r = blockIdx.x + gridDim.x; r < a.slab_rows; r += gridDim.x) a.slab[((size_t)which * a.slab_rows + r) * COUT + ch] = 0.f;
     }
   }
 }
@@ -494,6 +497,9 @@ __global__ __launch_bounds__(256) void thin_tile_kernel(const ThinFwdArgs a) {
       const int which = tid / COUT, ch = tid % COUT;
       const float s = (red[(0 * 2 + which) * COUT + ch] + red[(1 * 2 + which) * COUT + ch]) + (red[(2 * 2 + which) * COUT + ch] + red[(3 * 2 + which) * COUT + ch]);
       a.slab[((size_t)which * a.slab_rows + blockIdx.x) * COUT + ch] = s;
+      // the slab has one row per 128 pixels of the layer, this persistent grid fewer workgroups: the rows nobody owns are zeros (two
+      // hipMemsetAsync launches per call did this before: 4 x 5 us on every step's forward chain)
+      for (int r = blockIdx.x + gridDim.x; r < a.slab_rows; r += gridDim.x) a.slab[((size_t)which * a.slab_rows + r) * COUT + ch] = 0.f;
     }
   }
 }
@@ -577,12 +583,6 @@ int launch_thin_fwd(const GatherGeom& g, int N, const void* in, int ldin, const 
   const int wgs = !tiled ? 1024 : 256 * (g.Cin == 32 ? ThinTile<32, 64>::WGS_PER_CU : ThinTile<64, 32>::WGS_PER_CU);
   int grid = chunks < wgs ? chunks : wgs;
   if (slab != nullptr && grid > slab_rows) grid = slab_rows;
-  if (slab != nullptr && slab_rows > grid) {
-    for (int which = 0; which < 2; ++which) {
-      hipError_t e = hipMemsetAsync(slab + ((size_t)which * slab_rows + grid) * g.Cout, 0, (size_t)(slab_rows - grid) * g.Cout * sizeof(float), st);
-      if (e != hipSuccess) return dc_set_error(e, __FILE__, __LINE__);
-    }
-  }
 #define THIN_FWD(CI, CO)                                                                                                        \
   do {                                                                                                                          \
     constexpr int LDS = ((9 * CI + 31) / 32) * CO * 64;                                                                         \

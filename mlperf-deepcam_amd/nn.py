@@ -294,11 +294,14 @@ class ArenaOptimizer:
         self.step_count = 0
         self.max_grad_norm = max_grad_norm
         self.grad_scale = 1.0
-        self._lr_host = torch.zeros(1, dtype=torch.float32).pin_memory()
-        self._step_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        # learning rate (float32) and step count (int32) side by side: ONE 8-byte host-to-device copy per step
+        self._scal_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self._lr_host = self._scal_host[:1].view(torch.float32)
+        self._step_host = self._scal_host[1:]
         self._scalars_copied = None
-        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._scal_dev = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.lr_dev = self._scal_dev[:1].view(torch.float32)
+        self.step_dev = self._scal_dev[1:]
         self._offsets = torch.tensor(lay.offsets(), dtype=torch.int64, device=dev)
         # the LAMB workspace holds an n-element update direction (226 MB): only LAMB allocates it
         self._lamb_ws = (torch.zeros(L.load().dc_lamb_workspace_words(len(lay.params), lay.n_params), dtype=torch.float32, device=dev)
@@ -321,8 +324,7 @@ class ArenaOptimizer:
             self._scalars_copied.synchronize()
         self._lr_host[0] = float(self.param_groups[0]["lr"])
         self._step_host[0] = self.step_count
-        self.lr_dev.copy_(self._lr_host, non_blocking=True)
-        self.step_dev.copy_(self._step_host, non_blocking=True)
+        self._scal_dev.copy_(self._scal_host, non_blocking=True)
         self._scalars_copied = torch.cuda.current_stream().record_event()
 
     def launch(self) -> None:
@@ -491,10 +493,12 @@ class TrainStep:
         self.eng = net.engine_for(shape=(batch, net.n_input, height, width))
         self.weight = list(weight)
         dev = self.eng.device
-        self.loss_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+        # loss sum (one double) and the nine confusion counts behind it in ONE 80-byte buffer: one memset per step clears both
+        self._acc = torch.zeros(10, dtype=torch.int64, device=dev)
+        self.loss_sum = self._acc[:1].view(torch.float64)
         self.with_metrics = with_metrics
         self.pred = torch.empty((batch, height, width), dtype=torch.int64, device=dev) if with_metrics else None
-        self.counts = torch.zeros(9, dtype=torch.int64, device=dev) if with_metrics else None
+        self.counts = self._acc[1:] if with_metrics else None
         self.npix = batch * height * width
         self.after_backward = None      # set by attach_reducer
         self._eng_handle = _ops.engine_handle(self.eng)
@@ -518,9 +522,7 @@ class TrainStep:
 
     def launch(self, x: torch.Tensor, labels: torch.Tensor) -> None:
         eng = self.eng
-        L.call("dc_memset_async", L.dptr(self.loss_sum), 0, 8, L.stream_ptr())
-        if self.counts is not None:
-            L.call("dc_memset_async", L.dptr(self.counts), 0, 8 * self.counts.numel(), L.stream_ptr())
+        L.call("dc_memset_async", L.dptr(self._acc), 0, 80 if self.counts is not None else 8, L.stream_ptr())
         if self.fuse_head_loss:
             # the loss pass rides inside the classifier's forward kernel (dc_head_fwd_loss): the logits are neither stored nor re-read
             t = labels.squeeze(1) if labels.dim() == 4 else labels
