@@ -290,6 +290,17 @@ int dc_bn_bwd_apply_fin(int dtype, long M, int C, long count, const void* dout, 
                         const float* save_invstd, const float* slab, int rows, float* dgamma, float* dbeta, void* dy, int lddy,
                         void* g_out, int ldg, const float* mscale, const float* mshift, void* stream);
 
+/* SeparableConv2d_same.forward as ONE operator (deeplab_xception.py:62-66: depthwise 3x3 "same", then pointwise 1x1) for the entry flow's thin
+ * layers: d [N,H,W,Cin] = depthwise(act(x)) -- act = the producer's BatchNorm(+ReLU), applied on load when pscale / pshift are given, as in
+ * dc_dwconv_fwd, whose bits d has -- and y [N,H,W,Cout] = pointwise(d), with the BatchNorm partial sums of the stored y in slab
+ * [2][slab_rows][Cout] (NULL: none): the kernel fills dc_sepconv_fwd_rows(...) rows, one per workgroup, and zeroes the caller's other rows.
+ * Served (rows > 0): bf16, stride 1, dilation 1, Cout 128, Cin 64 / 128, H % 8 == 0, W % 16 (Cin 128) or 32 (Cin 64) == 0, at least 65 536
+ * pixels -- block 1 of the entry flow, where both halves are HBM-bound and d would otherwise be read back by a second launch.  wdw: the packed
+ * depthwise taps (dc_dwconv_pack_weights), wf: the packed pointwise forward operand (dc_conv_pack_weights). */
+int dc_sepconv_fwd_rows(int dtype, int Cin, int Cout, int stride, int dil, int N, int H, int W);
+int dc_sepconv_fwd(int dtype, int Cin, int Cout, int N, int H, int W, const void* x, int ldx, const float* pscale, const float* pshift,
+                   int prelu, const float* wdw, void* d, int ldd, const void* wf, void* y, int ldy, float* slab, int slab_rows, void* stream);
+
 /* dc_bn_bwd_apply of a BatchNorm + dc_conv_dgrad + the weight gradient of the pointwise (1x1, stride 1) conv in front of it in ONE pass over
  * (dout, y, x): dy = the BatchNorm's input gradient (relu 2: dout masked by y * mscale + mshift > 0; relu 0: no mask) is formed in registers,
  * rounded to bf16 as dc_bn_bwd_apply stores it, and feeds both products from LDS; it is never written.  dx [M][Cin] = dy . W (wb: the packed

@@ -471,6 +471,7 @@ extern "C" int dc_dw_set_option(const char* name, int value) {
   if (strcmp(name, "dw_cg") == 0) { dw_tile_set_cg(value); return 0; }
   if (strcmp(name, "dw_pipe") == 0) { dw_pipe_set(value); return 0; }
   if (strcmp(name, "pw_bn_bwd") == 0) { pw_bn_bwd_set(value); return 0; }
+  if (strcmp(name, "sep_fwd") == 0) { sep_fwd_set(value); return 0; }
   return -1;
 }
 

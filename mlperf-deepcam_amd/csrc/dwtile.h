@@ -38,6 +38,7 @@ int launch_dw_pipe(int dil, bool flip, const void* in, int ldin, const float* wp
                    const DwResStats* res = nullptr);
 void dw_pipe_set(int v);
 void pw_bn_bwd_set(int v);       // pwbwd.hip: tuning switch "pw_bn_bwd"
+void sep_fwd_set(int v);         // sepfwd.hip: tuning switch "sep_fwd"
 bool dw_pipe_forward();
 
 // stride-2 kernels (dwtile_s2.hip).  mode 0 forward, 1 data gradient (p1 = addend or null), 2 weight-gradient rows into the slab

@@ -204,7 +204,8 @@ class Engine:
         self.fuse_bn_bwd_fin = os.environ.get("DC_FUSE_BN_BWD_FIN", "1") != "0"    # dc_bn_bwd_finalize inside dc_bn_bwd_apply for short slabs
         # BatchNorm backward apply + pointwise data gradient + pointwise weight gradient of the entry flow's thin layers in one pass (dc_pw_bn_bwd)
         self.fuse_pw_bn_bwd = os.environ.get("DC_FUSE_PW_BN_BWD", "1") != "0"
-        self.fuse_head_wgrad = os.environ.get("DC_FUSE_HEAD_WGRAD", "1") != "0"     # the head's weight gradient inside its statistics pass
+        self.fuse_head_wgrad = os.environ.get("DC_FUSE_HEAD_WGRAD", "1") != "0"
+        self.fuse_sep_fwd = os.environ.get("DC_FUSE_SEP_FWD", "1") != "0"           # depthwise + pointwise forward of the thin layers in one kernel
         # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
         # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 40.31 -> 40.10 (round 3; 1 / 2 / 3 / 4 layers:
         # 40.31 / 40.28 / 40.10 / 40.18) -- the fp32 split slabs (256 KiB per workgroup whatever the batch) are a third of a 728-channel
@@ -375,6 +376,7 @@ class Engine:
         else:
             self.fwd_train.append(lambda: fwd(True))
             self.fwd_eval.append(lambda: fwd(False))
+            y.conv_fwd = {"wf": wf, "slab": slab, "rows": rows, "plain": k == 1 and stride == 1 and not transposed and bias is None and not f32 and out is None}
 
         def make_bwd():
             pwf = y.pw_fuse
@@ -526,6 +528,7 @@ class Engine:
         fwd_train = fwd
         self.fwd_train.append(fwd_train)
         self.fwd_eval.append(fwd)
+        y.dw_fwd = {"src": src, "ps": ps, "psh": psh, "prelu": prelu, "taps": pw, "stride": stride, "dil": dil}     # (_sep may fuse the forward)
 
         def make_bwd():
             dy = y.grad
@@ -725,6 +728,22 @@ class Engine:
         d = self._dw(x, s.prefix + ".conv1.weight", s.stride, s.dil, s.prefix + ".dw")
         y, slab, rows = self._conv(d, s.prefix + ".pointwise.weight", s.cout, stats=bool(s.bn), name=s.prefix + ".pw",
                                    bn_fuse=bool(s.bn) and residual is None)
+        # the entry flow's thin layers: depthwise + pointwise forward as ONE operator (dc_sepconv_fwd: d is written once and not read back);
+        # the two forward entries the builders above appended are replaced, everything backward stays as it is
+        dwf, cvf = getattr(d, "dw_fwd", None), getattr(y, "conv_fwd", None)
+        if (self.fuse_sep_fwd and dwf is not None and cvf is not None and cvf["plain"] and d.parent is None and
+                L.load().dc_sepconv_fwd_rows(self.dt, d.C, s.cout, dwf["stride"], dwf["dil"], d.N, d.H, d.W) > 0 and
+                (slab is None or L.load().dc_sepconv_fwd_rows(self.dt, d.C, s.cout, 1, 1, d.N, d.H, d.W) <= rows)):
+            src, wf_t = dwf["src"], cvf["wf"]
+
+            def sep_fwd(train: bool):
+                L.call("dc_sepconv_fwd", self.dt, d.C, s.cout, d.N, d.H, d.W, src.ptr, src.ld, dwf["ps"], dwf["psh"], dwf["prelu"], dwf["taps"],
+                       d.ptr, d.ld, L.dptr(wf_t), y.ptr, y.ld, L.dptr(slab) if (train and slab is not None) else None, rows if slab is not None else 0,
+                       self._st())
+            del self.fwd_train[-2:]
+            del self.fwd_eval[-2:]
+            self.fwd_train.append(lambda: sep_fwd(True))
+            self.fwd_eval.append(lambda: sep_fwd(False))
         if not s.bn:
             return y
         relu = s.relu_after if relu_override is None else relu_override

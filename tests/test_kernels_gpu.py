@@ -1812,3 +1812,61 @@ def test_pointwise_bn_backward_in_one_pass(name, cin, cout, N, H, W, relu):
     assert torch.equal(dx.float(), dx_ref.float()), name
     err = (gw.reshape(cout, cin).double() - gw_ref).abs().max().item()
     assert err <= 2e-5 * gw_ref.abs().max().item() + 1e-3, (name, err, gw_ref.abs().max().item())
+
+
+SEPFWD_CASES = [("b1_sep2_lazy", 128, 2, 192, 192, 1, 1), ("b1_sep1_stored", 64, 2, 192, 192, 0, 0), ("affine_lazy64", 64, 1, 264, 256, 1, 0),
+                ("one_row_of_tiles", 128, 1, 8, 8208, 0, 0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cin,N,H,W,lazy,relu", SEPFWD_CASES, ids=[c[0] for c in SEPFWD_CASES])
+def test_separable_conv_forward_as_one_operator(name, cin, N, H, W, lazy, relu):
+    """dc_sepconv_fwd (depthwise 3x3 + pointwise 1x1 of the entry flow's thin layers in one kernel, the producer's BatchNorm applied on load)
+    against dc_dwconv_fwd followed by dc_conv_fwd: the depthwise output and the pointwise output bit for bit, the BatchNorm sums after their
+    finalize-style column sums to fp32 accuracy; rows the kernel does not own are zeros; pad channels of the outputs untouched."""
+    dtype, dt, cout = torch.bfloat16, L.DC_BF16, 128
+    lib = L.load()
+    rows = lib.dc_sepconv_fwd_rows(dt, cin, cout, 1, 1, N, H, W)
+    assert rows > 0 and lib.dc_sepconv_fwd_rows(dt, cin, cout, 2, 1, N, H, W) == 0 and lib.dc_sepconv_fwd_rows(dt, 96, cout, 1, 1, N, H, W) == 0
+    assert lib.dc_sepconv_fwd_rows(dt, cin, cout, 1, 1, N, H + 4, W) == 0
+    g = torch.Generator().manual_seed(3)
+    xdev = (torch.randn(N, H, W, cin + 8, generator=g)).to(dtype).to(dev())
+    xv = xdev[..., :cin]
+    wm = rnd(cin, 1, 3, 3, seed=2, scale=1 / 3).to(dev())
+    wd = torch.empty(9 * cin, device=dev())
+    L.call("dc_dwconv_pack_weights", cin, vptr(wm), vptr(wd), S())
+    w = rnd(cout, cin, 1, 1, seed=6, scale=cin ** -0.5).to(dev())
+    d = L.ConvDesc(dt, 1, 1, 0, 1, 0, cin, cout)
+    nwf, nwb = C.c_size_t(), C.c_size_t()
+    L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
+    wf = torch.zeros(nwf.value, dtype=dtype, device=dev())
+    L.call("dc_conv_pack_weights", C.byref(d), vptr(w), vptr(wf), None, S())
+    sc = (rnd(cin, seed=7).abs() + 0.5).to(dev()) if lazy else None
+    sh = rnd(cin, seed=8, scale=0.3).to(dev()) if lazy else None
+    # two operators
+    _, d_ref = empty_nhwc(N, H, W, cin, dtype)
+    L.call("dc_dwconv_fwd", dt, cin, 1, 1, N, H, W, vptr(xv), cin + 8, vptr(wd), vptr(d_ref), cin, vptr(sc) if lazy else None, vptr(sh) if lazy else None,
+           relu, S())
+    _, y_ref = empty_nhwc(N, H, W, cout, dtype)
+    rows_ref = lib.dc_conv_stat_rows(C.byref(d), N, H, W)
+    slab_ref = torch.full((2, rows_ref, cout), float("nan"), device=dev())
+    L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(d_ref), cin, vptr(wf), None, vptr(y_ref), cout, vptr(slab_ref), 0, S())
+    # one operator
+    db, dv = empty_nhwc(N, H, W, cin, dtype, ld=cin + 16)
+    yb, yv = empty_nhwc(N, H, W, cout, dtype, ld=cout + 8)
+    slab = torch.full((2, rows_ref, cout), float("nan"), device=dev())
+    L.call("dc_sepconv_fwd", dt, cin, cout, N, H, W, vptr(xv), cin + 8, vptr(sc) if lazy else None, vptr(sh) if lazy else None, relu, vptr(wd),
+           vptr(dv), cin + 16, vptr(wf), vptr(yv), cout + 8, vptr(slab), rows_ref, S())
+    torch.cuda.synchronize()
+    assert torch.equal(dv.float(), d_ref.float()), name
+    assert torch.equal(yv.float(), y_ref.float()), name
+    assert torch.isnan(db[..., cin:].float()).all() and torch.isnan(yb[..., cout:].float()).all()
+    assert not torch.isnan(slab).any() and (slab[:, rows:] == 0).all()
+    got, want = slab.double().sum(1), slab_ref.double().sum(1)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-3), (name, (got - want).abs().max().item())
+    # eval mode: no statistics
+    yv.fill_(0)
+    L.call("dc_sepconv_fwd", dt, cin, cout, N, H, W, vptr(xv), cin + 8, vptr(sc) if lazy else None, vptr(sh) if lazy else None, relu, vptr(wd),
+           vptr(dv), cin + 16, vptr(wf), vptr(yv), cout + 8, None, 0, S())
+    torch.cuda.synchronize()
+    assert torch.equal(yv.float(), y_ref.float())
