@@ -225,6 +225,12 @@ int dc_dwconv_dgrad_bnstats_wgrad(int dtype, int C, int stride, int dil, int N, 
                                   const float* w_packed, void* dx, int lddx, const void* ybn, int ldybn, const float* save_mean,
                                   const float* save_invstd, const float* mscale, const float* mshift, int relu, float* slab,
                                   float* wslab, void* stream);
+/* The same when this layer is not the only reader of that BatchNorm's output: dx = conv^T(dy) + addend (what the other readers left; may alias
+ * dx), the sums are those of the complete gradient -- the caller makes this layer the LAST writer (stride 1). */
+int dc_dwconv_dgrad_bnstats_wgrad_add(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                      const float* w, const void* addend, int ldadd, void* dx, int lddx, const void* ybn, int ldybn,
+                                      const float* save_mean, const float* save_invstd, const float* mscale, const float* mshift, int relu,
+                                      float* slab, float* wslab, void* stream);
 /* The same fusion where the layer's forward input is a stored tensor x, or act(x*pscale + pshift) of one: data gradient (written, or
  * added onto `addend`: the first separable conv of an Xception block, whose input gradient joins the shortcut's) plus weight-gradient
  * rows; no BatchNorm sums. */

@@ -582,6 +582,29 @@ extern "C" int dc_dwconv_dgrad_bnstats_wgrad(int dtype, int C, int stride, int d
   return launch_dw_tile(dtype, dil, true, dy, lddy, w, nullptr, 0, dx, lddx, N, Hi, Wi, C, (hipStream_t)stream, nullptr, nullptr, 0, &bs);
 }
 
+// dc_dwconv_dgrad_bnstats_wgrad when this layer is not the only reader of the BatchNorm's output: the data gradient is added onto what the
+// other readers left in `addend` (may alias dx) and the sums are those of the COMPLETE gradient -- the caller makes this layer the last
+// writer (block 1's first depthwise layer behind the shortcut conv: the BatchNorm in front of both is bn2, whose 226 MB output gradient and
+// input a separate dc_bn_bwd_reduce pass would read once more).  Stride 1.
+extern "C" int dc_dwconv_dgrad_bnstats_wgrad_add(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                                 const float* w, const void* addend, int ldadd, void* dx, int lddx, const void* ybn, int ldybn,
+                                                 const float* save_mean, const float* save_invstd, const float* mscale, const float* mshift, int relu,
+                                                 float* slab, float* wslab, void* stream) {
+  if (int e = dw_check(dtype, C, stride, dil, N, Hi, Wi)) return e;
+  DC_REQUIRE(stride == 1, "dc_dwconv_dgrad_bnstats_wgrad_add: stride 1");
+  if (int e = dc_check_view(dy, lddy, C, dtype, "dc_dwconv_dgrad_bnstats_wgrad_add dy")) return e;
+  if (int e = dc_check_view(dx, lddx, C, dtype, "dc_dwconv_dgrad_bnstats_wgrad_add dx")) return e;
+  if (int e = dc_check_view(ybn, ldybn, C, dtype, "dc_dwconv_dgrad_bnstats_wgrad_add y")) return e;
+  if (addend != nullptr)
+    if (int e = dc_check_view(addend, ldadd, C, dtype, "dc_dwconv_dgrad_bnstats_wgrad_add addend")) return e;
+  DC_REQUIRE(w && save_mean && save_invstd && slab && wslab && mscale && mshift, "dc_dwconv_dgrad_bnstats_wgrad_add: null argument");
+  DC_REQUIRE(dc_dwconv_dgrad_wgrad_rows(dtype, C, stride, dil, N, Hi, Wi) > 0, "dc_dwconv_dgrad_bnstats_wgrad_add: shape not served");
+  DwBnStats bs;
+  bs.y = ybn; bs.ldy = ldybn; bs.mean = save_mean; bs.invstd = save_invstd; bs.mscale = mscale; bs.mshift = mshift; bs.relu = relu ? 1 : 0;
+  bs.slab = slab; bs.rows = 0; bs.wslab = wslab;
+  return launch_dw_tile(dtype, dil, true, dy, lddy, w, addend, ldadd, dx, lddx, N, Hi, Wi, C, (hipStream_t)stream, nullptr, nullptr, 0, &bs);
+}
+
 // Data gradient (optionally accumulated onto `addend`) plus this layer's weight-gradient rows when the layer's forward input is a
 // STORED tensor x (pscale == null) or act(x*pscale + pshift) of one: the first separable conv of an Xception block, whose input is the
 // block input and whose data gradient joins the shortcut's.

@@ -1,5 +1,5 @@
 // Persistent, software-pipelined stride-1 depthwise 3x3 (forward, data gradient with or without the BatchNorm sums / this layer's
-// weight gradient riding along): the bf16 layers with at least 128 channels on images whose extents are multiples of 8.
+// weight gradient riding along): the bf16 layers with at least 64 channels on images whose extents are multiples of 8.
 //
 // dwtile.hip's kernel is a grid of short-lived workgroups: request the halo tile, wait for ALL of it, (transform,) compute, store, exit;
 // 1 296 of them on 768 (or, for the 232-register fused data gradient, 512) slots.  On the 728-channel layers it moved 2.4 - 2.9 TB/s
@@ -511,7 +511,9 @@ extern "C" int dc_debug_dwp_stamps(unsigned long long* out) {
 
 // workgroups per channel block (= slab rows of the sums that ride along), 0: the shape is not served
 int dw_pipe_rows(int dtype, int C, int dil, int N, int H, int W) {
-  if (!g_dw_pipe || dtype != DC_BF16 || C < P_CH || (C & 7) || (H % P_TH) || (W % P_TW) || (dil != 1 && dil != 2)) return 0;
+  // (64 channels -- block 1's first depthwise layer, 226 MB of gradient at local batch 8 -- fill half of a 128-channel block: the idle lanes
+  // cost nothing beside one pass over dy that also takes the BatchNorm sums and the weight gradient)
+  if (!g_dw_pipe || dtype != DC_BF16 || C < P_CH / 2 || (C & 7) || (H % P_TH) || (W % P_TW) || (dil != 1 && dil != 2)) return 0;
   const int ncb = cdiv(C / 8, P_CG);
   const long ptiles = (long)N * (H / P_TH) * (W / P_TW);
   long wc = 256 / ncb;               // one workgroup per CU

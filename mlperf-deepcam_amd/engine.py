@@ -205,6 +205,7 @@ class Engine:
         # BatchNorm backward apply + pointwise data gradient + pointwise weight gradient of the entry flow's thin layers in one pass (dc_pw_bn_bwd)
         self.fuse_pw_bn_bwd = os.environ.get("DC_FUSE_PW_BN_BWD", "1") != "0"
         self.fuse_head_wgrad = os.environ.get("DC_FUSE_HEAD_WGRAD", "1") != "0"
+        self.fuse_bn_src_dw = os.environ.get("DC_FUSE_BN_SRC_DW", "1") != "0"       # a stored BatchNorm output's last depthwise reader takes its backward sums
         self.fuse_sep_fwd = os.environ.get("DC_FUSE_SEP_FWD", "1") != "0"           # depthwise + pointwise forward of the thin layers in one kernel
         # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
         # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 40.31 -> 40.10 (round 3; 1 / 2 / 3 / 4 layers:
@@ -557,9 +558,18 @@ class Engine:
                 res = None
             # the BatchNorm's make_bwd runs after this one: if it finds that ANOTHER consumer wrote the gradient later (this layer was not the
             # last writer after all), it cancels the fusion and this layer falls back to the plain fused data + weight gradient
-            fuse_state = {"res": res}
-            if res is not None:
-                x.fused_bwd_cancel = lambda: fuse_state.update(res=None)
+            # the stored input is a BatchNorm(+ReLU) output whose mask is recomputed from the BatchNorm's input (bn_src) and that several layers read
+            # (bn2: block 1's first depthwise layer and its shortcut conv): the depthwise layer, writing the gradient LAST, takes that BatchNorm's
+            # backward sums on the way (dc_dwconv_dgrad_bnstats_wgrad_add) instead of a dc_bn_bwd_reduce pass over the 226 MB gradient and input
+            bsrc = getattr(x, "bn_src", None) if (not lazy and res is None and wrows > 0 and srows == 0 and stride == 1 and self.fuse_bn_src_dw) else None
+            if bsrc is not None and getattr(x, "fused_bwd", 1) is None and x.parent is None:
+                bslab2 = self._f32(2 * wrows * Cc)
+                x.fused_bwd = (bslab2, wrows, x.grad_takes)
+            else:
+                bsrc = None
+            fuse_state = {"res": res, "bsrc": bsrc}
+            if res is not None or bsrc is not None:
+                x.fused_bwd_cancel = lambda: fuse_state.update(res=None, bsrc=None)
             ready = [wname]
             if wrows > 0:
                 # the rows stay in this layer's own slab until the next dense weight-gradient launch folds them (dc_fold_slabs); the
@@ -576,6 +586,12 @@ class Engine:
                     L.call("dc_dwconv_dgrad_wgrad_bnres", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
                            dx.ptr, dx.ld, src.ptr, src.ld, L.dptr(wslab), res["y"].ptr, res["y"].ld, L.dptr(res["mean"]), L.dptr(res["invstd"]),
                            res["relu"], L.dptr(rslab2), self._st())
+                    return
+                bs = fuse_state["bsrc"]
+                if bs is not None:
+                    L.call("dc_dwconv_dgrad_bnstats_wgrad_add", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
+                           dx.ptr, dx.ld, bs["y"].ptr, bs["y"].ld, L.dptr(bs["mean"]), L.dptr(bs["invstd"]), L.dptr(bs["scale"]), L.dptr(bs["shift"]),
+                           bs["relu"], L.dptr(bslab2), L.dptr(wslab), self._st())
                     return
                 if wrows > 0 and srows == 0:
                     L.call("dc_dwconv_dgrad_wgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,

@@ -88,6 +88,7 @@ _SIGS = {
     "dc_dwconv_dgrad_bnstats": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P, P, P, P, I, P, P]),
     "dc_dwconv_dgrad_wgrad_rows": (I, [I, I, I, I, I, I, I]),
     "dc_dwconv_dgrad_bnstats_wgrad": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P, P, P, P, I, P, P, P]),
+    "dc_dwconv_dgrad_bnstats_wgrad_add": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P, I, P, P, P, P, I, P, P, P]),
     "dc_dwconv_dgrad_wgrad": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P, I, P, P, I, P, P]),
     "dc_dwconv_dgrad_wgrad_bnres_rows": (I, [I, I, I, I, I, I, I]),
     "dc_dwconv_dgrad_wgrad_bnres": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P, I, P, P, I, P, P, I, P, P]),

@@ -975,7 +975,7 @@ def test_depthwise_tiled_matches_register_window_path():
 
 
 PIPE_CASES = [("728", 728, 1, 2, 16, 24), ("728_b8", 728, 1, 8, 48, 72), ("1024d2", 1024, 2, 2, 16, 16), ("1536", 1536, 1, 1, 8, 8),
-              ("128", 128, 1, 1, 40, 64), ("256_one_tile_each", 256, 1, 1, 8, 16)]
+              ("128", 128, 1, 1, 40, 64), ("256_one_tile_each", 256, 1, 1, 8, 16), ("64_half_block", 64, 1, 2, 40, 48)]
 
 
 @pytest.mark.parametrize("case", PIPE_CASES, ids=[c[0] for c in PIPE_CASES])
@@ -1032,6 +1032,25 @@ def test_depthwise_pipelined_kernel_matches_tiled(case):
             torch.cuda.synchronize()
             assert torch.equal(slab, slab2) and torch.equal(g3, g4) and torch.equal(g3, g1)
             out[f"stats{relu}"] = (dgam, dbet, gw)
+            # the same with an addend (this layer is the LAST of several writers of the gradient): dx = the accumulated gradient, the sums are
+            # those of it (against dc_bn_bwd_reduce over that dx), the weight gradient is unchanged
+            _, g6 = empty_nhwc(N, H, W, Cc, torch.bfloat16)
+            slab3 = torch.full((2, rows, Cc), float("nan"), device=dev())
+            wslab3 = torch.full((wrows, 9, Cc), float("nan"), device=dev())
+            gw3 = torch.full((Cc, 1, 3, 3), float("nan"), device=dev())
+            L.call("dc_dwconv_dgrad_bnstats_wgrad_add", dt, Cc, 1, dil, N, H, W, vptr(gyv), ld, vptr(wd), vptr(addv), Cc, vptr(g6), Cc, vptr(xv), ld,
+                   vptr(mean), vptr(invstd), vptr(sc), vptr(sh), relu, vptr(slab3), vptr(wslab3), S())
+            L.call("dc_dwconv_wgrad_reduce", Cc, wrows, vptr(wslab3), vptr(gw3), S())
+            M_ = N * H * W
+            rrows = lib.dc_bn_stat_rows(M_)
+            rslab = torch.full((2, rrows, Cc), float("nan"), device=dev())
+            L.call("dc_bn_bwd_reduce", dt, M_, Cc, vptr(g2), Cc, vptr(xv), ld, None, 0, 2 if relu else 0, vptr(mean), vptr(invstd), vptr(rslab), vptr(sc),
+                   vptr(sh), S())
+            torch.cuda.synchronize()
+            assert torch.equal(g6, g2)
+            want, got = rslab.double().sum(1), slab3.double().sum(1)
+            assert torch.allclose(got, want, rtol=1e-4, atol=1e-4 * float(want.abs().max())), (relu, (got - want).abs().max().item())
+            np.testing.assert_allclose(gw3.cpu().numpy(), gw.cpu().numpy(), rtol=3e-5, atol=3e-5 * float(gw.abs().max()))
         # stored (or lazily affine) layer input, addend, no statistics
         for aff in (0, 1):
             _, g5 = empty_nhwc(N, H, W, Cc, torch.bfloat16)
