@@ -685,7 +685,11 @@ struct PackEntry {
 //   P[t][a][b] (b contiguous) and Q[t][b][a] (a contiguous).  A conv ([cout][cin][t]) has wf = P, wb = Q; a transposed conv
 // ([cin][cout][t]) has wb = P, wf = Q.  (The first version stored single bf16 elements with a stride of one K row:
 // 0.9 ms per step for 56 M weights; a tile pass runs near copy speed.)
-constexpr int PACK_LDS_FLOATS = 32 * (32 * 9 + 1);   // 32 x 32 x 9 taps (+1 pad per row); also holds 64 x (64 + 1)
+constexpr int PACK_LDS_FLOATS = 32 * (32 * 9 + 1);   // fp32 storage: 32 x 32 x 9 taps (+1 pad per row); also holds 64 x (64 + 1)
+// bf16 storage: the 3 x 3 tiles sit in LDS already rounded (2 bytes per element, rows of 32 * 9 + 2), so the kernel's LDS is that of the
+// 64 x 65-float pointwise tile and seven workgroups fit a CU instead of three (the repack is a chain of short load - transpose - store lives)
+constexpr int PACK_ROW16 = 32 * 9 + 2;
+constexpr int PACK_LDS_FLOATS_BF16 = (32 * PACK_ROW16 * 2 + 3) / 4 > 64 * 65 ? (32 * PACK_ROW16 * 2 + 3) / 4 : 64 * 65;
 
 template <typename T>
 __device__ inline void pack_store_run(T* dst, float v0, float v1);
@@ -707,6 +711,40 @@ __device__ inline void pack_dense_tile(const PackEntry& e, int tile, float* lds)
   const int a0 = (tile / ntb) * TS, b0 = (tile % ntb) * TS;
   const int run = min(TS, B - b0) * TAPS;       // contiguous floats per master row of this tile
   __syncthreads();                              // previous tile fully written out
+  if constexpr (sizeof(T) == 2 && TAPS == 9) {
+    // bf16: rounded on the way into LDS (the same rounding the stores below did), two bytes per element
+    unsigned short* l16 = reinterpret_cast<unsigned short*>(lds);
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < TS * TS * TAPS; idx += 256) {
+      const int al = idx / (TS * TAPS), j = idx - al * (TS * TAPS);
+      float v = 0.f;
+      if (a0 + al < A && j < run) v = e.master[((size_t)(a0 + al) * B + b0) * TAPS + j];
+      l16[al * PACK_ROW16 + j] = __builtin_bit_cast(unsigned short, (bf16)v);
+    }
+    __syncthreads();
+    constexpr int UPR16 = TS / 2;
+    if (P != nullptr) {
+#pragma unroll 4
+      for (int idx = threadIdx.x; idx < TAPS * TS * UPR16; idx += 256) {
+        const int u = idx % UPR16, al = (idx / UPR16) % TS, t = idx / (UPR16 * TS);
+        const int bl = u * 2;
+        if (a0 + al < A && b0 + bl < B)
+          *reinterpret_cast<uint32_t*>(P + ((size_t)t * A + a0 + al) * ldp + b0 + bl) =
+              (uint32_t)l16[al * PACK_ROW16 + bl * TAPS + t] | ((uint32_t)l16[al * PACK_ROW16 + (bl + 1) * TAPS + t] << 16);
+      }
+    }
+    if (Q != nullptr) {
+#pragma unroll 4
+      for (int idx = threadIdx.x; idx < TAPS * TS * UPR16; idx += 256) {
+        const int u = idx % UPR16, bl = (idx / UPR16) % TS, t = idx / (UPR16 * TS);
+        const int al = u * 2;
+        if (b0 + bl < B && a0 + al < A)
+          *reinterpret_cast<uint32_t*>(Q + ((size_t)t * B + b0 + bl) * ldq + a0 + al) =
+              (uint32_t)l16[al * PACK_ROW16 + bl * TAPS + t] | ((uint32_t)l16[(al + 1) * PACK_ROW16 + bl * TAPS + t] << 16);
+      }
+    }
+    return;
+  }
 #pragma unroll 4
   for (int idx = threadIdx.x; idx < TS * TS * TAPS; idx += 256) {
     const int al = idx / (TS * TAPS), j = idx - al * (TS * TAPS);
@@ -810,7 +848,7 @@ constexpr int PACK_MAX_ENTRIES = 1024;
 // waited for 128 workgroups to chew through 512 tiles each -- 0.28 ms for 450 MB.)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_all_kernel(const PackEntry* __restrict__ table, int nentries) {
-  __shared__ float lds[PACK_LDS_FLOATS];
+  __shared__ float lds[sizeof(T) == 2 ? PACK_LDS_FLOATS_BF16 : PACK_LDS_FLOATS];
   __shared__ int prefix[PACK_MAX_ENTRIES + 1];
   for (int i = threadIdx.x; i < nentries; i += 256) prefix[i + 1] = pack_entry_tiles(table[i]);
   if (threadIdx.x == 0) prefix[0] = 0;

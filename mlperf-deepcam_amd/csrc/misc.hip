@@ -286,20 +286,36 @@ __global__ __launch_bounds__(256) void lamb_stage1_kernel(const int64_t* __restr
   }
 }
 
-// stage 2: every workgroup adds the chunk sums of its tensor in the same fixed order (at most ~1200 chunks), then updates its chunk
-__global__ __launch_bounds__(256) void lamb_stage2_kernel(const int64_t* __restrict__ offs, const int* __restrict__ chunk_prefix,
-                                                          int ntensors, float* __restrict__ p, const float* __restrict__ u,
-                                                          const float* lr_dev, const float* __restrict__ part, float wd) {
-  __shared__ double sh[4];
-  int t;
-  long beg, end;
-  if (!lamb_locate(offs, chunk_prefix, ntensors, t, beg, end)) return;
+// lr * trust ratio of tensor t = blockIdx.x: the chunk sums of the tensor in a fixed order (at most ~1200 chunks)
+__device__ inline float lamb_step_size(const int* __restrict__ chunk_prefix, int t, const float* lr_dev, const float* __restrict__ part, float wd,
+                                       double* sh) {
   const int c0 = chunk_prefix[t], nc = chunk_prefix[t + 1] - c0;
   const float wn = (float)sqrt(block_sum_fixed(part + 2 * (size_t)c0, nc, 2, sh));
   const float un = (float)sqrt(block_sum_fixed(part + 2 * (size_t)c0 + 1, nc, 2, sh));
   // apex FusedLAMB (use_nvlamb = False, its default): the trust ratio applies only to tensors with non-zero weight decay
   const float ratio = (wd != 0.f && wn > 0.f && un > 0.f) ? wn / un : 1.f;
-  const float a = *lr_dev * ratio;
+  return *lr_dev * ratio;
+}
+
+// one workgroup per tensor (stage 2's 14 000 workgroups each repeated the sum of their tensor's chunk norms: up to 1 152 pairs for the ASPP
+// kernels, as long as the 16 KiB of parameters a workgroup then updates)
+__global__ __launch_bounds__(256) void lamb_ratio_kernel(const int* __restrict__ chunk_prefix, int ntensors, const float* lr_dev,
+                                                         const float* __restrict__ part, float wd, float* __restrict__ step_size) {
+  __shared__ double sh[4];
+  const float a = lamb_step_size(chunk_prefix, blockIdx.x, lr_dev, part, wd, sh);
+  if (threadIdx.x == 0) step_size[blockIdx.x] = a;
+}
+
+// stage 2: the update of a chunk with its tensor's step size (step_size: lamb_ratio_kernel's; null: summed here, the same bits)
+__global__ __launch_bounds__(256) void lamb_stage2_kernel(const int64_t* __restrict__ offs, const int* __restrict__ chunk_prefix,
+                                                          int ntensors, float* __restrict__ p, const float* __restrict__ u,
+                                                          const float* lr_dev, const float* __restrict__ part, float wd,
+                                                          const float* __restrict__ step_size) {
+  __shared__ double sh[4];
+  int t;
+  long beg, end;
+  if (!lamb_locate(offs, chunk_prefix, ntensors, t, beg, end)) return;
+  const float a = step_size != nullptr ? step_size[t] : lamb_step_size(chunk_prefix, t, lr_dev, part, wd, sh);
   for (long i = beg + threadIdx.x; i < end; i += 256) p[i] = fmaf(-a, u[i], p[i]);
 }
 
@@ -474,8 +490,14 @@ extern "C" int dc_lamb_step(int ntensors, const int64_t* offsets_dev, long n, fl
   hipLaunchKernelGGL(lamb_stage1_kernel, dim3((unsigned)max_chunks), dim3(256), 0, st, offsets_dev, chunk_prefix, ntensors, p, g, upd,
                      m, v, beta1, beta2, eps, weight_decay, step_dev, max_grad_norm, grad_scale, gpartial, part);
   DC_CHECK_LAUNCH();
+  // the per-tensor step sizes go where the gradient partial sums were (stage 1 was their last reader)
+  float* step_size = ntensors <= SUMSQ_BLOCKS ? gpartial : nullptr;
+  if (step_size != nullptr) {
+    hipLaunchKernelGGL(lamb_ratio_kernel, dim3(ntensors), dim3(256), 0, st, chunk_prefix, ntensors, lr_dev, part, weight_decay, step_size);
+    DC_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(lamb_stage2_kernel, dim3((unsigned)max_chunks), dim3(256), 0, st, offsets_dev, chunk_prefix, ntensors, p, upd,
-                     lr_dev, part, weight_decay);
+                     lr_dev, part, weight_decay, step_size);
   DC_CHECK_LAUNCH();
   return 0;
 }
