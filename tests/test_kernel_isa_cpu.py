@@ -93,3 +93,20 @@ def test_pipelined_depthwise_tile_loops_hold_only_counted_memory_operations(tmp_
             body = lines[a:b]
             bad = [x.strip() for x in body if "scratch_" in x or re.search(r"\b(global|buffer|flat)_load_(?!lds)", x) and " lds" not in x]
             assert not bad, f"{name}: uncounted vector-memory operations inside the tile loop (asm lines {a}-{b}): {bad[:4]}"
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src,name,count,max_vgprs", [("pwbwd.hip", "pw_bn_bwd_kernel", 2, 256), ("pwbwd.hip", "pw_bn_bwd256_kernel", 2, 256),
+                                                      ("sepfwd.hip", "sepconv_fwd_kernel", 2, 256)])
+def test_one_pass_kernels_of_the_entry_flow_keep_their_occupancy(tmp_path, src, name, count, max_vgprs):
+    """The one-pass kernels of round 5 (pwbwd.hip, sepfwd.hip) are sized for TWO workgroups (or one 512-thread workgroup) per CU: 256 registers
+    per lane.  They hold their accumulators, the resident weight fragments and a stage of prefetched operands at 232 - 252 registers; a spill
+    would put scratch traffic into an HBM-bound loop and more registers would halve the workgroups per CU -- both silently."""
+    asm = _device_asm(src, tmp_path)
+    kernels = _kernels(asm, name)
+    assert len(kernels) == count, sorted(kernels)
+    for kname, lines in kernels.items():
+        assert not any("scratch_" in x for x in lines), f"{kname}: scratch access"
+        m = re.search(r"\.amdhsa_kernel %s\b.*?\.amdhsa_next_free_vgpr (\d+)" % re.escape(kname), asm, re.S)
+        assert m, kname
+        assert int(m.group(1)) <= max_vgprs, f"{kname}: {m.group(1)} registers"
