@@ -751,6 +751,10 @@ class Engine:
                 L.load().dc_sepconv_fwd_rows(self.dt, d.C, s.cout, dwf["stride"], dwf["dil"], d.N, d.H, d.W) > 0 and
                 (slab is None or L.load().dc_sepconv_fwd_rows(self.dt, d.C, s.cout, 1, 1, d.N, d.H, d.W) <= rows)):
             src, wf_t = dwf["src"], cvf["wf"]
+            if slab is not None:
+                # the kernel leaves one statistics row per workgroup: the BatchNorm behind it is told so (the slab _conv sized for one row per 128
+                # pixels is simply longer than needed), and its finalize needs no two-stage fold of 13 824 rows that are mostly zeros
+                rows = L.load().dc_sepconv_fwd_rows(self.dt, d.C, s.cout, 1, 1, d.N, d.H, d.W)
 
             def sep_fwd(train: bool):
                 L.call("dc_sepconv_fwd", self.dt, d.C, s.cout, d.N, d.H, d.W, src.ptr, src.ld, dwf["ps"], dwf["psh"], dwf["prelu"], dwf["taps"],
