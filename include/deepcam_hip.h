@@ -203,6 +203,16 @@ int dc_dwconv_pack_weights(int C, const float* master, float* packed, void* stre
  * raw conv output and every in-bounds element is read as act(x*pscale[c] + pshift[c]); padding stays zero. */
 int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,
                   const float* wp, void* y, int ldy, const float* pscale, const float* pshift, int prelu, void* stream);
+/* dc_dwconv_fwd through a training-mode BatchNorm(+ReLU) whose dc_bn_finalize it runs itself (SeparableConv2d_same after bn + relu inside a
+ * Block, deeplab_xception.py:83-98, at small batch): x is the raw output of the convolution in front of that BatchNorm, slab[2][rows][C]
+ * its partial sums with rows <= dc_bn_bwd_apply_fin_max_rows().  Every workgroup sums the slab for its own channels while its halo tile
+ * travels (order and bits of dc_bn_finalize); the workgroups of pixel tile 0 store scale / shift / save_mean / save_invstd and update
+ * the running statistics.  dc_dwconv_fwd_fin_ok: 1 when the shape is served (stride 1, dilation 1 or 2, the tiled kernel). */
+int dc_dwconv_fwd_fin_ok(int dtype, int C, int stride, int dil, int N, int Hi, int Wi);
+int dc_dwconv_fwd_fin(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx, const float* w, void* y, int ldy,
+                      int prelu, long count, const float* slab, int rows, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* scale, float* shift,
+                      float* save_mean, float* save_invstd, void* stream);
 /* dx = dw_backward_data(dy) [+ addend]  (addend: same shape as dx, e.g. the residual branch's gradient) */
 int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
                     const float* wp, const void* addend, int ldadd, void* dx, int lddx, void* stream);
@@ -273,6 +283,14 @@ int dc_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float*
 /* out = act(y*scale + shift [+ residual]),  act = ReLU when relu != 0 */
 int dc_bn_apply(int dtype, long M, int C, const void* y, int ldy, const float* scale, const float* shift,
                 const void* residual, int ldr, int relu, void* out, int ldo, void* stream);
+/* dc_bn_finalize + dc_bn_apply in one launch (nn.BatchNorm2d in training mode, deeplab_xception.py:104-119 block outputs at small batch):
+ * for a SHORT slab, rows <= dc_bn_bwd_apply_fin_max_rows(), every block of the apply kernel sums the slab for its own channels -- the order
+ * and the bits of dc_bn_finalize -- and block row 0 stores scale / shift / save_mean / save_invstd and updates the running statistics.
+ * The slab is read, not consumed. */
+int dc_bn_apply_fin(int dtype, long M, int C, long count, const void* y, int ldy, const float* slab, int rows, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                    float* scale, float* shift, float* save_mean, float* save_invstd, const void* residual, int ldr, int relu, void* out,
+                    int ldo, void* stream);
 /* backward, step 1: g = dout * (out > 0 if relu), partial sums of g and g*xhat -> slab[2][rows][C].
  * relu == 2: the activation was fused into its consumer and never stored; the mask is recomputed as
  * y*mscale[c] + mshift[c] > 0 (the forward scale/shift vectors), `out` is ignored. */

@@ -198,17 +198,39 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(long M, int C, const T* _
 template <typename T, int CGW>
 __global__ __launch_bounds__(256) void bn_apply_rows_kernel(long M, int C, int APPLY_ROWS, const T* __restrict__ y, int ldy,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            const T* __restrict__ res, int ldr, int relu, T* __restrict__ out, int ldo) {
+                                                            const T* __restrict__ res, int ldr, int relu, T* __restrict__ out, int ldo,
+                                                            const BnFinArgs fin) {
   constexpr int KPV = Elem<T>::kPerVec;
   constexpr int RL = 256 / CGW;
   const int cgl = threadIdx.x % CGW, rl = threadIdx.x / CGW;
   const int c0 = (blockIdx.x * CGW + cgl) * KPV;
-  if (c0 >= C) return;
   float sc[KPV], sh[KPV];
+  if (fin.slab != nullptr) {
+    // dc_bn_apply_fin: the finalize of a short slab by every block for its own channels (bn_fin.h: bn_short_fin); block row 0 stores
+    constexpr int CW = CGW * KPV;
+    __shared__ float fincoef[2][CW];
+    for (int i = threadIdx.x; i < CW; i += 256) {
+      const int c = blockIdx.x * CW + i;
+      float a = 0.f, b = 0.f;
+      if (c < C) bn_short_fin(fin, c, blockIdx.y == 0, a, b);
+      fincoef[0][i] = a;
+      fincoef[1][i] = b;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && fin.nbt != nullptr) *fin.nbt += 1;
+    __syncthreads();
+    if (c0 >= C) return;
 #pragma unroll
-  for (int e = 0; e < KPV; ++e) {
-    sc[e] = scale[c0 + e];
-    sh[e] = shift[c0 + e];
+    for (int e = 0; e < KPV; ++e) {
+      sc[e] = fincoef[0][cgl * KPV + e];
+      sh[e] = fincoef[1][cgl * KPV + e];
+    }
+  } else {
+    if (c0 >= C) return;
+#pragma unroll
+    for (int e = 0; e < KPV; ++e) {
+      sc[e] = scale[c0 + e];
+      sh[e] = shift[c0 + e];
+    }
   }
   const long rbeg = (long)blockIdx.y * APPLY_ROWS;
   const long rend = rbeg + APPLY_ROWS < M ? rbeg + APPLY_ROWS : M;
@@ -445,13 +467,9 @@ extern "C" int dc_bn_finalize(int C, long count, float* slab, int rows, const fl
                               float eps, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
   DC_REQUIRE(C > 0 && rows > 0 && slab && gamma && beta && scale && shift, "dc_bn_finalize: bad argument");
   if (count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
-  const double unbias = (double)count / (double)(count - 1);
-  BnFinArgs a;
   const int parts = fold_large_slab(slab, rows, C, (hipStream_t)stream);
-  a.slab = slab; a.rows = rows; a.C = C; a.parts = parts; a.inv_count = 1.0 / (double)count; a.unbias = unbias;
-  a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
-  a.nbt = reinterpret_cast<long long*>(num_batches_tracked); a.momentum = momentum; a.eps = eps;
-  a.scale = scale; a.shift = shift; a.save_mean = save_mean; a.save_invstd = save_invstd;
+  const BnFinArgs a = bn_fin_args(C, count, slab, rows, parts, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
+                                  shift, save_mean, save_invstd);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, (hipStream_t)stream, a);
   DC_CHECK_LAUNCH();
   return 0;
@@ -466,8 +484,10 @@ extern "C" int dc_bn_eval_coeffs(int C, const float* gamma, const float* beta, c
   return 0;
 }
 
-extern "C" int dc_bn_apply(int dtype, long M, int C, const void* y, int ldy, const float* scale, const float* shift,
-                           const void* residual, int ldr, int relu, void* out, int ldo, void* stream) {
+static int bn_apply_impl(int dtype, long M, int C, const void* y, int ldy, const float* scale, const float* shift,
+                         const void* residual, int ldr, int relu, void* out, int ldo, void* stream, const BnFinArgs* finp, int rows_per_block) {
+  BnFinArgs fin;
+  if (finp != nullptr) fin = *finp; else fin.slab = nullptr;
   if (int e = dc_check_view(y, ldy, C, dtype, "dc_bn_apply y")) return e;
   if (int e = dc_check_view(out, ldo, C, dtype, "dc_bn_apply out")) return e;
   if (residual)
@@ -478,10 +498,10 @@ extern "C" int dc_bn_apply(int dtype, long M, int C, const void* y, int ldy, con
   if (g_bn_apply_rows) {
     // bn_bwd_apply's block shape (a block as narrow as the tensor, rows per block growing with the row lanes)
     const int cgw = narrow_cg(C / kpv, g_bn_cgw);
-    const int APPLY_ROWS = g_bn_rows * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
+    const int APPLY_ROWS = (rows_per_block > 0 ? rows_per_block : g_bn_rows) * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
     if (cdiv(M, APPLY_ROWS) <= 65535) {
       const dim3 blocks2(cdiv(C / kpv, cgw), cdiv(M, APPLY_ROWS));
-#define BN_AR(TT, W) hipLaunchKernelGGL((bn_apply_rows_kernel<TT, W>), blocks2, dim3(256), 0, st, M, C, APPLY_ROWS, (const TT*)y, ldy, scale, shift, (const TT*)residual, ldr, relu, (TT*)out, ldo)
+#define BN_AR(TT, W) hipLaunchKernelGGL((bn_apply_rows_kernel<TT, W>), blocks2, dim3(256), 0, st, M, C, APPLY_ROWS, (const TT*)y, ldy, scale, shift, (const TT*)residual, ldr, relu, (TT*)out, ldo, fin)
       if (dtype == DC_BF16) { if (cgw == 64) BN_AR(bf16, 64); else if (cgw == 32) BN_AR(bf16, 32); else if (cgw == 16) BN_AR(bf16, 16); else if (cgw == 8) BN_AR(bf16, 8); else BN_AR(bf16, 4); }
       else                  { if (cgw == 64) BN_AR(float, 64); else if (cgw == 32) BN_AR(float, 32); else if (cgw == 16) BN_AR(float, 16); else if (cgw == 8) BN_AR(float, 8); else BN_AR(float, 4); }
 #undef BN_AR
@@ -489,6 +509,7 @@ extern "C" int dc_bn_apply(int dtype, long M, int C, const void* y, int ldy, con
       return 0;
     }
   }
+  DC_REQUIRE(finp == nullptr, "dc_bn_apply_fin: shape not served by the row-block kernel");
   const int blocks = ew_blocks(M * (C / kpv));
   if (dtype == DC_BF16)
     hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(blocks), dim3(256), 0, st, M, C, (const bf16*)y, ldy, scale, shift, (const bf16*)residual, ldr, relu, (bf16*)out, ldo);
@@ -496,6 +517,26 @@ extern "C" int dc_bn_apply(int dtype, long M, int C, const void* y, int ldy, con
     hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, M, C, (const float*)y, ldy, scale, shift, (const float*)residual, ldr, relu, (float*)out, ldo);
   DC_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int dc_bn_apply(int dtype, long M, int C, const void* y, int ldy, const float* scale, const float* shift,
+                           const void* residual, int ldr, int relu, void* out, int ldo, void* stream) {
+  return bn_apply_impl(dtype, M, C, y, ldy, scale, shift, residual, ldr, relu, out, ldo, stream, nullptr, 0);
+}
+
+// dc_bn_finalize + dc_bn_apply in one launch for a SHORT slab (rows <= dc_bn_bwd_apply_fin_max_rows()): every block sums the slab for its own
+// channels (same order, same bits as dc_bn_finalize), block row 0 stores scale / shift / save_mean / save_invstd and the running statistics.
+// Each block repeats 2 * rows * 256 loads, so it takes 64 rows of the tensor instead of 32.
+extern "C" int dc_bn_apply_fin(int dtype, long M, int C, long count, const void* y, int ldy, const float* slab, int rows, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                               float eps, float* scale, float* shift, float* save_mean, float* save_invstd, const void* residual, int ldr,
+                               int relu, void* out, int ldo, void* stream) {
+  DC_REQUIRE(C > 0 && slab && gamma && beta && scale && shift && rows > 0 && rows <= FIN_RL,
+             "dc_bn_apply_fin: needs a slab of at most dc_bn_bwd_apply_fin_max_rows() rows");
+  if (count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
+  const BnFinArgs a = bn_fin_args(C, count, slab, rows, 0, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
+                                  shift, save_mean, save_invstd);
+  return bn_apply_impl(dtype, M, C, y, ldy, scale, shift, residual, ldr, relu, out, ldo, stream, &a, 2 * g_bn_rows);
 }
 
 extern "C" int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int lddo, const void* y, int ldy,

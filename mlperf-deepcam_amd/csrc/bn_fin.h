@@ -23,6 +23,17 @@ struct BnFinArgs {
   float* save_invstd;
 };
 
+inline BnFinArgs bn_fin_args(int C, long count, const float* slab, int rows, int parts, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* scale,
+                             float* shift, float* save_mean, float* save_invstd) {
+  BnFinArgs a;
+  a.slab = slab; a.rows = rows; a.C = C; a.parts = parts; a.inv_count = 1.0 / (double)count; a.unbias = (double)count / (double)(count - 1);
+  a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+  a.nbt = reinterpret_cast<long long*>(num_batches_tracked); a.momentum = momentum; a.eps = eps;
+  a.scale = scale; a.shift = shift; a.save_mean = save_mean; a.save_invstd = save_invstd;
+  return a;
+}
+
 // Column sums of a [rows][C] fp32 slab in fp64: 4 channels x 64 row-lanes per 256-thread block, so that even the
 // 3456-row slabs of the 192x288 layers cost ~50 dependent loads per thread instead of thousands.  `ld(which, row)` returns element
 // (row, this thread's channel) of slab `which` as a double.
@@ -108,6 +119,24 @@ __device__ inline void slab_fold_block(float* slab, int rows, int C, double (&re
   }
 }
 
+// From the sums of one channel to its coefficients (and, with `store`, to the stored vectors and the running statistics).
+__device__ inline void bn_fin_coefs(const BnFinArgs& a, int c, double s, double q, bool store, float& sc, float& sh) {
+  const double mean = s * a.inv_count;
+  double var = q * a.inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float g = a.gamma[c], b = a.beta[c];
+  sc = g * invstd;
+  sh = b - (float)mean * sc;
+  if (!store) return;
+  a.scale[c] = sc;
+  a.shift[c] = sh;
+  if (a.save_mean) a.save_mean[c] = (float)mean;
+  if (a.save_invstd) a.save_invstd[c] = invstd;
+  if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+  if (a.running_var) a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)(var * a.unbias);
+}
+
 // One 4-channel block of dc_bn_finalize (256 threads; red: 4 KiB of LDS).
 __device__ inline void bn_finalize_block(const BnFinArgs& a, int cblock, double (&red)[2][FIN_RL][FIN_CH]) {
   const int C = a.C;
@@ -116,18 +145,24 @@ __device__ inline void bn_finalize_block(const BnFinArgs& a, int cblock, double 
   slab_colsum2(SlabLoad{a.slab, a.slab + (size_t)a.rows * C, C, c, a.parts}, a.parts ? a.parts : a.rows, c < C, red, s, q);
   if (cblock == 0 && threadIdx.x == 0 && a.nbt != nullptr) *a.nbt += 1;
   if (threadIdx.x >= FIN_CH || c >= C) return;
-  const double mean = s * a.inv_count;
-  double var = q * a.inv_count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
-  const float g = a.gamma[c], b = a.beta[c];
-  const float sc = g * invstd;
-  a.scale[c] = sc;
-  a.shift[c] = b - (float)mean * sc;
-  if (a.save_mean) a.save_mean[c] = (float)mean;
-  if (a.save_invstd) a.save_invstd[c] = invstd;
-  if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
-  if (a.running_var) a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)(var * a.unbias);
+  float sc, sh;
+  bn_fin_coefs(a, c, s, q, true, sc, sh);
+}
+
+// dc_dwconv_fwd_fin / dc_bn_apply_fin: the finalize of a SHORT slab (at most FIN_RL rows, not folded) done by the kernel that consumes the
+// coefficients, every workgroup for its own channels: the rows in sequence in fp64, which is the order slab_colsum2 has for such a slab (one
+// row per row lane, the lanes added in sequence), then bn_fin_coefs -- the same bits as dc_bn_finalize, one launch and one dependent kernel
+// boundary less per BatchNorm.  `store`: this workgroup is the one that writes the vectors and the running statistics of channel c.
+__device__ inline void bn_short_fin(const BnFinArgs& a, int c, bool store, float& sc, float& sh) {
+  double s = 0.0, q = 0.0;
+  const float* s0 = a.slab + c;
+  const float* s1 = a.slab + (size_t)a.rows * a.C + c;
+#pragma unroll 16
+  for (int r = 0; r < a.rows; ++r) {
+    s += (double)s0[(size_t)r * a.C];
+    q += (double)s1[(size_t)r * a.C];
+  }
+  bn_fin_coefs(a, c, s, q, store, sc, sh);
 }
 
 }  // namespace dc

@@ -6,6 +6,7 @@
 
 #include "common.h"
 #include "dwtile.h"
+#include "bn_fin.h"
 #include "dwtile_common.h"
 
 namespace dc {
@@ -498,6 +499,28 @@ extern "C" int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int H
     return launch_dw_tile_s2(dtype, 0, N, Hi, Wi, C, x, ldx, w, nullptr, 0, y, ldy, nullptr, nullptr, st, pscale, pshift, prelu);
   return dtype == DC_BF16 ? launch_dw<bf16, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st, pscale, pshift, prelu)
                           : launch_dw<float, 0>(x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, Ho, Wo, C, stride, dil, st, pscale, pshift, prelu);
+}
+
+// dc_dwconv_fwd reading through a BatchNorm(+ReLU) whose finalize it runs itself: the producer left a SHORT slab of partial sums
+// (rows <= dc_bn_bwd_apply_fin_max_rows()), every workgroup sums it for its own channels while its halo tile travels (same order, same bits as
+// dc_bn_finalize), the workgroups of pixel tile 0 store scale / shift / save_mean / save_invstd and the running statistics.
+extern "C" int dc_dwconv_fwd_fin_ok(int dtype, int C, int stride, int dil, int N, int Hi, int Wi) {
+  return g_dw_tile && !dw_pipe_forward() && stride == 1 && (dil == 1 || dil == 2) && (dtype == DC_BF16 || dtype == DC_F32) &&
+         C % (dtype == DC_BF16 ? 8 : 4) == 0;
+}
+extern "C" int dc_dwconv_fwd_fin(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx, const float* w,
+                                 void* y, int ldy, int prelu, long count, const float* slab, int rows, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                                 float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+  if (int e = dw_check(dtype, C, stride, dil, N, Hi, Wi)) return e;
+  if (int e = dc_check_view(x, ldx, C, dtype, "dc_dwconv_fwd_fin x")) return e;
+  if (int e = dc_check_view(y, ldy, C, dtype, "dc_dwconv_fwd_fin y")) return e;
+  DC_REQUIRE(w && slab && gamma && beta && scale && shift && rows > 0, "dc_dwconv_fwd_fin: null argument");
+  DC_REQUIRE(dc_dwconv_fwd_fin_ok(dtype, C, stride, dil, N, Hi, Wi), "dc_dwconv_fwd_fin: shape not served (dc_dwconv_fwd_fin_ok)");
+  if (count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
+  const BnFinArgs a = bn_fin_args(C, count, slab, rows, 0, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
+                                  shift, save_mean, save_invstd);
+  return launch_dw_tile(dtype, dil, false, x, ldx, w, nullptr, 0, y, ldy, N, Hi, Wi, C, (hipStream_t)stream, nullptr, nullptr, prelu, nullptr, &a);
 }
 
 extern "C" int dc_dwconv_dgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,

@@ -6,6 +6,7 @@
 namespace dc {
 
 struct DwBnStats;   // dwtile_common.h
+struct BnFinArgs;   // bn_fin.h
 // the BatchNorm whose stored output relu(bn(y) + residual) is a depthwise layer's input: its backward sums ride along with that layer's data
 // gradient (dwpipe.hip, PM_RES)
 struct DwResStats {
@@ -21,7 +22,7 @@ constexpr int DWT_MAX_ROWS = 2048;   // most partial rows the weight-gradient sl
 
 int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
                    void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale = nullptr,
-                   const float* pshift = nullptr, int prelu = 0, const DwBnStats* bnstats = nullptr);
+                   const float* pshift = nullptr, int prelu = 0, const DwBnStats* bnstats = nullptr, const BnFinArgs* fin = nullptr);
 int dw_tile_rows(int dtype, int C, int N, int H, int W);   // pixel tiles of the stride-1 kernels = slab rows of the fused BN statistics
 int launch_dw_tile_wgrad(int dtype, int dil, const void* x, int ldx, const void* dy, int lddy, float* slab, float* grad_w, int N,
                          int H, int W, int C, hipStream_t st, const float* pscale = nullptr, const float* pshift = nullptr, int prelu = 0);

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "dwtile.h"
 #include "dwtile_common.h"
+#include "bn_fin.h"
 
 namespace dc {
 
@@ -68,7 +69,7 @@ template <typename T, int DIL, bool FLIP, int CG, bool WG = false>
 __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int ldin, const float* __restrict__ wp,
                                                   const T* __restrict__ addend, int ldadd, T* __restrict__ out, int ldout, int H, int W,
                                                   int C, int ncgb, int ntx, int nty, const float* __restrict__ pscale,
-                                                  const float* __restrict__ pshift, int prelu, const DwBnStats st) {
+                                                  const float* __restrict__ pshift, int prelu, const DwBnStats st, const BnFinArgs fin) {
   typedef TileCfg<DIL, CG> K;
   constexpr int KPV = Elem<T>::kPerVec, KH = KPV / 2;
   constexpr int WC = DT_PX + 2 * DIL;
@@ -89,9 +90,30 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
   const int ch0 = cok ? cg0 * KPV + h * KH : 0;                          // first of this thread's channels
   float wk[9][KH];
   load_taps<KH>(wp, ch0, C, FLIP, wk);
+  const float* ps = pscale;
+  const float* psh = pshift;
+  int cbase = 0;
+  if constexpr (!FLIP && !WG) {
+    // dc_dwconv_fwd_fin: the producer's BatchNorm finalize over a short slab, by every workgroup for its own channels while its halo
+    // travels (bn_fin.h: bn_short_fin); the workgroup of pixel tile 0 stores the vectors the backward pass reads
+    __shared__ float fincoef[2][CG * KPV];
+    if (fin.slab != nullptr) {
+      for (int i = threadIdx.x; i < CG * KPV; i += 256) {
+        const int c = cg0 * KPV + i;
+        float sc = 0.f, sh = 0.f;
+        if (c < C) bn_short_fin(fin, c, tile_id == 0, sc, sh);
+        fincoef[0][i] = sc;
+        fincoef[1][i] = sh;
+      }
+      if (t == 0 && threadIdx.x == 0 && fin.nbt != nullptr) *fin.nbt += 1;
+      ps = fincoef[0];
+      psh = fincoef[1];
+      cbase = cg0 * KPV;
+    }
+  }
   __syncthreads();   // vmcnt(0) + barrier: the whole halo tile has landed
-  if (!FLIP && pscale != nullptr) {   // fused BatchNorm(+ReLU) of the producer, applied once per staged element
-    bn_transform_tile<T, K::HH, K::HW, CG>(smem, y0 - DIL, x0 - DIL, H, W, pscale, pshift, prelu, cg0, ngroups);
+  if (!FLIP && ps != nullptr) {   // fused BatchNorm(+ReLU) of the producer, applied once per staged element
+    bn_transform_tile<T, K::HH, K::HW, CG>(smem, y0 - DIL, x0 - DIL, H, W, ps, psh, prelu, cg0, ngroups, cbase);
     __syncthreads();
   }
   const bool stats = FLIP && st.slab != nullptr;
@@ -425,35 +447,39 @@ size_t dw_tile_wgrad_workspace(int C, int N, int H, int W) {
 
 template <typename T, int DIL, bool FLIP, int CG>
 static void launch_fwd1(const TileGrid& t, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out,
-                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats& bs) {
+                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats& bs, const BnFinArgs& fin) {
   if constexpr (FLIP) {
     if (bs.wslab != nullptr) {          // data gradient + BatchNorm sums + this layer's weight-gradient rows
       constexpr int FOLD = TileCfg<DIL, CG>::NSL * 9 * CG * Elem<T>::kPerVec * (int)sizeof(float);
       constexpr int LDSW = TileCfg<DIL, CG>::LDS_BYTES > FOLD ? TileCfg<DIL, CG>::LDS_BYTES : FOLD;
       DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, true, CG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSW));
       hipLaunchKernelGGL((dwt_kernel<T, DIL, true, CG, true>), dim3(t.ntiles * t.ncgb), dim3(256), LDSW, st, (const T*)in, ldin, wp,
-                         (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs);
+                         (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs, fin);
       return;
     }
   }
   constexpr int LDS = TileCfg<DIL, CG>::LDS_BYTES;
   DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, FLIP, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   hipLaunchKernelGGL((dwt_kernel<T, DIL, FLIP, CG>), dim3(t.ntiles * t.ncgb), dim3(256), LDS, st, (const T*)in, ldin, wp,
-                     (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs);
+                     (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs, fin);
 }
 
 template <typename T, int DIL, bool FLIP>
 static void launch_fwd2(const TileGrid& t, const void* in, int ldin, const float* wp, const void* addend, int ldadd, void* out,
-                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats& bs) {
-  if (t.cg == 32) launch_fwd1<T, DIL, FLIP, 32>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs);
-  else if (t.cg == 16) launch_fwd1<T, DIL, FLIP, 16>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs);
-  else launch_fwd1<T, DIL, FLIP, 8>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs);
+                        int ldout, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu, const DwBnStats& bs, const BnFinArgs& fin) {
+  if (t.cg == 32) launch_fwd1<T, DIL, FLIP, 32>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs, fin);
+  else if (t.cg == 16) launch_fwd1<T, DIL, FLIP, 16>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs, fin);
+  else launch_fwd1<T, DIL, FLIP, 8>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs, fin);
 }
 
 int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, const float* wp, const void* addend, int ldadd,
                    void* out, int ldout, int N, int H, int W, int C, hipStream_t st, const float* pscale, const float* pshift, int prelu,
-                   const DwBnStats* bnstats) {
+                   const DwBnStats* bnstats, const BnFinArgs* finp) {
   const int kpv = dtype == DC_BF16 ? 8 : 4;
+  BnFinArgs fin;
+  if (finp != nullptr) fin = *finp; else fin.slab = nullptr;
+  DC_REQUIRE(finp == nullptr || (!flip && !dw_pipe_forward() && finp->rows <= FIN_RL && finp->parts == 0),
+             "dc_dwconv_fwd_fin: a forward pass on the tiled kernel over a slab of at most dc_bn_bwd_apply_fin_max_rows() rows");
   // the persistent pipelined kernel serves the data gradients (52.0 -> 41.5 us with BatchNorm sums and weight gradient on the 728-channel
   // layers at local batch 8); the forward pass stays here unless option "dw_pipe" = 2 (23.4 vs 24.1 us plain, 34.5 vs 31.7 us with the
   // BatchNorm applied on load: its in-place transform pass costs eight waves more than it costs three co-resident workgroups)
@@ -464,7 +490,7 @@ int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, cons
   DwBnStats bs;
   if (bnstats != nullptr) bs = *bnstats; else { bs.slab = nullptr; bs.y = nullptr; bs.ldy = 0; bs.mean = bs.invstd = bs.mscale = bs.mshift = nullptr; bs.relu = 0; bs.rows = 0; bs.wslab = nullptr; }
   if (bs.slab != nullptr) bs.rows = t.ntiles;
-#define DWT(TT, D, F) launch_fwd2<TT, D, F>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs)
+#define DWT(TT, D, F) launch_fwd2<TT, D, F>(t, in, ldin, wp, addend, ldadd, out, ldout, H, W, C, st, pscale, pshift, prelu, bs, fin)
   if (dtype == DC_BF16) {
     if (dil == 1) { if (flip) DWT(bf16, 1, true); else DWT(bf16, 1, false); }
     else          { if (flip) DWT(bf16, 2, true); else DWT(bf16, 2, false); }

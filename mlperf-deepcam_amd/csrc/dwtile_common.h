@@ -137,16 +137,16 @@ __device__ inline void bn_acc_store(float* red, const float (&a)[KH], const floa
 // coefficients live in registers.  Call between two workgroup barriers.
 template <typename T, int HH, int HW, int CG>
 __device__ inline void bn_transform_tile(char* smem, int iy0, int ix0, int H, int W, const float* __restrict__ pscale,
-                                         const float* __restrict__ pshift, int prelu, int cg0, int ngroups) {
+                                         const float* __restrict__ pshift, int prelu, int cg0, int ngroups, int cbase = 0) {
   constexpr int KPV = Elem<T>::kPerVec;
   constexpr int HP = HH * HW, ITER = (HP * CG + 255) / 256;
   const int tid = threadIdx.x, g = tid % CG;
   if (cg0 + g >= ngroups) return;
-  float sc[KPV], sh[KPV];
+  float sc[KPV], sh[KPV];        // (cbase: the vectors start at channel cbase -- a workgroup's own coefficients in LDS)
 #pragma unroll
   for (int e = 0; e < KPV; ++e) {
-    sc[e] = pscale[(cg0 + g) * KPV + e];
-    sh[e] = pshift[(cg0 + g) * KPV + e];
+    sc[e] = pscale[(cg0 + g) * KPV + e - cbase];
+    sh[e] = pshift[(cg0 + g) * KPV + e - cbase];
   }
 #pragma unroll 2
   for (int it = 0; it < ITER; ++it) {

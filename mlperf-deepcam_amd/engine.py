@@ -202,6 +202,11 @@ class Engine:
         # the last writer of that output's gradient (dc_dwconv_dgrad_wgrad_bnres) instead of a dc_bn_bwd_reduce pass over three tensors
         self.fuse_bn_res = os.environ.get("DC_FUSE_BN_RES", "1") != "0"
         self.fuse_bn_bwd_fin = os.environ.get("DC_FUSE_BN_BWD_FIN", "1") != "0"    # dc_bn_bwd_finalize inside dc_bn_bwd_apply for short slabs
+        # dc_bn_finalize inside the kernel that consumes the coefficients (dc_dwconv_fwd_fin, dc_bn_apply_fin) for short slabs of small tensors
+        self.fuse_bn_fwd_fin = os.environ.get("DC_FUSE_BN_FWD_FIN", "1") != "0"
+        # timing experiments only: "fwd" / "bwd" / "both" leave out the BatchNorm finalize launches (results are then garbage): what the
+        # 77 + 78 tiny kernels and the dispatch gaps around them cost the chain
+        self._debug_skip_finalize = os.environ.get("DC_DEBUG_SKIP_BN_FINALIZE", "")
         # BatchNorm backward apply + pointwise data gradient + pointwise weight gradient of the entry flow's thin layers in one pass (dc_pw_bn_bwd)
         self.fuse_pw_bn_bwd = os.environ.get("DC_FUSE_PW_BN_BWD", "1") != "0"
         self.fuse_head_wgrad = os.environ.get("DC_FUSE_HEAD_WGRAD", "1") != "0"
@@ -269,9 +274,6 @@ class Engine:
         self.on_grad_ready: Optional[Callable[[List[str]], None]] = None
         self._debug_skip_side = os.environ.get("DC_DEBUG_SKIP_SIDE", "0") == "1"
         self._debug_skip_kind = os.environ.get("DC_DEBUG_SKIP_KIND", "")     # "_conv" / "_dw": skip that kind of weight gradient (timing only)
-        # timing experiments only: "fwd" / "bwd" / "both" leave out the BatchNorm finalize launches (results are then garbage): what the
-        # 77 + 78 tiny kernels and the dispatch gaps around them cost the chain
-        self._debug_skip_finalize = os.environ.get("DC_DEBUG_SKIP_BN_FINALIZE", "")
         self.region_marks: Optional[list] = None      # bench.py sets a list to collect (name, event) at the encoder boundaries
         self.loss_args: Optional[dict] = None         # set per call by nn.TrainStep (DC_FUSE_HEAD_LOSS): loss inside the classifier's kernel
 
@@ -527,9 +529,17 @@ class Engine:
             L.call("dc_dwconv_fwd", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, pw, y.ptr, y.ld, ps, psh, prelu, self._st())
 
         fwd_train = fwd
+        fin = getattr(x, "fin", None) if lazy else None
+        if fin is not None and not fin["taken"] and lib.dc_dwconv_fwd_fin_ok(self.dt, Cc, stride, dil, N, H, W):
+            fin["taken"] = True           # this layer runs the BatchNorm's finalize itself (dc_dwconv_fwd_fin)
+
+            def fwd_train():
+                L.call("dc_dwconv_fwd_fin", self.dt, Cc, stride, dil, N, H, W, src.ptr, src.ld, pw, y.ptr, y.ld, prelu, *fin["args"], self._st())
+        else:
+            fin = None
         self.fwd_train.append(fwd_train)
         self.fwd_eval.append(fwd)
-        y.dw_fwd = {"src": src, "ps": ps, "psh": psh, "prelu": prelu, "taps": pw, "stride": stride, "dil": dil}     # (_sep may fuse the forward)
+        y.dw_fwd = {"fin": fin is not None, "src": src, "ps": ps, "psh": psh, "prelu": prelu, "taps": pw, "stride": stride, "dil": dil}     # (_sep may fuse the forward)
 
         def make_bwd():
             dy = y.grad
@@ -635,7 +645,19 @@ class Engine:
         rptr = (lambda: residual.ptr) if residual is not None else (lambda: None)
         rld = residual.ld if residual is not None else 0
 
+        # a short slab of a small tensor (the 54 rows the 128-pixel tiles leave at local batch 2 on the 48 x 72 layers): the consumer of the
+        # coefficients sums it itself, every workgroup for its own channels (same bits): one launch and one dependent boundary less per
+        # BatchNorm.  Lazy: the depthwise layer that reads through this BatchNorm takes it (_dw sets fin["taken"])
+        fin = None
+        if self.fuse_bn_fwd_fin and rows <= lib.dc_bn_bwd_apply_fin_max_rows() and M <= 8192 and not self._debug_skip_finalize:
+            fin = {"taken": False, "args": (M, L.dptr(slab), rows, gam, bet, rm, rv, nbt, BN_MOMENTUM, BN_EPS, L.dptr(scale), L.dptr(shift),
+                                            L.dptr(mean), L.dptr(invstd))}
+
         def fwd_train():
+            if fin is not None and (fin["taken"] or not lazy):
+                if not lazy:
+                    L.call("dc_bn_apply_fin", bdt, M, Cc, M, y.ptr, y.ld, *fin["args"][1:], rptr(), rld, relu_i, o.ptr, o.ld, self._st())
+                return
             if self._debug_skip_finalize == "async":
                 # (timing experiment with realistic data: the finalize runs unordered on a stream of its own, the chain uses the previous
                 # step's coefficients)
@@ -658,6 +680,7 @@ class Engine:
         lz = LazyAct(y, scale, shift, relu, (name or bname) + ".lazy") if lazy else None
         if lz is not None:
             lz.mean, lz.invstd, lz.fused_bwd = mean, invstd, None
+            lz.fin = fin
         elif residual is None and out is None and (self.mask_from_y or not relu):
             # a stored BatchNorm(+ReLU) output whose ReLU mask is recomputed from y: a sole dense-conv consumer may take this
             # BatchNorm's backward sums in its data-gradient epilogue (_conv(..., sole_consumer=True), the classifier head)
@@ -747,7 +770,7 @@ class Engine:
         # the entry flow's thin layers: depthwise + pointwise forward as ONE operator (dc_sepconv_fwd: d is written once and not read back);
         # the two forward entries the builders above appended are replaced, everything backward stays as it is
         dwf, cvf = getattr(d, "dw_fwd", None), getattr(y, "conv_fwd", None)
-        if (self.fuse_sep_fwd and dwf is not None and cvf is not None and cvf["plain"] and d.parent is None and
+        if (self.fuse_sep_fwd and dwf is not None and not dwf["fin"] and cvf is not None and cvf["plain"] and d.parent is None and
                 L.load().dc_sepconv_fwd_rows(self.dt, d.C, s.cout, dwf["stride"], dwf["dil"], d.N, d.H, d.W) > 0 and
                 (slab is None or L.load().dc_sepconv_fwd_rows(self.dt, d.C, s.cout, 1, 1, d.N, d.H, d.W) <= rows)):
             src, wf_t = dwf["src"], cvf["wf"]

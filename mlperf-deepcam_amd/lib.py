@@ -83,6 +83,8 @@ _SIGS = {
     "dc_colsum_workspace": (SZ, [L, I]),
     "dc_dwconv_pack_weights": (I, [I, P, P, P]),
     "dc_dwconv_fwd": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, P, I, P]),
+    "dc_dwconv_fwd_fin_ok": (I, [I, I, I, I, I, I, I]),
+    "dc_dwconv_fwd_fin": (I, [I, I, I, I, I, I, I, P, I, P, P, I, I, L, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),
     "dc_dwconv_dgrad": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P]),
     "dc_dwconv_dgrad_bnstats_rows": (I, [I, I, I, I, I, I, I]),
     "dc_dwconv_dgrad_bnstats": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P, P, P, P, I, P, P]),
@@ -100,6 +102,7 @@ _SIGS = {
     "dc_bn_finalize": (I, [I, L, P, I, P, P, P, P, P, F, F, P, P, P, P, P]),
     "dc_bn_eval_coeffs": (I, [I, P, P, P, P, F, P, P, P]),
     "dc_bn_apply": (I, [I, L, I, P, I, P, P, P, I, I, P, I, P]),
+    "dc_bn_apply_fin": (I, [I, L, I, L, P, I, P, I, P, P, P, P, P, F, F, P, P, P, P, P, I, I, P, I, P]),
     "dc_bn_bwd_reduce": (I, [I, L, I, P, I, P, I, P, I, I, P, P, P, P, P, P]),
     "dc_bn_bwd_finalize": (I, [I, P, I, P, P, P]),
     "dc_bn_bwd_apply": (I, [I, L, I, L, P, I, P, I, P, I, I, P, P, P, P, P, P, I, P, I, P, P, P]),

@@ -942,6 +942,82 @@ def test_depthwise_dgrad_with_fused_weight_gradient(case, dtype, relu):
     np.testing.assert_allclose(gw.cpu().numpy(), gw_sep.cpu().numpy(), rtol=2e-5, atol=2e-5 * float(gw_sep.abs().max()))
 
 
+FIN_CASES = [("mid_b2", torch.bfloat16, 728, 1, 2, 48, 72, 54), ("exit_d2", torch.bfloat16, 1536, 2, 1, 20, 24, 7),
+             ("ragged", torch.bfloat16, 256, 1, 3, 11, 13, 64), ("one_row", torch.bfloat16, 128, 1, 1, 8, 8, 1),
+             ("f32", torch.float32, 64, 1, 2, 18, 14, 9)]
+
+
+@pytest.mark.parametrize("case", FIN_CASES, ids=[c[0] for c in FIN_CASES])
+def test_batchnorm_finalize_inside_its_consumer(case):
+    """A short slab of BatchNorm partial sums (at most dc_bn_bwd_apply_fin_max_rows() rows) is summed by the kernel that consumes the
+    coefficients, every workgroup for its own channels: dc_dwconv_fwd_fin against dc_bn_finalize + dc_dwconv_fwd, dc_bn_apply_fin against
+    dc_bn_finalize + dc_bn_apply -- outputs, stored vectors and running statistics bit for bit (nn.BatchNorm2d in training mode inside a Block,
+    deeplab_xception.py:83-119)."""
+    _, dtype, Cc, dil, N, H, W, rows = case
+    dt = L.dtype_code(dtype)
+    lib = L.load()
+    assert rows <= lib.dc_bn_bwd_apply_fin_max_rows() and lib.dc_dwconv_fwd_fin_ok(dt, Cc, 1, dil, N, H, W) == 1
+    M = N * H * W
+    y = q(rnd(N, Cc, H, W, seed=21) * 1.5 + 0.25, dtype)
+    res = q(rnd(N, Cc, H, W, seed=22), dtype)
+    ld = (Cc + 63) // 64 * 64
+    _, yv = to_nhwc(y, dtype, ld=ld)
+    _, rv_ = to_nhwc(res, dtype)
+    # partial sums as a producer's epilogue leaves them: `rows` rows that add up to the tensor's column sums
+    yf = from_nhwc(yv).permute(0, 2, 3, 1).reshape(M, Cc).float().to(dev())
+    bounds = np.linspace(0, M, rows + 1).astype(int)
+    slab = torch.stack([torch.stack([yf[a:b].sum(0) for a, b in zip(bounds[:-1], bounds[1:])]),
+                        torch.stack([(yf[a:b] ** 2).sum(0) for a, b in zip(bounds[:-1], bounds[1:])])]).contiguous()
+    gamma, beta = (torch.rand(Cc) + 0.5).to(dev()), rnd(Cc, seed=23, scale=0.3).to(dev())
+    wm = rnd(Cc, 1, 3, 3, seed=24, scale=1 / 3).to(dev())
+    wd = torch.empty(9 * Cc, device=dev())
+    L.call("dc_dwconv_pack_weights", Cc, vptr(wm), vptr(wd), S())
+
+    def state():
+        st = {"rm": rnd(Cc, seed=25).to(dev()), "rv": (torch.rand(Cc, generator=torch.Generator().manual_seed(26)) + 0.5).to(dev()),
+              "nbt": torch.full((1,), 5, dtype=torch.int64, device=dev())}
+        for k in ("scale", "shift", "mean", "invstd"):
+            st[k] = torch.full((Cc,), float("nan"), device=dev())
+        return st
+
+    def fin_args(st):
+        return (vptr(slab), rows, vptr(gamma), vptr(beta), vptr(st["rm"]), vptr(st["rv"]), vptr(st["nbt"]), 0.1, 1e-5, vptr(st["scale"]),
+                vptr(st["shift"]), vptr(st["mean"]), vptr(st["invstd"]))
+
+    def same_state(a, b):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+        assert int(a["nbt"]) == 6
+
+    for prelu in (1, 0):
+        ref, got = state(), state()
+        L.call("dc_bn_finalize", Cc, M, *fin_args(ref), S())
+        _, d_ref = empty_nhwc(N, H, W, Cc, dtype)
+        L.call("dc_dwconv_fwd", dt, Cc, 1, dil, N, H, W, vptr(yv), ld, vptr(wd), vptr(d_ref), Cc, vptr(ref["scale"]), vptr(ref["shift"]), prelu, S())
+        db, d_got = empty_nhwc(N, H, W, Cc, dtype, ld=Cc + 16, off=8)
+        L.call("dc_dwconv_fwd_fin", dt, Cc, 1, dil, N, H, W, vptr(yv), ld, vptr(wd), vptr(d_got), Cc + 16, prelu, M, *fin_args(got), S())
+        torch.cuda.synchronize()
+        assert torch.equal(d_got.float(), d_ref.float()) and torch.isnan(db[..., :8].float()).all() and torch.isnan(db[..., 8 + Cc:].float()).all()
+        same_state(ref, got)
+        for use_res in (True, False):
+            got = state()
+            _, o_ref = empty_nhwc(N, H, W, Cc, dtype)
+            L.call("dc_bn_apply", dt, M, Cc, vptr(yv), ld, vptr(ref["scale"]), vptr(ref["shift"]), vptr(rv_) if use_res else None, Cc, prelu,
+                   vptr(o_ref), Cc, S())
+            ob, o_got = empty_nhwc(N, H, W, Cc, dtype, ld=Cc + 16, off=8)
+            L.call("dc_bn_apply_fin", dt, M, Cc, M, vptr(yv), ld, *fin_args(got), vptr(rv_) if use_res else None, Cc, prelu, vptr(o_got),
+                   Cc + 16, S())
+            torch.cuda.synchronize()
+            assert torch.equal(o_got.float(), o_ref.float()) and torch.isnan(ob[..., :8].float()).all() and torch.isnan(ob[..., 8 + Cc:].float()).all()
+            same_state(ref, got)
+    # against torch on the real statistics
+    o = F.batch_norm(from_nhwc(yv).float().cpu(), None, None, gamma.cpu(), beta.cpu(), True, 0.1, 1e-5)
+    assert_close(from_nhwc(o_got), o, dtype, bf16=2e-2)
+    # a slab longer than the kernels take is refused
+    with pytest.raises(L.DeepcamHipError):
+        L.call("dc_bn_apply_fin", dt, M, Cc, M, vptr(yv), ld, vptr(slab), 65, *fin_args(state())[2:], None, 0, 0, vptr(o_got), Cc + 16, S())
+
+
 @pytest.mark.parametrize("tpb", [3, 50])
 def test_depthwise_wgrad_several_tiles_per_workgroup(tpb):
     """The weight-gradient planner gives a workgroup several tiles only on large layers; force it on a small one."""
