@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(long M, int C, const T* _
 // thread's channels never change, so scale / shift live in registers and four rows are in flight per thread.  The grid-stride kernel above
 // divides a 64-bit element index by the channel-group count and re-loads sixteen coefficients for every 16 bytes it moves (5.0 TB/s on the
 // 728-channel block outputs where this layout's backward twin reaches 5.9); same arithmetic, same bits.
-template <typename T, int CGW>
+template <typename T, int CGW, bool FIN = false>      // (FIN: an instantiation of its own -- the finalize's 64 loads in flight cost 36 registers)
 __global__ __launch_bounds__(256) void bn_apply_rows_kernel(long M, int C, int APPLY_ROWS, const T* __restrict__ y, int ldy,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const T* __restrict__ res, int ldr, int relu, T* __restrict__ out, int ldo,
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void bn_apply_rows_kernel(long M, int C, int A
   const int cgl = threadIdx.x % CGW, rl = threadIdx.x / CGW;
   const int c0 = (blockIdx.x * CGW + cgl) * KPV;
   float sc[KPV], sh[KPV];
-  if (fin.slab != nullptr) {
+  if constexpr (FIN) {
     // dc_bn_apply_fin: the finalize of a short slab by every block for its own channels (bn_fin.h: bn_short_fin); block row 0 stores
     constexpr int CW = CGW * KPV;
     __shared__ float fincoef[2][CW];
@@ -314,14 +314,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, int AP
         // bn_bwd_finalize_kernel's order (rows in sequence, fp64) and rounded to fp32 as that kernel stores them: same bits, one launch
         // and one dependent kernel boundary less per BatchNorm.  The row blocks of a channel block all compute the same numbers; block
         // row 0 stores the parameter gradients.
-        double sb = 0.0, sg = 0.0;
-        const float* s0 = fin_slab + c;
-        const float* s1 = fin_slab + (size_t)fin_rows * C + c;
-#pragma unroll 16
-        for (int r = 0; r < fin_rows; ++r) {
-          sb += (double)s0[(size_t)r * C];
-          sg += (double)s1[(size_t)r * C];
-        }
+        double sb, sg;
+        slab_seq_sum2(fin_slab, fin_rows, C, c, sb, sg);
         db = (float)sb;
         dg = (float)sg;
         if (blockIdx.y == 0) {
@@ -501,7 +495,8 @@ static int bn_apply_impl(int dtype, long M, int C, const void* y, int ldy, const
     const int APPLY_ROWS = (rows_per_block > 0 ? rows_per_block : g_bn_rows) * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
     if (cdiv(M, APPLY_ROWS) <= 65535) {
       const dim3 blocks2(cdiv(C / kpv, cgw), cdiv(M, APPLY_ROWS));
-#define BN_AR(TT, W) hipLaunchKernelGGL((bn_apply_rows_kernel<TT, W>), blocks2, dim3(256), 0, st, M, C, APPLY_ROWS, (const TT*)y, ldy, scale, shift, (const TT*)residual, ldr, relu, (TT*)out, ldo, fin)
+#define BN_AR(TT, W) do { if (finp != nullptr) hipLaunchKernelGGL((bn_apply_rows_kernel<TT, W, true>), blocks2, dim3(256), 0, st, M, C, APPLY_ROWS, (const TT*)y, ldy, scale, shift, (const TT*)residual, ldr, relu, (TT*)out, ldo, fin); \
+                          else hipLaunchKernelGGL((bn_apply_rows_kernel<TT, W, false>), blocks2, dim3(256), 0, st, M, C, APPLY_ROWS, (const TT*)y, ldy, scale, shift, (const TT*)residual, ldr, relu, (TT*)out, ldo, fin); } while (0)
       if (dtype == DC_BF16) { if (cgw == 64) BN_AR(bf16, 64); else if (cgw == 32) BN_AR(bf16, 32); else if (cgw == 16) BN_AR(bf16, 16); else if (cgw == 8) BN_AR(bf16, 8); else BN_AR(bf16, 4); }
       else                  { if (cgw == 64) BN_AR(float, 64); else if (cgw == 32) BN_AR(float, 32); else if (cgw == 16) BN_AR(float, 16); else if (cgw == 8) BN_AR(float, 8); else BN_AR(float, 4); }
 #undef BN_AR

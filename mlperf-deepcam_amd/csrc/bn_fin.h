@@ -153,15 +153,25 @@ __device__ inline void bn_finalize_block(const BnFinArgs& a, int cblock, double 
 // coefficients, every workgroup for its own channels: the rows in sequence in fp64, which is the order slab_colsum2 has for such a slab (one
 // row per row lane, the lanes added in sequence), then bn_fin_coefs -- the same bits as dc_bn_finalize, one launch and one dependent kernel
 // boundary less per BatchNorm.  `store`: this workgroup is the one that writes the vectors and the running statistics of channel c.
-__device__ inline void bn_short_fin(const BnFinArgs& a, int c, bool store, float& sc, float& sh) {
-  double s = 0.0, q = 0.0;
-  const float* s0 = a.slab + c;
-  const float* s1 = a.slab + (size_t)a.rows * a.C + c;
-#pragma unroll 16
-  for (int r = 0; r < a.rows; ++r) {
-    s += (double)s0[(size_t)r * a.C];
-    q += (double)s1[(size_t)r * a.C];
+// (the two column sums of a short slab, rows in sequence, for channel c)
+__device__ inline void slab_seq_sum2(const float* __restrict__ slab, int rows, int C, int c, double& s, double& q) {
+  s = q = 0.0;
+  const float* s0 = slab + c;
+  const float* s1 = slab + (size_t)rows * C + c;
+  // (sixteen rows of both sums in flight: measured against 64 loads in flight -- everything a wave may have outstanding -- the step at local
+  // batch 2 is 0.13 ms SLOWER with the deeper batch: every workgroup of the launch reads the same few hundred lines at the same moment)
+#ifndef DC_FIN_UNROLL
+#define DC_FIN_UNROLL 16
+#endif
+#pragma unroll DC_FIN_UNROLL
+  for (int r = 0; r < rows; ++r) {
+    s += (double)s0[(size_t)r * C];
+    q += (double)s1[(size_t)r * C];
   }
+}
+__device__ inline void bn_short_fin(const BnFinArgs& a, int c, bool store, float& sc, float& sh) {
+  double s, q;
+  slab_seq_sum2(a.slab, a.rows, a.C, c, s, q);
   bn_fin_coefs(a, c, s, q, store, sc, sh);
 }
 
