@@ -6,7 +6,7 @@ from mlperf_deepcam_amd import lib as L
 dev = torch.device("cuda", 0); dt = L.DC_BF16; lib = L.load(); st = L.stream_ptr(); P = L.dptr
 NB, REPS = 4, 40
 for (Cc, H, W, N, dil) in [(728, 48, 72, 8, 1), (256, 192, 288, 8, 1), (128, 384, 576, 8, 1), (1536, 48, 72, 8, 2)]:
-    ld = (Cc + 31) // 32 * 32; M = N * H * W; T = M * ld * 2
+    ld = (Cc + 63) // 64 * 64; M = N * H * W; T = M * ld * 2
     act = lambda: [torch.randn(N, H, W, ld, device=dev).to(torch.bfloat16) for _ in range(NB)]
     x, y, dy, dx, add = act(), act(), act(), act(), act()
     wp = torch.randn(9 * Cc, device=dev) * 0.2
