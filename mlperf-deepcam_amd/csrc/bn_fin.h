@@ -158,15 +158,28 @@ __device__ inline void slab_seq_sum2(const float* __restrict__ slab, int rows, i
   s = q = 0.0;
   const float* s0 = slab + c;
   const float* s1 = slab + (size_t)rows * C + c;
-  // (sixteen rows of both sums in flight: measured against 64 loads in flight -- everything a wave may have outstanding -- the step at local
-  // batch 2 is 0.13 ms SLOWER with the deeper batch: every workgroup of the launch reads the same few hundred lines at the same moment)
-#ifndef DC_FIN_UNROLL
-#define DC_FIN_UNROLL 16
+  // Sixteen rows of both sums are requested before the first is added (written out as a batch: left to itself the compiler issues one load,
+  // waits, adds -- 108 round trips beyond L2 for a 54-row slab, 0.7 ms per step at local batch 2).  Why sixteen: against 64 loads in flight --
+  // everything a wave may have outstanding -- the step is 0.13 ms SLOWER with the deeper batch (every workgroup of the launch reads the same
+  // few hundred lines at the same moment), 8 and 4 rows are 0.08 / 0.16 ms slower.  Rows past the end re-read the last row and add +0.0,
+  // which leaves a partial sum as it is.
+#ifndef DC_FIN_ROWS
+#define DC_FIN_ROWS 16
 #endif
-#pragma unroll DC_FIN_UNROLL
-  for (int r = 0; r < rows; ++r) {
-    s += (double)s0[(size_t)r * C];
-    q += (double)s1[(size_t)r * C];
+  constexpr int FB = DC_FIN_ROWS;
+  for (int r0 = 0; r0 < rows; r0 += FB) {
+    float x[FB], y[FB];
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+      const int r = r0 + i < rows ? r0 + i : rows - 1;
+      x[i] = s0[(size_t)r * C];
+      y[i] = s1[(size_t)r * C];
+    }
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+      s += (double)(r0 + i < rows ? x[i] : 0.f);
+      q += (double)(r0 + i < rows ? y[i] : 0.f);
+    }
   }
 }
 __device__ inline void bn_short_fin(const BnFinArgs& a, int c, bool store, float& sc, float& sh) {

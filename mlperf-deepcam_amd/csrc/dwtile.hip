@@ -65,7 +65,8 @@ __device__ inline void stage_halo(char* smem, const T* __restrict__ in, int ldin
 }
 
 // forward (FLIP = false) and data gradient (FLIP = true: the same stencil with the taps reversed, plus an optional addend)
-template <typename T, int DIL, bool FLIP, int CG, bool WG = false>
+// FIN (forward only): an instantiation of its own -- its 2 KiB of coefficients beside the 52 KiB halo tile would take the third workgroup off a CU
+template <typename T, int DIL, bool FLIP, int CG, bool WG = false, bool FIN = false>
 __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int ldin, const float* __restrict__ wp,
                                                   const T* __restrict__ addend, int ldadd, T* __restrict__ out, int ldout, int H, int W,
                                                   int C, int ncgb, int ntx, int nty, const float* __restrict__ pscale,
@@ -93,11 +94,11 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
   const float* ps = pscale;
   const float* psh = pshift;
   int cbase = 0;
-  if constexpr (!FLIP && !WG) {
+  if constexpr (FIN) {
     // dc_dwconv_fwd_fin: the producer's BatchNorm finalize over a short slab, by every workgroup for its own channels while its halo
     // travels (bn_fin.h: bn_short_fin); the workgroup of pixel tile 0 stores the vectors the backward pass reads
     __shared__ float fincoef[2][CG * KPV];
-    if (fin.slab != nullptr) {
+    {
       for (int i = threadIdx.x; i < CG * KPV; i += 256) {
         const int c = cg0 * KPV + i;
         float sc = 0.f, sh = 0.f;
@@ -459,6 +460,14 @@ static void launch_fwd1(const TileGrid& t, const void* in, int ldin, const float
     }
   }
   constexpr int LDS = TileCfg<DIL, CG>::LDS_BYTES;
+  if constexpr (!FLIP) {
+    if (fin.slab != nullptr) {
+      DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, false, CG, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+      hipLaunchKernelGGL((dwt_kernel<T, DIL, false, CG, false, true>), dim3(t.ntiles * t.ncgb), dim3(256), LDS, st, (const T*)in, ldin, wp,
+                         (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs, fin);
+      return;
+    }
+  }
   DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, FLIP, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   hipLaunchKernelGGL((dwt_kernel<T, DIL, FLIP, CG>), dim3(t.ntiles * t.ncgb), dim3(256), LDS, st, (const T*)in, ldin, wp,
                      (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs, fin);
