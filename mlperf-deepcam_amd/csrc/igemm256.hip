@@ -591,11 +591,24 @@ int igemm256_splitk_plan(const IgemmParams& p, size_t* slab_bytes) {
   if (slab_bytes) *slab_bytes = 0;
   if (!g_splitk || p.g.os != 1 || p.m_beg != 0 || p.bias != nullptr || p.accumulate || p.bst.y != nullptr || (p.g.Cout & 7)) return 1;
   const long tiles = igemm256_tiles(p);
-  if (tiles < 1 || tiles > 128) return 1;
+  if (tiles < 1) return 1;
   const int ngk = ((p.g.Cin + BK - 1) / BK + 3) / 4;
-  int s = (int)(256 / tiles);
-  if (s > ngk / 2) s = ngk / 2;
-  if (s > 8) s = 8;
+  int s = 1;
+  if (tiles <= 128) {
+    s = (int)(256 / tiles);
+    if (s > ngk / 2) s = ngk / 2;
+    if (s > 8) s = 8;
+  } else if (g_splitk > 1) {
+    // more than one round with a thin last one (the grouped atrous launch at local batch 8: 324 tiles of 576 K steps, the second round a
+    // quarter full): the split count of 2 - 4 that fills the rounds best, if it fills them at least a tenth better than the plain launch
+    auto fill = [](long n) { return (double)n / (double)(((n + 255) / 256) * 256); };
+    double best = fill(tiles) + 0.10;
+    for (int c = 2; c <= 4 && c <= ngk / 2; ++c)
+      if (fill(tiles * c) > best) {
+        best = fill(tiles * c);
+        s = c;
+      }
+  }
   if (s < 2) return 1;
   if (slab_bytes) *slab_bytes = (size_t)s * tiles * TM * TN * sizeof(float);
   return s;
