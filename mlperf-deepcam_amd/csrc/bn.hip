@@ -209,12 +209,29 @@ __global__ __launch_bounds__(256) void bn_apply_rows_kernel(long M, int C, int A
     // dc_bn_apply_fin: the finalize of a short slab by every block for its own channels (bn_fin.h: bn_short_fin); block row 0 stores
     constexpr int CW = CGW * KPV;
     __shared__ float fincoef[2][CW];
-    for (int i = threadIdx.x; i < CW; i += 256) {
-      const int c = blockIdx.x * CW + i;
-      float a = 0.f, b = 0.f;
-      if (c < C) bn_short_fin(fin, c, blockIdx.y == 0, a, b);
-      fincoef[0][i] = a;
-      fincoef[1][i] = b;
+    if constexpr (CW <= 256) {
+      __shared__ double finred[2][4][CW];
+      double s, q;
+      slab_quad_sum2<CW>(fin.slab, fin.rows, C, blockIdx.x * CW, finred, s, q);
+      if (threadIdx.x < CW) {
+        const int c = blockIdx.x * CW + threadIdx.x;
+        float a = 0.f, b = 0.f;
+        if (c < C) bn_fin_coefs(fin, c, s, q, blockIdx.y == 0, a, b);
+        fincoef[0][threadIdx.x] = a;
+        fincoef[1][threadIdx.x] = b;
+      }
+    } else {
+      for (int i = threadIdx.x; i < CW; i += 256) {
+        const int c = blockIdx.x * CW + i;
+        float a = 0.f, b = 0.f;
+        if (c < C) {
+          double s, q;
+          slab_quad_sum2_thread(fin.slab, fin.rows, C, c, s, q);
+          bn_fin_coefs(fin, c, s, q, blockIdx.y == 0, a, b);
+        }
+        fincoef[0][i] = a;
+        fincoef[1][i] = b;
+      }
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && fin.nbt != nullptr) *fin.nbt += 1;
     __syncthreads();
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, const float
   __shared__ double red[2][FIN_RL][FIN_CH];
   const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
   double s, q;
-  slab_colsum2(SlabLoad{slab, slab + (size_t)rows * C, C, c, parts}, parts ? parts : rows, c < C, red, s, q);
+  slab_colsum2(SlabLoad{slab, slab + (size_t)rows * C, C, c, parts}, parts ? parts : rows, c < C, red, s, q, slab_is_short(rows, parts));
   if (threadIdx.x >= FIN_CH || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
@@ -304,18 +321,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, int AP
   // dy = ca*g + cb*(x - mean) + cd.  The block's coefficients are computed once, by one thread per channel, and handed out
   // through LDS: fetching the seven per-channel vectors in every thread cost as many load instructions as 8 rows of data.
   __shared__ __attribute__((aligned(16))) float coef[6][CW];
+  // dc_bn_bwd_apply_fin: the finalize of a SHORT slab (at most FIN_RL rows) done here, by every block for its own channels, in
+  // bn_bwd_finalize_kernel's order (bn_fin.h: the quad order, fp64) and rounded to fp32 as that kernel stores them: same bits, one launch
+  // and one dependent kernel boundary less per BatchNorm.  The row blocks of a channel block all compute the same numbers; block
+  // row 0 stores the parameter gradients.
+  double fsb = 0.0, fsg = 0.0;      // thread i < CW: the two sums of channel blockIdx.x * CW + i
+  if constexpr (CW <= 256) {
+    __shared__ double finred[2][4][CW];
+    if (fin_slab != nullptr) slab_quad_sum2<CW>(fin_slab, fin_rows, C, blockIdx.x * CW, finred, fsb, fsg);
+  }
   for (int i = threadIdx.x; i < CW; i += 256) {
     const int c = blockIdx.x * CW + i;
     float a = 0.f, b = 0.f, d = 0.f, m = 0.f, s1 = 0.f, s2 = 0.f;
     if (c < C) {
       float dg, db;
       if (fin_slab != nullptr) {
-        // dc_bn_bwd_apply_fin: the finalize of a SHORT slab (at most FIN_RL rows) done here, by every block for its own channels, in
-        // bn_bwd_finalize_kernel's order (rows in sequence, fp64) and rounded to fp32 as that kernel stores them: same bits, one launch
-        // and one dependent kernel boundary less per BatchNorm.  The row blocks of a channel block all compute the same numbers; block
-        // row 0 stores the parameter gradients.
-        double sb, sg;
-        slab_seq_sum2(fin_slab, fin_rows, C, c, sb, sg);
+        double sb = fsb, sg = fsg;
+        if constexpr (CW > 256) slab_quad_sum2_thread(fin_slab, fin_rows, C, c, sb, sg);
         db = (float)sb;
         dg = (float)sg;
         if (blockIdx.y == 0) {

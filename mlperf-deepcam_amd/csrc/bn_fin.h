@@ -38,8 +38,11 @@ inline BnFinArgs bn_fin_args(int C, long count, const float* slab, int rows, int
 // 3456-row slabs of the 192x288 layers cost ~50 dependent loads per thread instead of thousands.  `ld(which, row)` returns element
 // (row, this thread's channel) of slab `which` as a double.
 constexpr int FIN_CH = 4, FIN_RL = 64;
+// `quad` (a short slab, rows <= FIN_RL: one row per row lane): the lanes are summed as FOUR interleaved sequences p_j = row j + row j+4 + ...,
+// then (p0 + p1) + (p2 + p3) -- the order in which the kernels that run the finalize themselves can take the slab with 16-byte loads, four
+// row lanes per channel quad (slab_quad_sum2 below): same bits either way.
 template <typename Load>
-__device__ inline void slab_colsum2(Load ld, int rows, bool ok, double (&red)[2][FIN_RL][FIN_CH], double& a, double& b) {
+__device__ inline void slab_colsum2(Load ld, int rows, bool ok, double (&red)[2][FIN_RL][FIN_CH], double& a, double& b, bool quad = false) {
   const int cl = threadIdx.x & (FIN_CH - 1), rl = threadIdx.x / FIN_CH;
   // FIN_UR independent partial sums per thread and slab: with two loads in flight the kernel was a chain of ~100 memory latencies on
   // the largest slabs; the partials are combined in a fixed order
@@ -76,13 +79,27 @@ __device__ inline void slab_colsum2(Load ld, int rows, bool ok, double (&red)[2]
   __syncthreads();
   a = b = 0.0;
   if (threadIdx.x < FIN_CH) {
+    if (quad) {
+      double pa[4] = {0.0, 0.0, 0.0, 0.0}, pb[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+      for (int i = 0; i < FIN_RL; i += 4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pa[j] += red[0][i + j][threadIdx.x];
+          pb[j] += red[1][i + j][threadIdx.x];
+        }
+      a = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+      b = (pb[0] + pb[1]) + (pb[2] + pb[3]);
+    } else {
 #pragma unroll 8
-    for (int i = 0; i < FIN_RL; ++i) {
-      a += red[0][i][threadIdx.x];
-      b += red[1][i][threadIdx.x];
+      for (int i = 0; i < FIN_RL; ++i) {
+        a += red[0][i][threadIdx.x];
+        b += red[1][i][threadIdx.x];
+      }
     }
   }
 }
+inline __host__ __device__ bool slab_is_short(int rows, int parts) { return parts == 0 && rows <= FIN_RL; }
 
 // Slabs of thousands of rows (one row per 128-pixel tile: 3456 on the 192 x 288 layers, 13 824 on the 384 x 576 ones) leave the finalize
 // kernels with C / 4 workgroups of 50 - 200 dependent rows per thread (8 workgroups for the 32-channel stem; 36 - 80 us per launch).
@@ -142,50 +159,84 @@ __device__ inline void bn_finalize_block(const BnFinArgs& a, int cblock, double 
   const int C = a.C;
   const int c = cblock * FIN_CH + (threadIdx.x & (FIN_CH - 1));
   double s, q;
-  slab_colsum2(SlabLoad{a.slab, a.slab + (size_t)a.rows * C, C, c, a.parts}, a.parts ? a.parts : a.rows, c < C, red, s, q);
+  slab_colsum2(SlabLoad{a.slab, a.slab + (size_t)a.rows * C, C, c, a.parts}, a.parts ? a.parts : a.rows, c < C, red, s, q, slab_is_short(a.rows, a.parts));
   if (cblock == 0 && threadIdx.x == 0 && a.nbt != nullptr) *a.nbt += 1;
   if (threadIdx.x >= FIN_CH || c >= C) return;
   float sc, sh;
   bn_fin_coefs(a, c, s, q, true, sc, sh);
 }
 
-// dc_dwconv_fwd_fin / dc_bn_apply_fin: the finalize of a SHORT slab (at most FIN_RL rows, not folded) done by the kernel that consumes the
-// coefficients, every workgroup for its own channels: the rows in sequence in fp64, which is the order slab_colsum2 has for such a slab (one
-// row per row lane, the lanes added in sequence), then bn_fin_coefs -- the same bits as dc_bn_finalize, one launch and one dependent kernel
-// boundary less per BatchNorm.  `store`: this workgroup is the one that writes the vectors and the running statistics of channel c.
-// (the two column sums of a short slab, rows in sequence, for channel c)
-__device__ inline void slab_seq_sum2(const float* __restrict__ slab, int rows, int C, int c, double& s, double& q) {
+// dc_dwconv_fwd_fin / dc_bn_apply_fin / dc_bn_bwd_apply_fin: the finalize of a SHORT slab (at most FIN_RL rows, not folded) done by the kernel that
+// consumes the coefficients, every workgroup for the CW channels it works on, in slab_colsum2's quad order -- the same bits as dc_bn_finalize /
+// dc_bn_bwd_finalize, one launch and one dependent kernel boundary less per BatchNorm.
+//
+// slab_quad_sum2 (all 256 threads; CW <= 256): a thread takes one of the four row sequences of a channel QUAD with 16-byte loads -- a 54-row slab
+// is 28 loads per thread, requested in two batches, where one thread per channel needed 108 --, the partial sums meet in LDS (red: 64 x CW
+// bytes) and thread i < CW returns the two sums of channel cbase + i.  The slab was written by the kernel in front of this one, on other XCDs:
+// every load is a trip beyond this XCD's L2, and every workgroup of the launch asks for the same lines at the same moment.
+template <int CW>
+__device__ inline void slab_quad_sum2(const float* __restrict__ slab, int rows, int C, int cbase, double (&red)[2][4][CW], double& s, double& q) {
+  static_assert(CW % 4 == 0 && CW <= 256, "one channel quad per thread and row sequence");
+  constexpr int NQ = CW / 4;
+  const int qd = threadIdx.x % NQ, j = threadIdx.x / NQ;
+  if (j < 4) {
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    const int c4 = cbase + 4 * qd;
+    if (c4 < C) {
+      const float* s0 = slab + c4;
+      const float* s1 = slab + (size_t)rows * C + c4;
+      constexpr int FB = 8;
+      for (int r0 = j; r0 < rows; r0 += 4 * FB) {
+        float4 x[FB], y[FB];
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+          const int r = r0 + 4 * i < rows ? r0 + 4 * i : r0;       // (a row past the end re-reads row r0 and adds +0.0)
+          x[i] = *reinterpret_cast<const float4*>(s0 + (size_t)r * C);
+          y[i] = *reinterpret_cast<const float4*>(s1 + (size_t)r * C);
+        }
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+          const bool ok = r0 + 4 * i < rows;
+          a[0] += (double)(ok ? x[i].x : 0.f); a[1] += (double)(ok ? x[i].y : 0.f); a[2] += (double)(ok ? x[i].z : 0.f); a[3] += (double)(ok ? x[i].w : 0.f);
+          b[0] += (double)(ok ? y[i].x : 0.f); b[1] += (double)(ok ? y[i].y : 0.f); b[2] += (double)(ok ? y[i].z : 0.f); b[3] += (double)(ok ? y[i].w : 0.f);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][j][4 * qd + e] = a[e];
+      red[1][j][4 * qd + e] = b[e];
+    }
+  }
+  __syncthreads();
   s = q = 0.0;
+  if (threadIdx.x < CW) {
+    const int i = threadIdx.x;
+    s = (red[0][0][i] + red[0][1][i]) + (red[0][2][i] + red[0][3][i]);
+    q = (red[1][0][i] + red[1][1][i]) + (red[1][2][i] + red[1][3][i]);
+  }
+}
+// The same sums by ONE thread for channel c (blocks of more than 256 channels): the four row sequences in turn.
+__device__ inline void slab_quad_sum2_thread(const float* __restrict__ slab, int rows, int C, int c, double& s, double& q) {
   const float* s0 = slab + c;
   const float* s1 = slab + (size_t)rows * C + c;
-  // Sixteen rows of both sums are requested before the first is added (written out as a batch: left to itself the compiler issues one load,
-  // waits, adds -- 108 round trips beyond L2 for a 54-row slab, 0.7 ms per step at local batch 2).  Why sixteen: against 64 loads in flight --
-  // everything a wave may have outstanding -- the step is 0.13 ms SLOWER with the deeper batch (every workgroup of the launch reads the same
-  // few hundred lines at the same moment), 8 and 4 rows are 0.08 / 0.16 ms slower.  Rows past the end re-read the last row and add +0.0,
-  // which leaves a partial sum as it is.
-#ifndef DC_FIN_ROWS
-#define DC_FIN_ROWS 16
-#endif
-  constexpr int FB = DC_FIN_ROWS;
-  for (int r0 = 0; r0 < rows; r0 += FB) {
-    float x[FB], y[FB];
+  double pa[4] = {0.0, 0.0, 0.0, 0.0}, pb[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int r0 = 0; r0 < rows; r0 += 16) {
+    float x[16], y[16];
 #pragma unroll
-    for (int i = 0; i < FB; ++i) {
+    for (int i = 0; i < 16; ++i) {
       const int r = r0 + i < rows ? r0 + i : rows - 1;
       x[i] = s0[(size_t)r * C];
       y[i] = s1[(size_t)r * C];
     }
 #pragma unroll
-    for (int i = 0; i < FB; ++i) {
-      s += (double)(r0 + i < rows ? x[i] : 0.f);
-      q += (double)(r0 + i < rows ? y[i] : 0.f);
+    for (int i = 0; i < 16; ++i) {
+      pa[i & 3] += (double)(r0 + i < rows ? x[i] : 0.f);
+      pb[i & 3] += (double)(r0 + i < rows ? y[i] : 0.f);
     }
   }
-}
-__device__ inline void bn_short_fin(const BnFinArgs& a, int c, bool store, float& sc, float& sh) {
-  double s, q;
-  slab_seq_sum2(a.slab, a.rows, a.C, c, s, q);
-  bn_fin_coefs(a, c, s, q, store, sc, sh);
+  s = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+  q = (pb[0] + pb[1]) + (pb[2] + pb[3]);
 }
 
 }  // namespace dc

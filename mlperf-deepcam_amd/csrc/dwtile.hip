@@ -97,14 +97,18 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
   if constexpr (FIN) {
     // dc_dwconv_fwd_fin: the producer's BatchNorm finalize over a short slab, by every workgroup for its own channels while its halo
     // travels (bn_fin.h: bn_short_fin); the workgroup of pixel tile 0 stores the vectors the backward pass reads
-    __shared__ float fincoef[2][CG * KPV];
+    constexpr int CW = CG * KPV;
+    __shared__ float fincoef[2][CW];
+    __shared__ double finred[2][4][CW];
     {
-      for (int i = threadIdx.x; i < CG * KPV; i += 256) {
-        const int c = cg0 * KPV + i;
+      double s, q;
+      slab_quad_sum2<CW>(fin.slab, fin.rows, C, cg0 * KPV, finred, s, q);
+      if (threadIdx.x < CW) {
+        const int c = cg0 * KPV + threadIdx.x;
         float sc = 0.f, sh = 0.f;
-        if (c < C) bn_short_fin(fin, c, tile_id == 0, sc, sh);
-        fincoef[0][i] = sc;
-        fincoef[1][i] = sh;
+        if (c < C) bn_fin_coefs(fin, c, s, q, tile_id == 0, sc, sh);
+        fincoef[0][threadIdx.x] = sc;
+        fincoef[1][threadIdx.x] = sh;
       }
       if (t == 0 && threadIdx.x == 0 && fin.nbt != nullptr) *fin.nbt += 1;
       ps = fincoef[0];

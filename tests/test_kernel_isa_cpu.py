@@ -115,7 +115,7 @@ def test_one_pass_kernels_of_the_entry_flow_keep_their_occupancy(tmp_path, src, 
 @pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
 def test_forward_depthwise_tile_kernel_keeps_three_workgroups_per_cu(tmp_path):
     """dwt_kernel's 8 x 8 pixel halo tile of 256 channels is 52 KiB of dynamic LDS: three workgroups on a CU's 160 KiB, with 4 KiB to spare.
-    The in-kernel BatchNorm finalize needs 2 KiB of static LDS for its coefficients and is therefore an instantiation of its own (FIN): in the
+    The in-kernel BatchNorm finalize needs 18 KiB of static LDS (2 KiB when this was found) and is therefore an instantiation of its own (FIN): in the
     plain forward kernel those 2 KiB took the third workgroup off every CU and the 728-channel launches went from 28.6 to 32.1 us -- silently."""
     asm = _device_asm("dwtile.hip", tmp_path)
     fwd = {k: v for k, v in _kernels(asm, "dwt_kernel").items() if "Li1ELb0ELi32ELb0E" in k and "DF16b" in k}
@@ -125,21 +125,24 @@ def test_forward_depthwise_tile_kernel_keeps_three_workgroups_per_cu(tmp_path):
         assert m, kname
         static_lds = int(m.group(1))
         if kname.split("Li1ELb0ELi32ELb0E")[1].startswith("Lb1"):
-            assert static_lds == 2048, f"{kname}: {static_lds}"
+            assert static_lds == 2048 + 16384, f"{kname}: {static_lds}"          # coefficients + the four row sequences' partial sums
         else:
             assert static_lds == 0, f"{kname}: {static_lds} bytes of static LDS beside the halo tile"
             assert 3 * (52 * 1024 + static_lds) <= 160 * 1024
 
 
-def _longest_load_run(lines):
-    """Most global_load_dword instructions (one fp32 per lane: the slab sums) issued back to back without a vmcnt wait between them."""
-    best = run = 0
+def _most_loads_outstanding(lines):
+    """Most global_load_dwordx4 results (a channel quad of a slab row each) outstanding at once: a load adds one, `s_waitcnt vmcnt(N)` leaves at
+    most N (vector-memory results return in order)."""
+    best = out = 0
     for x in lines:
-        if re.search(r"\bglobal_load_dword\s", x):
-            run += 1
-            best = max(best, run)
-        elif "s_waitcnt" in x and "vmcnt" in x:
-            run = 0
+        if re.search(r"\bglobal_load_dwordx4\s", x):
+            out += 1
+            best = max(best, out)
+        else:
+            m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", x)
+            if m:
+                out = min(out, int(m.group(1)))
     return best
 
 
@@ -147,11 +150,12 @@ def _longest_load_run(lines):
 @pytest.mark.parametrize("src,name,select", [("dwtile.hip", "dwt_kernel", "Li1ELb0ELi32ELb0ELb1E"), ("bn.hip", "bn_apply_rows_kernel", "Li32ELb1E"),
                                              ("bn.hip", "bn_bwd_apply_kernel", "Li32E")])
 def test_in_kernel_batchnorm_finalize_keeps_its_slab_loads_in_flight(tmp_path, src, name, select):
-    """bn_fin.h: slab_seq_sum2 asks for sixteen rows of both sums before it adds the first.  Written as a plain loop the compiler issued ONE load,
-    waited and added (in the FIN instantiation of dwt_kernel; in the shared instantiation before it, the same source gave 32 in flight): a
-    54-row slab then costs 108 trips beyond L2 per workgroup and local batch 2 loses 0.7 ms per step -- with correct results."""
+    """bn_fin.h: slab_quad_sum2 asks for eight rows of both sums (sixteen 16-byte loads) before it adds the first.  Written as a plain loop the
+    compiler issued ONE load, waited and added (in the FIN instantiation of dwt_kernel; in the shared instantiation before it, the same source
+    gave 32 in flight): a 54-row slab then costs 108 trips beyond L2 per workgroup and local batch 2 loses 0.7 ms per step -- with correct
+    results.  (Serialized, the most outstanding would be the main loops' own four to twelve.)"""
     asm = _device_asm(src, tmp_path)
     kernels = {k: v for k, v in _kernels(asm, name).items() if select in k and "DF16b" in k}
     assert len(kernels) == 1, sorted(kernels)
     for kname, lines in kernels.items():
-        assert _longest_load_run(lines) >= 32, f"{kname}: at most {_longest_load_run(lines)} slab loads in flight"
+        assert _most_loads_outstanding(lines) >= 12, f"{kname}: at most {_most_loads_outstanding(lines)} slab loads in flight"
