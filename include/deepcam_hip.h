@@ -207,7 +207,8 @@ int dc_dwconv_fwd(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, 
  * Block, deeplab_xception.py:83-98, at small batch): x is the raw output of the convolution in front of that BatchNorm, slab[2][rows][C]
  * its partial sums with rows <= dc_bn_bwd_apply_fin_max_rows().  Every workgroup sums the slab for its own channels while its halo tile
  * travels (order and bits of dc_bn_finalize); the workgroups of pixel tile 0 store scale / shift / save_mean / save_invstd and update
- * the running statistics.  dc_dwconv_fwd_fin_ok: 1 when the shape is served (stride 1, dilation 1 or 2, the tiled kernel). */
+ * the running statistics.  The slab is read with 16-byte loads: 16-byte aligned (as are dc_bn_apply_fin's and dc_bn_bwd_apply_fin's).
+ * dc_dwconv_fwd_fin_ok: 1 when the shape is served (stride 1, dilation 1 or 2, the tiled kernel). */
 int dc_dwconv_fwd_fin_ok(int dtype, int C, int stride, int dil, int N, int Hi, int Wi);
 int dc_dwconv_fwd_fin(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx, const float* w, void* y, int ldy,
                       int prelu, long count, const float* slab, int rows, const float* gamma, const float* beta, float* running_mean,

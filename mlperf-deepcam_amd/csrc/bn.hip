@@ -550,6 +550,7 @@ extern "C" int dc_bn_apply_fin(int dtype, long M, int C, long count, const void*
                                int relu, void* out, int ldo, void* stream) {
   DC_REQUIRE(C > 0 && slab && gamma && beta && scale && shift && rows > 0 && rows <= FIN_RL,
              "dc_bn_apply_fin: needs a slab of at most dc_bn_bwd_apply_fin_max_rows() rows");
+  DC_REQUIRE(((uintptr_t)slab & 15) == 0 && C % 4 == 0, "dc_bn_apply_fin: the slab is read with 16-byte loads (16-byte aligned, C a multiple of 4)");
   if (count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
   const BnFinArgs a = bn_fin_args(C, count, slab, rows, 0, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
                                   shift, save_mean, save_invstd);
@@ -623,6 +624,7 @@ extern "C" int dc_bn_bwd_apply_fin(int dtype, long M, int C, long count, const v
                                    const float* save_invstd, const float* slab, int rows, float* dgamma, float* dbeta, void* dy, int lddy,
                                    void* g_out, int ldg, const float* mscale, const float* mshift, void* stream) {
   DC_REQUIRE(slab != nullptr && rows > 0 && rows <= FIN_RL && dgamma && dbeta, "dc_bn_bwd_apply_fin: needs a slab of at most dc_bn_bwd_apply_fin_max_rows() rows");
+  DC_REQUIRE(((uintptr_t)slab & 15) == 0 && C % 4 == 0, "dc_bn_bwd_apply_fin: the slab is read with 16-byte loads (16-byte aligned, C a multiple of 4)");
   return bn_bwd_apply_impl(dtype, M, C, count, dout, lddo, y, ldy, out, ldout, relu, gamma, save_mean, save_invstd, nullptr, nullptr, dy, lddy, g_out, ldg,
                            mscale, mshift, stream, slab, rows, dgamma, dbeta);
 }

@@ -516,6 +516,7 @@ extern "C" int dc_dwconv_fwd_fin(int dtype, int C, int stride, int dil, int N, i
   if (int e = dc_check_view(x, ldx, C, dtype, "dc_dwconv_fwd_fin x")) return e;
   if (int e = dc_check_view(y, ldy, C, dtype, "dc_dwconv_fwd_fin y")) return e;
   DC_REQUIRE(w && slab && gamma && beta && scale && shift && rows > 0, "dc_dwconv_fwd_fin: null argument");
+  DC_REQUIRE(((uintptr_t)slab & 15) == 0, "dc_dwconv_fwd_fin: the slab is read with 16-byte loads (16-byte aligned)");
   DC_REQUIRE(dc_dwconv_fwd_fin_ok(dtype, C, stride, dil, N, Hi, Wi), "dc_dwconv_fwd_fin: shape not served (dc_dwconv_fwd_fin_ok)");
   if (count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
   const BnFinArgs a = bn_fin_args(C, count, slab, rows, 0, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,

@@ -1031,6 +1031,10 @@ def test_batchnorm_finalize_inside_its_consumer(case):
     # against torch on the real statistics
     o = F.batch_norm(from_nhwc(yv).float().cpu(), None, None, gamma.cpu(), beta.cpu(), True, 0.1, 1e-5)
     assert_close(from_nhwc(o_got), o, dtype, bf16=2e-2)
+    # a slab that is not 16-byte aligned is refused (the kernels take it with 16-byte loads)
+    with pytest.raises(L.DeepcamHipError):
+        L.call("dc_bn_apply_fin", dt, M, Cc, M, vptr(yv), ld, C.c_void_p(slab.data_ptr() + 4), rows, *fin_args(state())[2:], None, 0, 0, vptr(o_got),
+               Cc + 16, S())
     # a slab longer than the kernels take is refused
     with pytest.raises(L.DeepcamHipError):
         L.call("dc_bn_apply_fin", dt, M, Cc, M, vptr(yv), ld, vptr(slab), 65, *fin_args(state())[2:], None, 0, 0, vptr(o_got), Cc + 16, S())
