@@ -302,6 +302,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, const float
 // coefficients are computed once and live in registers -- the earlier grid-stride version re-loaded five vectors per element
 // and ran at 3.2 TB/s where a copy reaches 4.9.
 static int g_bn_cgw = 32, g_bn_rows = 32;
+static int g_bn_fin_mul_f = 2, g_bn_fin_mul_b = 1;   // rows per block of the kernels that run a finalize themselves, in units of bn_rows ("bn_fin_mul_fwd" / "_bwd")
 static int g_bn_apply_rows = 1;     // dc_bn_apply on bn_apply_rows_kernel (0: the grid-stride kernel; "bn_apply_rows")
 template <typename T, int CGW>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, int APPLY_ROWS, float inv_count, const T* __restrict__ dout,
@@ -447,6 +448,8 @@ extern "C" int dc_bn_set_option(const char* name, int value) {
   if (strcmp(name, "bn_cgw") == 0 && (value == 16 || value == 32 || value == 64)) { g_bn_cgw = value; return 0; }
   if (strcmp(name, "bn_rows") == 0 && value >= 16 && value % 16 == 0) { g_bn_rows = value; return 0; }
   if (strcmp(name, "bn_apply_rows") == 0) { g_bn_apply_rows = value != 0; return 0; }
+  if (strcmp(name, "bn_fin_mul_fwd") == 0 && value >= 1 && value <= 16) { g_bn_fin_mul_f = value; return 0; }
+  if (strcmp(name, "bn_fin_mul_bwd") == 0 && value >= 1 && value <= 16) { g_bn_fin_mul_b = value; return 0; }
   return -1;
 }
 
@@ -554,7 +557,7 @@ extern "C" int dc_bn_apply_fin(int dtype, long M, int C, long count, const void*
   if (count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
   const BnFinArgs a = bn_fin_args(C, count, slab, rows, 0, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
                                   shift, save_mean, save_invstd);
-  return bn_apply_impl(dtype, M, C, y, ldy, scale, shift, residual, ldr, relu, out, ldo, stream, &a, 2 * g_bn_rows);
+  return bn_apply_impl(dtype, M, C, y, ldy, scale, shift, residual, ldr, relu, out, ldo, stream, &a, g_bn_fin_mul_f * g_bn_rows);
 }
 
 extern "C" int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int lddo, const void* y, int ldy,
@@ -597,7 +600,7 @@ static int bn_bwd_apply_impl(int dtype, long M, int C, long count, const void* d
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   // a block as narrow as the tensor (see narrow_cg); the rows per block grow with the row lanes so that every thread has its four rows
   const int cgw = narrow_cg(C / kpv, g_bn_cgw);
-  const int APPLY_ROWS = g_bn_rows * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
+  const int APPLY_ROWS = g_bn_rows * (fin_slab != nullptr ? g_bn_fin_mul_b : 1) * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
   DC_REQUIRE(cdiv(M, APPLY_ROWS) <= 65535, "dc_bn_bwd_apply: too many rows for one launch");
   const dim3 blocks(cdiv(C / kpv, cgw), cdiv(M, APPLY_ROWS));
   const float inv = 1.0f / (float)count;
