@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, const float
 // coefficients are computed once and live in registers -- the earlier grid-stride version re-loaded five vectors per element
 // and ran at 3.2 TB/s where a copy reaches 4.9.
 static int g_bn_cgw = 32, g_bn_rows = 32;
-static int g_bn_fin_mul_f = 2, g_bn_fin_mul_b = 1;   // rows per block of the kernels that run a finalize themselves, in units of bn_rows ("bn_fin_mul_fwd" / "_bwd")
+static int g_bn_fin_mul_f = 2, g_bn_fin_mul_b = 2;   // rows per block of the kernels that run a finalize themselves, in units of bn_rows ("bn_fin_mul_fwd" / "_bwd")
 static int g_bn_apply_rows = 1;     // dc_bn_apply on bn_apply_rows_kernel (0: the grid-stride kernel; "bn_apply_rows")
 template <typename T, int CGW>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long M, int C, int APPLY_ROWS, float inv_count, const T* __restrict__ dout,

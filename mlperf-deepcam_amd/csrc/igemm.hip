@@ -977,7 +977,7 @@ static const struct { const char* name; int value; } kOptionDefaults[] = {
     {"igemm256_phase_fast", 1}, {"wgrad_target_blocks", 768},
     {"wgrad_mode", 1}, {"wgrad_min_steps", 16}, {"wgrad256", 1}, {"wgrad256_pad", 115}, {"thin_wgrad", 1}, {"wgrad256_slots", 192}, {"wgrad256_min_stages", 96},
     {"wgrad384", 1}, {"wgrad384_slots", 192}, {"wgrad384_fill", 66}, {"wgrad384_min_stages", 96}, {"head_fused", 1},
-    {"head_dgrad_fused", 1}, {"head_wgrad_fused", 1}, {"igemm256_splitk", 1}, {"igemm_zfill", 1}, {"pw_bn_bwd", 3}, {"sep_fwd", 1}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_pipe", 1}, {"bn_cgw", 32}, {"bn_rows", 32}, {"bn_apply_rows", 1}, {"bn_fin_mul_fwd", 2}, {"bn_fin_mul_bwd", 1},
+    {"head_dgrad_fused", 1}, {"head_wgrad_fused", 1}, {"igemm256_splitk", 1}, {"igemm_zfill", 1}, {"pw_bn_bwd", 3}, {"sep_fwd", 1}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_pipe", 1}, {"bn_cgw", 32}, {"bn_rows", 32}, {"bn_apply_rows", 1}, {"bn_fin_mul_fwd", 2}, {"bn_fin_mul_bwd", 2},
 };
 
 extern "C" int dc_reset_options(void) {

@@ -204,7 +204,7 @@ class Engine:
         self.fuse_bn_bwd_fin = os.environ.get("DC_FUSE_BN_BWD_FIN", "1") != "0"    # dc_bn_bwd_finalize inside dc_bn_bwd_apply for short slabs
         # dc_bn_finalize inside the kernel that consumes the coefficients (dc_dwconv_fwd_fin, dc_bn_apply_fin) for short slabs of small tensors
         self.fuse_bn_fwd_fin = os.environ.get("DC_FUSE_BN_FWD_FIN", "1") != "0"
-        self.bn_fin_max_m = int(os.environ.get("DC_BN_FIN_MAX_M", "8192"))           # ... below this many pixels (each workgroup repeats the sum)
+        self.bn_fin_max_m = int(os.environ.get("DC_BN_FIN_MAX_M", "16384"))          # ... up to this many pixels (each workgroup repeats the sum)
         # timing experiments only: "fwd" / "bwd" / "both" leave out the BatchNorm finalize launches (results are then garbage): what the
         # 77 + 78 tiny kernels and the dispatch gaps around them cost the chain
         self._debug_skip_finalize = os.environ.get("DC_DEBUG_SKIP_BN_FINALIZE", "")
@@ -734,7 +734,8 @@ class Engine:
             # a short slab (the 42 rows the persistent depthwise data gradient leaves on the 728-channel layers) of a SMALL tensor: the apply
             # kernel sums it itself (dc_bn_bwd_apply_fin, same bits): one launch and one dependent boundary less per BatchNorm of the middle
             # flow.  Every 32-row block repeats the sum for its channels, so it pays only while the grid is small: local batch 2 12.47 ->
-            # 12.38 ms, batch 4 19.80 -> 19.83, batch 8 33.47 -> 33.88 (2 592 blocks re-reading 86 KB each): on below 8 192 pixels
+            # 12.38 ms, batch 4 19.80 -> 19.83, batch 8 33.47 -> 33.88 (2 592 blocks re-reading 86 KB each).  With 64 rows per block in this form
+            # (option bn_fin_mul_bwd = 2) batch 4 gains too (19.02 -> 18.93) and batch 8 is level at best: on up to 16 384 pixels (DC_BN_FIN_MAX_M)
             fin_in_apply = (self.fuse_bn_bwd_fin and apply_by is None and pwf is None and rrows <= lib.dc_bn_bwd_apply_fin_max_rows() and M <= self.bn_fin_max_m
                             and os.environ.get("DC_DEBUG_SKIP_BN_FINALIZE", "") not in ("bwd", "both"))     # (the timing switch is read later)
 
