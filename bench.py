@@ -234,6 +234,12 @@ def main():
 
     for _ in range(a.warmup):
         step(x, y)
+    # the host enqueues ~660 launches per step through ctypes, which leaves garbage behind; as `timeit` does, the collector is off inside the
+    # timed region (nothing of the step is skipped).  It is not what makes one step of twenty 1 - 6 ms longer at local batch 2 on some boxes
+    # (the lines read the same with it on): that is the host between launches, and `--program` takes the host out of the loop
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     comm_events.clear()
     # per-step HIP events on the launch stream (SURVEY 8d asks for the median of per-step times beside the mean): recording an event
@@ -246,6 +252,7 @@ def main():
     marks[a.steps].record()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     step_ms = {"median": round(per_step[len(per_step) // 2] if len(per_step) % 2 else
                                0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2]), 3),
