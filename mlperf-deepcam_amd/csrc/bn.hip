@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void bn_apply_rows_kernel(long M, int C, int A
   const int c0 = (blockIdx.x * CGW + cgl) * KPV;
   float sc[KPV], sh[KPV];
   if constexpr (FIN) {
-    // dc_bn_apply_fin: the finalize of a short slab by every block for its own channels (bn_fin.h: bn_short_fin); block row 0 stores
+    // dc_bn_apply_fin: the finalize of a short slab by every block for its own channels (bn_fin.h: slab_quad_sum2); block row 0 stores
     constexpr int CW = CGW * KPV;
     __shared__ float fincoef[2][CW];
     if constexpr (CW <= 256) {

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
   int cbase = 0;
   if constexpr (FIN) {
     // dc_dwconv_fwd_fin: the producer's BatchNorm finalize over a short slab, by every workgroup for its own channels while its halo
-    // travels (bn_fin.h: bn_short_fin); the workgroup of pixel tile 0 stores the vectors the backward pass reads
+    // travels (bn_fin.h: slab_quad_sum2); the workgroup of pixel tile 0 stores the vectors the backward pass reads
     constexpr int CW = CG * KPV;
     __shared__ float fincoef[2][CW];
     __shared__ double finred[2][4][CW];
