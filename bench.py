@@ -73,6 +73,53 @@ def cpu_baseline(H, W, local_batch=2, timed_steps=3, step_budget_s=60.0):
             "seconds_per_step": round(total, 3), "forward_s": round(fwd, 3), "backward_s": round(bwd, 3), "optimizer_s": round(opt_s, 3)}
 
 
+def torch_gpu_baseline(H, W, local_batch, dev, mode="nhwc", timed_steps=5):
+    """--torch_gpu_baseline: the oracle's train step (the network as a chain of torch operators: F.conv2d, F.batch_norm, F.conv_transpose2d ...,
+    autograd, torch.optim.Adam) on THIS GPU, eager, bf16 autocast over fp32 weights, channels_last -- what the reference's own stack
+    (PyTorch operators over MIOpen / rocBLAS; the reference runs apex O1 mixed precision, train_hdf5_ddp.py:222-224) delivers on the hardware the
+    headline number is quoted on.  A reported baseline like cpu_baseline, at the same local batch as the timed step; never the thing measured.
+    mode: "nchw" = as the reference runs it (contiguous NCHW tensors, no algorithm search); "nhwc" = channels_last tensors; "_tuned" = with
+    torch.backends.cudnn.benchmark (MIOpen's search for the fastest algorithm per convolution, minutes of warm-up)."""
+    from oracle import loss_metric as olm, model as omodel      # timed as a baseline, never shipped
+    cw = olm.class_weights(-0.125)
+    sd = omodel.init_state(333)
+    fmt = torch.contiguous_format if mode.startswith("nchw") else torch.channels_last
+    torch.backends.cudnn.benchmark = mode.endswith("_tuned")
+    sd = {k: (v.to(dev).contiguous(memory_format=fmt) if v.dim() == 4 else v.to(dev)) for k, v in sd.items()}
+    keys = omodel.param_keys(sd)
+    params = [sd[k].requires_grad_(True) for k in keys]
+    opt = torch.optim.Adam(params, lr=1e-3, eps=1e-8, weight_decay=1e-6)
+    x, y = synthetic_batch(local_batch, H, W, 1234, dev)
+    x = x.contiguous(memory_format=fmt)
+
+    def one():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = omodel.forward(sd, x, training=True)
+        loss = olm.fp_loss(logits.float(), y, cw)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    t0 = time.perf_counter()
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize(dev)
+    warm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(timed_steps):
+        loss = one()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / timed_steps
+    out = {"value": local_batch / dt, "unit": "samples/s", "ms_per_step": round(dt * 1e3, 2), "kind": "port",
+           "sample": f"oracle train step through torch operators on the GPU (eager, bf16 autocast, {mode}, torch.optim.Adam), B={local_batch} {H}x{W}, "
+                     f"2 warm-up steps ({warm:.1f} s) + {timed_steps} timed", "loss_last_step": round(float(loss.detach()), 6),
+           "peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
+    del params, sd, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 class KernelTimer:
     """HIP-event timing of every launch of the two MFMA kernel families on the stream they run on:
        igemm  dc::igemm256_kernel / dc::igemm256p_kernel / dc::pw384_kernel / dc::pw192_kernel / dc::igemm_kernel<T> / dc::tiny_gemm_kernel<T>
@@ -157,6 +204,8 @@ def main():
     ap.add_argument("--height", type=int, default=768)
     ap.add_argument("--width", type=int, default=1152)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--torch_gpu_baseline", choices=["nchw", "nchw_tuned", "nhwc", "nhwc_tuned"], default=None, help="also time the oracle's step through PyTorch's own operators on this GPU "
+                    "(eager, bf16 autocast, MIOpen / rocBLAS): the reference's stack on the same hardware, reported as `torch_rocm_baseline`")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (default: eager launches, which "
                     "measured faster once weight gradients moved to a side stream: 55.3 vs 59.5 ms at B=8)")
     ap.add_argument("--program", action="store_true", help="replay the step from the C-side launch list (TrainStep.enable_program: dc_program_run, "
@@ -380,6 +429,14 @@ def main():
                "loss_last_step": round(loss, 6), "roofline": roof}
         if comm is not None:
             out["comm"] = comm
+        if world == 1 and a.torch_gpu_baseline:
+            try:
+                del step, net, opt            # the engine's arenas go back to the allocator first
+                torch.cuda.empty_cache()
+                out["torch_rocm_baseline"] = torch_gpu_baseline(H, W, B, dev, a.torch_gpu_baseline)
+                out["torch_rocm_baseline"]["this_repository_over_it"] = round(sps / out["torch_rocm_baseline"]["value"], 2)
+            except Exception as e:  # a baseline must never take the GPU number down with it
+                out["torch_rocm_baseline"] = {"value": None, "unit": "samples/s", "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(H, W)

@@ -24,7 +24,7 @@ def weighted_ce_map(logit: torch.Tensor, target: torch.Tensor, weight: Sequence[
     losses.py:35-36 builds nn.CrossEntropyLoss(weight, reduction='none').  The two
     "false positive" factors at :41-46 multiply by (eq & ne) == 0, i.e. they are identities.
     """
-    w = torch.tensor(np.array(weight), dtype=torch.float64).float()          # losses.py:35 goes through numpy float64 -> float32
+    w = torch.tensor(np.array(weight), dtype=torch.float64).float().to(logit.device)   # losses.py:35 goes through numpy float64 -> float32
     t = target.squeeze(1) if target.dim() == 4 else target
     t = t.long()
     lse = torch.logsumexp(logit, 1)
