@@ -2,8 +2,9 @@
 
 This package is a plain-PyTorch (CPU, fp32) restatement of the reference's
 hot path (azrael417/mlperf-deepcam, src/deepCam).  It exists so that tests,
-``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg have
-something to check the HIP path against.  Nothing under ``mlperf-deepcam_amd/``
+``__graft_entry__.smoke()`` and ``bench.py``'s baseline legs (``cpu_baseline``; the opt-in
+``torch_rocm_baseline``, the same step through PyTorch's operators on the GPU) have
+something to check the HIP path against and to time beside it.  Nothing under ``mlperf-deepcam_amd/``
 may import it: the product path must fail loudly when the HIP library is
 missing, never fall back to this code.
 
