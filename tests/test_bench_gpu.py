@@ -1,0 +1,21 @@
+"""bench.py's optional baseline leg on the GPU (the default line and the N > 1 paths are covered in test_dist_gpu.py / test_profile_gpu.py)."""
+import json, os, subprocess, sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_reports_the_torch_operator_baseline_when_asked():
+    """--torch_gpu_baseline nchw: after the timed steps the oracle's train step runs on the same GPU through PyTorch-ROCm's own operators (eager,
+    bf16 autocast) and is reported beside the line -- `torch_rocm_baseline`, a baseline like `cpu_baseline`; the line itself is unchanged."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--local_batch_size", "2", "--height", "128", "--width", "192",
+           "--no_cpu_baseline", "--torch_gpu_baseline", "nchw"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    base = out["torch_rocm_baseline"]
+    assert out["value"] > 0 and out["vs_baseline"] is None and "cpu_baseline" not in out
+    assert base["value"] is not None and base["value"] > 0, base
+    assert base["unit"] == "samples/s" and base["kind"] == "port" and "nchw" in base["sample"]
+    assert abs(base["this_repository_over_it"] - out["value"] / base["value"]) < 0.01 * base["this_repository_over_it"] + 0.01
