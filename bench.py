@@ -101,10 +101,23 @@ def torch_gpu_baseline(H, W, local_batch, dev, mode="nhwc", timed_steps=5):
         opt.step()
         return loss
 
+    # MIOpen compiles (and, "_tuned", searches) kernels for ~60 convolution shapes in the first steps: minutes without output otherwise
+    import sys, threading
+    done = threading.Event()
+
+    def heartbeat():
+        t = time.perf_counter()
+        while not done.wait(60.0):
+            print(f"torch_gpu_baseline [{mode}]: warming up, {time.perf_counter() - t:.0f} s", file=sys.stderr, flush=True)
+
+    threading.Thread(target=heartbeat, daemon=True).start()
     t0 = time.perf_counter()
-    for _ in range(2):
-        one()
-    torch.cuda.synchronize(dev)
+    try:
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize(dev)
+    finally:
+        done.set()
     warm = time.perf_counter() - t0
     t0 = time.perf_counter()
     for _ in range(timed_steps):
