@@ -125,7 +125,7 @@ def torch_gpu_baseline(H, W, local_batch, dev, mode="nhwc", timed_steps=5):
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / timed_steps
     out = {"value": local_batch / dt, "unit": "samples/s", "ms_per_step": round(dt * 1e3, 2), "kind": "port",
-           "sample": f"oracle train step through torch operators on the GPU (eager, bf16 autocast, {mode}, torch.optim.Adam), B={local_batch} {H}x{W}, "
+           "sample": f"oracle train step through torch operators on the GPU (eager, bf16 autocast, {mode}, torch.optim.Adam with wd 1e-6 -- the headline step's optimizer may differ (LAMB, wd 1e-2): a cheaper update on this side, so the ratio is conservative), B={local_batch} {H}x{W}, "
                      f"2 warm-up steps ({warm:.1f} s) + {timed_steps} timed", "loss_last_step": round(float(loss.detach()), 6),
            "peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
     del params, sd, opt
@@ -206,6 +206,71 @@ class KernelTimer:
         return out
 
 
+def also_config(dnn, B, H, W, dtype_name, optimizer, steps, warmup, dev):
+    """BASELINE.json configs[1] (local batch 2, fp32) and configs[2] (local batch 4, bf16) timed in the same process as the
+    headline configuration, the same way (W warm-up steps, K steps between two synchronisations, nothing skipped), each with its whole-step and
+    encoder-region fraction of the dtype's MFMA peak.  Single GPU only; runs after the headline's timed region and roofline passes."""
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=dtype, seed=333)
+    net.materialize(B, H, W)
+    net.train()
+    wd = 1e-2 if optimizer != "Adam" else 1e-6
+    opt = dnn.make_optimizer(optimizer, net, 1e-3, 1e-8, wd)
+    step = dnn.TrainStep(net, opt, dnn.class_weights(-0.125), B, H, W, with_metrics=False)
+    x, y = synthetic_batch(B, H, W, 1234, dev)
+    for _ in range(warmup):
+        step(x, y)
+    import gc
+    gc.collect()
+    gc.disable()
+    try:
+        torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            marks[i].record()
+            step(x, y)
+        marks[steps].record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    loss = step.loss()
+    sps = steps * B / dt
+    peak = PEAK[dtype_name]
+    scale = (H * W) / (768 * 1152)
+    # the encoder region on its own, one stream (as the headline's third roofline pass)
+    eng = net.engine
+    side = eng.use_side_stream
+    eng.use_side_stream = False
+    eng.region_marks = []
+    nroof = min(steps, 3)
+    for _ in range(nroof):
+        step(x, y)
+    torch.cuda.synchronize()
+    ev = eng.region_marks
+    eng.region_marks = None
+    eng.use_side_stream = side
+    per = [dict(ev[i:i + 4]) for i in range(0, len(ev) - len(ev) % 4, 4)]
+    t_fwd = sum(m["fwd_begin"].elapsed_time(m["fwd_enc_end"]) for m in per) / len(per)
+    t_bwd = sum(m["bwd_enc_begin"].elapsed_time(m["bwd_end"]) for m in per) / len(per)
+    enc_flop = ENCODER_FLOP_PER_SAMPLE * B * scale
+    out = {"config": {"workload": f"DeepLabV3+/Xception train step (fwd + weighted CE + bwd + {optimizer}), {H}x{W}x16, local_batch={B}, "
+                                  f"{dtype_name} activations / fp32 master weights, random-init seed 333",
+                      "local_batch": B, "optimizer": optimizer},
+           "dtype": dtype_name, "value": round(sps, 3), "unit": "samples/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3), "step_ms_median": round(per_step[len(per_step) // 2], 3),
+           "loss_last_step": round(loss, 6),
+           "whole_step_frac": round(sps * FLOP_PER_SAMPLE * scale / peak, 4),
+           "encoder_region": {"fwd_ms": round(t_fwd, 3), "bwd_ms": round(t_bwd, 3),
+                              "achieved": round(enc_flop / ((t_fwd + t_bwd) * 1e-3) / 1e12, 2),
+                              "frac": round(enc_flop / ((t_fwd + t_bwd) * 1e-3) / peak, 4)}}
+    del step, net, opt, eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,6 +282,8 @@ def main():
     ap.add_argument("--height", type=int, default=768)
     ap.add_argument("--width", type=int, default=1152)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_also", action="store_true", help="skip the two other single-GPU configurations of BASELINE.json (local batch 2 fp32 Adam, "
+                    "local batch 4 bf16) that a default N=1 run times after the headline and attaches as `also`")
     ap.add_argument("--torch_gpu_baseline", choices=["nchw", "nchw_tuned", "nhwc", "nhwc_tuned"], default=None, help="also time the oracle's step through PyTorch's own operators on this GPU "
                     "(eager, bf16 autocast, MIOpen / rocBLAS): the reference's stack on the same hardware, reported as `torch_rocm_baseline`")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (default: eager launches, which "
@@ -284,7 +351,10 @@ def main():
         step.enable_graph()
         graphed = True
     programmed = False
-    if a.program and not graphed and (world == 1 or reducer.collective == "library"):
+    if a.program and (graphed or not (world == 1 or reducer.collective == "library")):
+        raise SystemExit("--program cannot be honoured: " + ("--graph replays the step already" if graphed else
+                         "with more than one rank the launch list needs the library's collective (DC_GRAD_COLLECTIVE=lib)"))
+    if a.program:
         step(x, y)
         step.enable_program()
         programmed = True
@@ -302,19 +372,21 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    barrier()
-    comm_events.clear()
-    # per-step HIP events on the launch stream (SURVEY 8d asks for the median of per-step times beside the mean): recording an event
-    # costs no synchronisation, the timed region stays K steps between two barriers
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        marks[i].record()
-        step(x, y)
-    marks[a.steps].record()
-    barrier()
-    dt = time.perf_counter() - t0
-    gc.enable()
+    try:
+        barrier()
+        comm_events.clear()
+        # per-step HIP events on the launch stream (SURVEY 8d asks for the median of per-step times beside the mean): recording an event
+        # costs no synchronisation, the timed region stays K steps between two barriers
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            marks[i].record()
+            step(x, y)
+        marks[a.steps].record()
+        barrier()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     step_ms = {"median": round(per_step[len(per_step) // 2] if len(per_step) % 2 else
                                0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2]), 3),
@@ -442,10 +514,19 @@ def main():
                "loss_last_step": round(loss, 6), "roofline": roof}
         if comm is not None:
             out["comm"] = comm
+        if world == 1:
+            del step, net, opt, eng       # the engine's arenas go back to the allocator before the other configurations / baselines
+            torch.cuda.empty_cache()
+        if world == 1 and not a.no_also and (B, a.dtype) == (8, "bf16"):
+            # BASELINE.json configs[1] and configs[2]: the other two single-GPU configurations, timed the same way in this process
+            out["also"] = []
+            for ab, adt, aopt in ((2, "fp32", "Adam"), (4, "bf16", a.optimizer)):
+                try:
+                    out["also"].append(also_config(dnn, ab, H, W, adt, aopt, a.steps, a.warmup, dev))
+                except Exception as e:  # never take the headline down
+                    out["also"].append({"config": {"local_batch": ab}, "dtype": adt, "value": None, "error": f"{type(e).__name__}: {e}"})
         if world == 1 and a.torch_gpu_baseline:
             try:
-                del step, net, opt            # the engine's arenas go back to the allocator first
-                torch.cuda.empty_cache()
                 out["torch_rocm_baseline"] = torch_gpu_baseline(H, W, B, dev, a.torch_gpu_baseline)
                 out["torch_rocm_baseline"]["this_repository_over_it"] = round(sps / out["torch_rocm_baseline"]["value"], 2)
             except Exception as e:  # a baseline must never take the GPU number down with it
@@ -459,6 +540,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        reducer.close()               # the library path's communicator (ncclComm_t, stream, events) goes back before the process group does
         dist.destroy_process_group()
 
 

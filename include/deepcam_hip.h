@@ -114,6 +114,17 @@ int dc_conv_stat_rows(const dc_conv_desc* d, int N, int Hi, int Wi);
 int dc_conv_fwd(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,
                 const float* bias, void* y, int ldy, float* stat_slab, int accumulate, void* stream);
 
+/* dc_conv_fwd / dc_conv_dgrad given BOTH packed images of the layer (replaces the same call sites: F.conv2d of the `pointwise` convs at
+ * architecture/deeplab_xception.py:60,65 and their autograd data gradient).  `wb` here / `wf` below is the image the plain entry point does not
+ * take; its rows are [k][n] for the GEMM in question, so a pointwise layer's weight stages can be 32-deep slabs of whole L2 lines
+ * (csrc/igemm224.hip: 224 x 384 tiles, three-deep operand rings).  Layers that kernel does not serve run exactly as through the plain entry
+ * points.  Outputs are bit-identical to the plain calls; the BatchNorm partial sums come in another summation order (one slab row per
+ * 224-pixel tile, the slab's other rows written as zeros: the slab keeps dc_conv_stat_rows rows). */
+int dc_conv_fwd_kn(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf, const void* wb,
+                   const float* bias, void* y, int ldy, float* stat_slab, int accumulate, void* stream);
+int dc_conv_dgrad_kn(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb, const void* wf,
+                     void* dx, int lddx, int accumulate, void* stream);
+
 /* Same as dc_conv_fwd, but the result is stored as fp32 (y: float NHWC, ldy in floats) whatever d->dtype is:
  * used where the consumer must not see bf16-rounded sums (the classifier head's logits). */
 int dc_conv_fwd_f32out(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,

@@ -123,7 +123,7 @@ extern "C" int dc_comm_create(const void* id128, int rank, int world, void** com
     if (!r.ok) { delete c; return dc_fail("dc_comm_create: RCCL (librccl.so) could not be loaded", __FILE__, __LINE__); }
     UniqueId id;
     memcpy(id.internal, id128, sizeof(id.internal));
-    if (int rc = r.comm_init_rank(&c->nccl, world, id, rank)) { delete c; return rccl_fail(rc, "ncclCommInitRank"); }
+    if (int rc = r.comm_init_rank(&c->nccl, world, id, rank)) { c->nccl = nullptr; delete c; return rccl_fail(rc, "ncclCommInitRank"); }
     c->owns_nccl = true;
   } else if (id128 != nullptr) {
     // a single rank WITH an id: bring RCCL up anyway (what the single-GPU test of the N > 1 call pattern wants to see)
@@ -131,29 +131,29 @@ extern "C" int dc_comm_create(const void* id128, int rank, int world, void** com
     if (!r.ok) { delete c; return dc_fail("dc_comm_create: RCCL (librccl.so) could not be loaded", __FILE__, __LINE__); }
     UniqueId id;
     memcpy(id.internal, id128, sizeof(id.internal));
-    if (int rc = r.comm_init_rank(&c->nccl, 1, id, 0)) { delete c; return rccl_fail(rc, "ncclCommInitRank"); }
+    if (int rc = r.comm_init_rank(&c->nccl, 1, id, 0)) { c->nccl = nullptr; delete c; return rccl_fail(rc, "ncclCommInitRank"); }
     c->owns_nccl = true;
   }
   if (c->nccl != nullptr)
-    if (int e = make_stream(c)) { delete c; return e; }
+    if (int e = make_stream(c)) { (void)dc_comm_destroy(c); return e; }      // the one owner of stream, events and communicator
   *comm = c;
   return 0;
 }
 
 extern "C" int dc_comm_adopt(void* nccl_comm, int rank, int world, void** comm) {
-  if (comm == nullptr || nccl_comm == nullptr || world < 1) return dc_fail("dc_comm_adopt: bad argument", __FILE__, __LINE__);
+  if (comm == nullptr || nccl_comm == nullptr || world < 1 || rank < 0 || rank >= world) return dc_fail("dc_comm_adopt: bad argument", __FILE__, __LINE__);
   if (!rccl().ok) return dc_fail("dc_comm_adopt: RCCL (librccl.so) could not be loaded", __FILE__, __LINE__);
   DcComm* c = new DcComm;
   c->rank = rank;
   c->world = world;
   c->nccl = nccl_comm;
-  if (int e = make_stream(c)) { delete c; return e; }
+  if (int e = make_stream(c)) { (void)dc_comm_destroy(c); return e; }        // (an adopted communicator is not destroyed)
   *comm = c;
   return 0;
 }
 
 extern "C" int dc_comm_create_callback(dc_allreduce_callback fn, void* ctx, int rank, int world, int sync_stream, void** comm) {
-  if (comm == nullptr || fn == nullptr || world < 1) return dc_fail("dc_comm_create_callback: bad argument", __FILE__, __LINE__);
+  if (comm == nullptr || fn == nullptr || world < 1 || rank < 0 || rank >= world) return dc_fail("dc_comm_create_callback: bad argument", __FILE__, __LINE__);
   DcComm* c = new DcComm;
   c->rank = rank;
   c->world = world;
@@ -167,12 +167,13 @@ extern "C" int dc_comm_create_callback(dc_allreduce_callback fn, void* ctx, int 
 extern "C" int dc_comm_destroy(void* comm) {
   DcComm* c = (DcComm*)comm;
   if (c == nullptr) return 0;
+  // every member on its own: make_stream may have stopped half way
   if (c->stream != nullptr) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
-    (void)hipEventDestroy(c->ev_in);
-    (void)hipEventDestroy(c->ev_out);
   }
+  if (c->ev_in != nullptr) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_out != nullptr) (void)hipEventDestroy(c->ev_out);
   if (c->nccl != nullptr && c->owns_nccl) (void)rccl().comm_destroy(c->nccl);
   delete c;
   return 0;

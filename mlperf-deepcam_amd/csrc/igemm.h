@@ -38,6 +38,8 @@ struct IgemmParams {
   GatherGeom g;
   int N, ldx, ldy;
   int ldw;     // K stride of a packed weight row: weight_ld(Cin)
+  const void* w_kn;   // the layer's OTHER packing, [k][n] rows of weight_ld(Cout) elements (pointwise layers: wb for the forward pass, wf for the
+  int ldw_kn;         // data gradient); null when the caller passes one image only.  The 224 x 384 kernel (igemm224.hip) takes its weights from it.
   int M;       // END of this launch's pixel range (per phase); N*Qh*Qw when the launch covers the layer
   int m_beg;   // first pixel of this launch's range (a multiple of 256): the mixed plan of run_gather cuts a layer into a
                // 256-tile launch over [0, m_beg') and a 128-tile launch over [m_beg', M)
@@ -87,6 +89,11 @@ void igemm256_set_splitk(int v);
 bool pw384_eligible(const IgemmParams& p);
 int launch_pw384(const IgemmParams& p, int npb, hipStream_t st);
 inline long pw384_tiles(const IgemmParams& p, int npb) { return (long)((p.g.Cout + 383) / 384) * ((p.M + 32 * npb - 1) / (32 * npb)); }
+
+// igemm224.hip: pointwise layers on a 224 x 384 tile with 32-deep weight stages from the [k][n] packing (p.w_kn) and three-deep operand rings
+bool pw224_eligible(const IgemmParams& p);
+int launch_pw224(const IgemmParams& p, hipStream_t st);
+inline long pw224_tiles(const IgemmParams& p) { return (long)((p.g.Cout + 383) / 384) * ((p.M + 223) / 224); }
 
 // igemm192.hip: pointwise layers with few pixels (local batch 2) on a 128 x 192 tile, eight waves, four 64-deep ring stages
 long pw192_tiles(const IgemmParams& p);

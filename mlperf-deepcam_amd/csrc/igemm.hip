@@ -549,7 +549,9 @@ static int g_pw384 = 1;
 static int g_pw192 = 1;             // 128 x 192 tiles for one-round launches of few pixels ("pw192")
 static int g_zfill = 1;             // 1 x 1 stride-2 data gradients written first-hand: one launch over phase (0, 0) stores all four phases ("igemm_zfill")
 static int g_pw384_k64 = 1;         // 256 x 384 tiles with 128-byte K rows where the planner picks that tile ("pw384_k64")
+static int g_pw224 = 1;             // 224 x 384 tiles with weights from the [k][n] packing where the caller passes it ("pw224"; 2: whenever eligible)
 static int pw384_plan(const IgemmParams& p) {
+  if (g_pw224 == 2 && pw224_eligible(p)) return 224;
   if (g_pw384 == 0 || !pw384_eligible(p)) return 0;
   if (g_pw384 == 2) return 8;
   if (g_pw384 == 3) return 4;
@@ -569,6 +571,8 @@ static int pw384_plan(const IgemmParams& p) {
   const long t192 = pw192_tiles(p);
   if (g_pw192 && best >= 1e9 && t192 >= 160 && t192 <= 256 && p.g.Cin >= 128 && p.g.Cout * 10 >= (long)cdiv(p.g.Cout, 192) * 192 * 9) return 192;
   if (best >= 0.9 * c_old) return 0;
+  // where the 256-pixel tile with 64-deep stages would run: the 224-pixel tile when it is ONE round too (728 -> 728 at M = 27 648: 248 tiles)
+  if (c8 < c4 && k64 && g_pw224 && pw224_eligible(p) && pw224_tiles(p) <= 256 && cdiv(t8, 256) == 1) return 224;
   return c8 < c4 ? (k64 ? 64 : 8) : 4;
 }
 
@@ -588,7 +592,7 @@ static int check_view(const void* ptr, int ld, int c, int dtype, const char* wha
 
 static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int Wi, const void* in, int ldin,
                       const void* w, const float* bias, void* out, int ldout, float* slab, int accumulate,
-                      void* stream, bool out32 = false, const BnBwdEpi* bst = nullptr) {
+                      void* stream, bool out32 = false, const BnBwdEpi* bst = nullptr, const void* w_kn = nullptr) {
   DC_REQUIRE(d != nullptr, "dc_conv: null descriptor");
   DC_REQUIRE(d->dtype == DC_F32 || d->dtype == DC_BF16, "dc_conv: bad dtype");
   DC_REQUIRE(d->transposed || d->k == 1 || d->k == 3, "dc_conv: kernel size must be 1 or 3");
@@ -603,6 +607,8 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   p.x = in; p.w = w; p.y = out; p.bias = bias; p.slab = slab;
   p.N = N; p.ldx = ldin; p.ldy = ldout;
   p.ldw = weight_ld(p.g.Cin);
+  p.w_kn = w_kn;
+  p.ldw_kn = weight_ld(p.g.Cout);
   const long M = (long)N * p.g.Qh * p.g.Qw;
   DC_REQUIRE(M < (1L << 31) - BM, "dc_conv: too many pixels for 32-bit indexing");
   p.M = (int)M;
@@ -631,7 +637,7 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   if (bst == nullptr && g_thin_fwd && thin_fwd_eligible(p.g, d->dtype, bias != nullptr, accumulate, out32))
     return launch_thin_fwd(p.g, N, in, ldin, w, p.ldw, out, ldout, slab, p.mtiles * p.g.os * p.g.os, st);
   if (d->dtype == DC_BF16 && !out32 && bst == nullptr) {      // (the BatchNorm-backward epilogue lives in the LDS-epilogue kernels)
-    if (const int npb = pw384_plan(p)) return npb == 192 ? launch_pw192(p, st) : launch_pw384(p, npb, st);
+    if (const int npb = pw384_plan(p)) return npb == 192 ? launch_pw192(p, st) : npb == 224 ? launch_pw224(p, st) : launch_pw384(p, npb, st);
   }
   if (d->dtype == DC_BF16 && !out32 && g_igemm256 != 0) {
     if (g_igemm256 == 2 || igemm256_wins(p)) {
@@ -940,6 +946,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "igemm256p_wgs") == 0) { g_igemm256p_wgs = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256p_min") == 0) { g_igemm256p_min = value; return 0; }
   if (name != nullptr && strcmp(name, "pw384_k64") == 0) { g_pw384_k64 = value; return 0; }
+  if (name != nullptr && strcmp(name, "pw224") == 0) { g_pw224 = value; return 0; }
   if (name != nullptr && strcmp(name, "pw192") == 0) { g_pw192 = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm_zfill") == 0) { g_zfill = value; return 0; }
   if (name != nullptr && strcmp(name, "igemm256_splitk") == 0) { igemm256_set_splitk(value); return 0; }
@@ -972,7 +979,7 @@ extern "C" int dc_set_option(const char* name, int value) {
 // so that a switch one test leaves behind cannot change what the next one measures -- a stale "restore" of this kind once ran the model
 // tests on an experimental kernel), and the library applies the same table when it is loaded, so the table IS the default.
 static const struct { const char* name; int value; } kOptionDefaults[] = {
-    {"igemm_mode", 2}, {"igemm256", 1}, {"pw384", 1}, {"pw384_k64", 1}, {"pw192", 1}, {"igemm256p", 1}, {"igemm256p_wgs", 0}, {"igemm256p_min", 257},
+    {"igemm_mode", 2}, {"igemm256", 1}, {"pw384", 1}, {"pw384_k64", 1}, {"pw224", 1}, {"pw192", 1}, {"igemm256p", 1}, {"igemm256p_wgs", 0}, {"igemm256p_min", 257},
     {"thin_fwd", 1}, {"thin_tile", 1}, {"igemm256_rel", 0}, {"pack_blocks", 2048},
     {"igemm256_phase_fast", 1}, {"wgrad_target_blocks", 768},
     {"wgrad_mode", 1}, {"wgrad_min_steps", 16}, {"wgrad256", 1}, {"wgrad256_pad", 115}, {"thin_wgrad", 1}, {"wgrad256_slots", 192}, {"wgrad256_min_stages", 96},
@@ -1010,6 +1017,18 @@ extern "C" int dc_conv_stat_rows(const dc_conv_desc* d, int N, int Hi, int Wi) {
 extern "C" int dc_conv_fwd(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf,
                            const float* bias, void* y, int ldy, float* stat_slab, int accumulate, void* stream) {
   return run_gather(d, kFwd, N, Hi, Wi, x, ldx, wf, bias, y, ldy, stat_slab, accumulate, stream);
+}
+
+// dc_conv_fwd / dc_conv_dgrad with BOTH packed images of the layer: w is the one the plain entry point takes, w_kn the other one (forward: wb,
+// data gradient: wf), whose rows are [k][n].  Pointwise layers may then run on the 224 x 384 tile kernel (igemm224.hip), which streams its weight
+// stages from w_kn; every other layer ignores it.  Same results as the plain entry points, bit for bit (BatchNorm sums: another summation order).
+extern "C" int dc_conv_fwd_kn(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf, const void* wb,
+                              const float* bias, void* y, int ldy, float* stat_slab, int accumulate, void* stream) {
+  return run_gather(d, kFwd, N, Hi, Wi, x, ldx, wf, bias, y, ldy, stat_slab, accumulate, stream, false, nullptr, wb);
+}
+extern "C" int dc_conv_dgrad_kn(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb, const void* wf,
+                                void* dx, int lddx, int accumulate, void* stream) {
+  return run_gather(d, kDgrad, N, Hi, Wi, dy, lddy, wb, nullptr, dx, lddx, nullptr, accumulate, stream, false, nullptr, wf);
 }
 
 // `count` "same" dilated 3x3 convolutions (stride 1, pad == dil) of ONE input in ONE launch of the 256-tile kernel: the three
@@ -1056,6 +1075,7 @@ static int dilated_group_impl(const dc_conv_desc* d, int N, int Hi, int Wi, int 
   p.bst = BnBwdEpi{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
   p.N = N; p.ldx = ldx; p.ldy = ldy;
   p.ldw = weight_ld(p.g.Cin);
+  p.w_kn = nullptr; p.ldw_kn = 0;
   p.M = (int)M; p.m_beg = 0; p.phase_fast = 0; p.zero_page = nullptr;
   p.mtiles = cdiv(M, BM);
   p.accumulate = 0;

@@ -1,0 +1,399 @@
+// Pointwise (1x1, stride 1) conv forward / data gradient as a GEMM on a 224 pixel x 384 channel tile, weights from the [k][n] packing.
+//
+// Why a fourth tile shape (round 6).  pw384_kernel (igemm384.hip) runs the 728 -> 728 layers of the middle flow -- 27.9 % of the network's FLOPs --
+// as 216 tiles of 256 x 384 on 256 CUs in 43 us: 4 us of prologue (an 80 KiB first stage), a 25 us K loop against 16.8 us of MFMA, 8.5 us of
+// output burst.  Its 64-deep stages of 128-byte K rows (whole L2 lines per LDS-DMA row piece) are 80 KiB each, so the ring is TWO stages = the
+// CU's whole LDS and only one stage is ever in flight: the fill runs in bursts, ~40 KiB in flight on average, and the probes of round 3 showed
+// fill and MFMA time adding up instead of overlapping.  What changes here:
+//
+//   weights   come from the OTHER packing of the layer, [k][n] (for the forward pass wb = [cin][cout], for the data gradient wf = [cout][cin]:
+//             both exist, dc_pack_all writes them).  A row of k is 384 contiguous channels = 768 B = six whole L2 lines, so a weight stage
+//             can be 32 deep and still move whole lines: 24 KiB instead of 48.  The MFMA's A fragment (channel per lane, 8 consecutive k)
+//             comes out of the [k][n] image through ds_read_b64_tr_b16, as wgrad384.hip reads its operands: quads of 64 channels,
+//             [quad][32 k rows][128 B], the four 32-byte chunks of a row XOR-ed with key(row) on the DMA's source address.  Lane group fg
+//             reads rows 8 fg .. 8 fg + 3 and 8 fg + 4 .. 8 fg + 7 (k = 8 fg + e as in every other GEMM kernel here: same MFMA, same K order,
+//             outputs bit for bit those of the other tile shapes), so a half-wave touches rows {0..3, 8..11} and the conflict-free key is
+//             ((row >> 1) & 1) | (((row >> 3) & 1) << 1); both reads of a fragment share a base register (512 B apart).
+//   pixels    stay [pixel][128 B] in 64-deep stages (pw384's K64 image and swizzle, ds_read_b128 fragments re-read in place).
+//   ring      THREE weight stages (3 x 24 KiB) and THREE pixel stages (3 x 28 KiB) = 156 KiB: W[s+2] and half of P[S+2] are issued during
+//             step s, so 52 - 92 KiB are in flight at any time, and the first MFMA waits for 52 KiB instead of 80.
+//   tile      224 pixels: 27 648 pixels are 124 x 2 = 248 tiles, i.e. 248 of the 256 CUs work (216 before) on 12.5 % fewer MFMAs and 5 % fewer
+//             fill bytes each.  8 waves = 2 pixel groups of 112 (7 blocks of 16) x 4 channel groups of 96 (6 blocks): 168 accumulator
+//             registers per wave.  Wave wc owns chunk pair wc & 1 (32 channels) of the quads (wc >> 1) + 2 u, u = 0..2: the two 16-channel
+//             blocks of a pair are adjacent, so the register epilogue's lane-pair exchange still stores 64 contiguous bytes per pixel, and a
+//             wave's six A fragments are two lane-constant bases plus immediates.
+//   schedule  igemm384.hip's: fragments two channel blocks ahead, counted lgkmcnt, the two waves of a SIMD issue their LDS-DMAs in different
+//             blocks of a step, ONE barrier per 32-deep step in front of its last channel block.
+//   hazards   RAW: in-order vmcnt.  A wave's issue order is ... W[s+1] | P-part(s), W[s+2]; at the end of step s it waits
+//             vmcnt(3 + P-part(s)): W[s+1] and everything older (all of P[S+1]) have landed; then the barrier.  WAR: W[s+2] goes into the slot
+//             of W[s-1], P[S+2] into the slot of P[S-1]; their last reads were waited for (lgkmcnt(0)) before the barrier of step s-1 / 2S-1.
+//             The last two steps issue nothing and wait vmcnt(0); pixel stages past the K extent are filled from the zero page.
+//   slab      BatchNorm partial sums: ONE row per tile (row = the tile's pixel-tile index) in the layer's usual slab of cdiv(M, 128) rows; the
+//             rows no tile owns are written as zeros by the first tiles, so the finalize kernels need not know the tile shape.
+#include <type_traits>
+
+#include "igemm.h"
+
+namespace dc {
+
+namespace {
+
+constexpr int TN = 384;                      // channels per workgroup
+constexpr int WSTG = 32 * TN * 2;            // one 32-deep weight stage: six quads of [32 k][64 n] = 24 KiB
+constexpr int NWS = 3, NPS = 3;              // ring depths
+constexpr int NPB = 7;                       // pixel blocks of 16 per wave
+
+static __device__ __attribute__((aligned(256))) unsigned char zero_page224[256];
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+__device__ inline uint32_t swap_rows16(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); }
+__device__ inline float row_sum16(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
+// MFMA, LDS fragment reads and their waits as (volatile) statements in one hand-placed order (igemm384.hip explains why)
+__device__ inline void mfma_v(f32x4& c, const bf16x8& av, const bf16x8& bv) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+}
+template <int OFF>
+__device__ inline void lds_read16(bf16x8& dst, uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+// one A fragment (16 channels x 32 k, channel per lane) = two transposing reads: k rows 8 fg .. + 3 and 8 fg + 4 .. + 7 (512 B apart)
+template <int OFF>
+__device__ inline void lds_read_tr(u32x4& dst, uint32_t addr) {
+  static_assert(OFF >= 0 && OFF + 512 < 65536, "ds_read offset field");
+  u32x2 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 512) : "memory");
+  dst[0] = lo[0]; dst[1] = lo[1]; dst[2] = hi[0]; dst[3] = hi[1];
+}
+template <int N>
+__device__ inline void lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ inline void vm_lgkm0_wait() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+template <int I, int N, typename F>
+__device__ inline void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int GP>
+struct Cfg {
+  static constexpr int GC = 8 / GP;                       // channel groups: 4
+  static constexpr int NCB = TN / 16 / GC;                // channel blocks per wave: 6
+  static constexpr int TM = GP * NPB * 16;                // pixels per workgroup: 224
+  static constexpr int PSTG = TM * 128;                   // one 64-deep pixel stage: 28 KiB
+  static constexpr int NPI = PSTG / 1024;                 // LDS-DMA instructions per pixel stage: 28
+  static constexpr int PSLOTS = (NPI + 7) / 8;            // per wave: 4 (the last one only on waves < NPI - 8 * (PSLOTS - 1))
+  static constexpr int HP = PSLOTS / 2;                   // per wave and 32-deep step: 2
+  static constexpr int POFF = NWS * WSTG;                 // LDS offset of the pixel ring
+  static constexpr int RING = NWS * WSTG + NPS * PSTG;    // 156 KiB
+  static_assert(PSLOTS % 2 == 0 && NCB % 3 == 0 && NCB % 2 == 0 && RING <= 160 * 1024, "plan");
+};
+
+template <int GP>
+__global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
+  typedef Cfg<GP> K;
+  constexpr int NCB = K::NCB, GC = K::GC, HP = K::HP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GatherGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave / GC;   // pixel group (112 pixels)
+  const int wc = wave % GC;    // channel group: chunk pair wc & 1 of the quads (wc >> 1) + 2 u
+  const bool late = wave >= 4; // the second wave of its SIMD: issues its LDS-DMAs in later blocks of a step
+
+  // XCD-aware tile order: consecutive tiles of an XCD are the channel tiles of one pixel tile (they share its pixel rows in L2)
+  const int ntn = (g.Cout + TN - 1) / TN;
+  const int nwg = gridDim.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + xslot;
+  const int tm = tile / ntn;
+  const int n0 = (tile % ntn) * TN, m0 = tm * K::TM;
+  const int nsteps = (g.Cin + 31) / 32;       // 32-deep steps (>= 4: eligibility)
+
+  // ---- LDS-DMA bookkeeping --------------------------------------------------------------------------------------------------
+  // Weight stage (24 instructions): instruction id = 4 quad + rg fills k rows 8 rg .. + 7 of quad `quad`; wave w issues ids w, w + 8, w + 16,
+  // i.e. rg = w & 3 and quads (w >> 2) + 2 i.  Lane: k row 8 rg + (lane >> 3), 16-byte piece lane & 7 of the 128-byte row = half (piece & 1) of
+  // physical chunk piece >> 1, which holds logical chunk (piece >> 1) ^ key(row).
+  // Pixel stage (28 instructions): id q fills pixel rows 8 q .. + 7; wave w issues q = w + 8 i (i = 3 only on waves < 4).  Lane: row 8 q +
+  // (lane >> 3), physical slot lane & 7 holds logical slot (lane & 7) ^ ((row >> 1) & 7) (pw384's K64 swizzle).
+  const uintptr_t zp = (uintptr_t)p.zero_page;
+  const uintptr_t xbase = (uintptr_t)p.x, wbase = (uintptr_t)p.w_kn;
+  const int krow = 8 * (wave & 3) + (lane >> 3);
+  const int wkey = ((krow >> 1) & 1) | (((krow >> 3) & 1) << 1);
+  unsigned srcw[3], srcp[K::PSLOTS];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int ncol = ((wave >> 2) + 2 * i) * 64 + ((((lane & 7) >> 1) ^ wkey) << 4) + (lane & 1) * 8;
+    srcw[i] = n0 + ncol < g.Cout ? (unsigned)(((size_t)krow * p.ldw_kn + n0 + ncol) * 2) : ~0u;
+  }
+  const int pslot = (lane & 7) ^ (((4 * wave) + (lane >> 4)) & 7);     // logical 16-byte K slot this lane fetches
+#pragma unroll
+  for (int i = 0; i < K::PSLOTS; ++i) {
+    const int m = m0 + 8 * (wave + 8 * i) + (lane >> 3);
+    srcp[i] = m < p.M ? (unsigned)(((size_t)m * p.ldx + pslot * 8) * 2) : ~0u;
+  }
+  const bool has_last = wave + 8 * (K::PSLOTS - 1) < K::NPI;           // (wave-uniform) this wave owns a last pixel instruction
+  const unsigned wstep = (unsigned)p.ldw_kn * 64u;                     // bytes between the k rows of consecutive steps (32 rows)
+  // wdst / pdst: LDS byte offset of the ring slot the stage goes to
+  auto issue_w = [&](int i, int s, uint32_t wdst) {
+    const bool ok = (srcw[i] != ~0u) & (32 * s + krow < g.Cin);
+    const uintptr_t a = ok ? wbase + (srcw[i] + (unsigned)s * wstep) : zp;
+    __builtin_amdgcn_global_load_lds((gas_ptr)a, (lds_ptr)(smem + wdst + (wave + 8 * i) * 1024), 16, 0, 0);
+  };
+  auto issue_p = [&](int i, int S, uint32_t pdst) {
+    const bool ok = (srcp[i] != ~0u) & (64 * S + pslot * 8 < g.Cin);
+    const uintptr_t a = ok ? xbase + (srcp[i] + (unsigned)S * 128u) : zp;
+    __builtin_amdgcn_global_load_lds((gas_ptr)a, (lds_ptr)(smem + pdst + (wave + 8 * i) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[NCB][NPB];   // [channel block][pixel block]
+#pragma unroll
+  for (int i = 0; i < NCB; ++i)
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  // A fragment of channel block i: quad (wc >> 1) + 2 (i >> 1), chunk 2 (wc & 1) + (i & 1); the lane supplies k row 8 fg + (fr >> 2) (its key is
+  // (fr >> 3) | ((fg & 1) << 1), the same for the row 4 further) and the 8-byte column group fr & 3 of the chunk
+  const int akey = ((fr >> 3) & 1) | ((fg & 1) << 1);
+  const int arow = 8 * fg + (fr >> 2);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem;
+  uint32_t a_base[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) a_base[e] = lds0 + (wc >> 1) * 4096 + arow * 128 + (((2 * (wc & 1) + e) ^ akey) << 5) + (fr & 3) * 8;
+  // B fragment of pixel block j, K half h: row grp * 112 + 16 j + fr, logical slot 4 h + fg
+  const uint32_t b_off = K::POFF + (grp * (NPB * 16) + fr) * 128 + ((fg ^ ((fr >> 1) & 7)) << 4);      // (without lds0: K half 1 is b_off ^ 64)
+  static_assert(NCB % 3 == 0, "fa ring");
+  u32x4 fa[3];
+  bf16x8 fb[NPB];
+
+  // One 32-deep step s (H = s & 1 at compile time).  Fragments of this step come from wcur (weight slot) and are already requested for
+  // channel blocks 0, 1 and all pixel blocks; the last block requests the next step's from wnxt / bnxt.  dma: issue W[s+2] and the H half of
+  // P[(s >> 1) + 2] during this step and wait for W[s+1] at its end; otherwise (the last two steps) issue nothing and wait for everything.
+  // Outstanding LDS reads at the top of a step, oldest first: fa[0] (2 instructions), fa[1] (2), fb[0] .. fb[6].
+  // wdst / pdst: the ring slots (LDS byte offsets) of W[s+2] and P[(s >> 1) + 2].
+  auto step = [&](auto h_tag, uint32_t wcur, uint32_t wnxt, uint32_t bnxt, int s, bool dma, uint32_t wdst, uint32_t pdst) {
+    constexpr int H = decltype(h_tag)::value;
+    const int S = s >> 1;
+    // this step's LDS-DMAs in issue order: pixel slots 2 H, 2 H + 1, then the three weight instructions
+    auto dma_k = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k < HP) {
+        constexpr int slot = HP * H + k;
+        if (slot < K::PSLOTS - 1 || has_last) issue_p(slot, S + 2, pdst);
+      } else {
+        issue_w(k - HP, s + 2, wdst);
+      }
+    };
+    constexpr int ND = HP + 3;                         // 5
+    // blocks in which the early waves (0..3) and the late waves (4..7) issue instruction k
+    constexpr int EB[5] = {0, 0, 1, 1, 2}, LB[5] = {2, 3, 3, 4, 4};
+    static_assert(ND == 5, "issue plan");
+    static_for<0, NCB>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i + 2 < NCB) lds_read_tr<((i + 2) >> 1) * 8192>(fa[(i + 2) % 3], wcur + a_base[(i + 2) & 1] - lds0);   // two blocks ahead
+      if (dma) {
+        static_for<0, ND>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if constexpr (EB[k] == i) { if (!late) dma_k(kc); }
+          if constexpr (LB[k] == i) { if (late) dma_k(kc); }
+        });
+      }
+      if constexpr (i == NCB - 1) {
+        // stage end: W[s+1] (and with it everything older) has landed for this wave; this step's own instructions stay in flight
+        if (dma) {
+          if (H == 0 || has_last) vm_lgkm0_wait<3 + HP>(); else vm_lgkm0_wait<3 + HP - 1>();
+        } else {
+          vm_lgkm0_wait<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        lds_read_tr<0>(fa[0], wnxt + a_base[0] - lds0);                              // next step's first two weight fragments
+        lds_read_tr<0>(fa[1], wnxt + a_base[1] - lds0);
+      }
+      static_for<0, NPB>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        // counted waits (LDS reads return in order).  Block 0: fa[0] (2), fa[1] (2), fb[0..6], then fa[2] (2) are outstanding: MFMA j needs all
+        // but the newest (NPB - 1 - j) + 2.  Blocks 1 .. NCB-3: fa[i] and the two fragments (4 instructions) requested after it; block NCB-2:
+        // one fragment (2) after it; the last block waited for everything in front of the barrier.
+        if constexpr (i == 0) lgkm_wait<NPB - 1 - j + 2>();
+        else if constexpr (j == 0 && i < NCB - 2) lgkm_wait<4>();
+        else if constexpr (j == 0 && i == NCB - 2) lgkm_wait<2>();
+        mfma_v(acc[i][j], __builtin_bit_cast(bf16x8, fa[i % 3]), fb[j]);
+        if constexpr (i == NCB - 1) lds_read16<j * 2048>(fb[j], bnxt);                // re-read in place for the next step
+      });
+    });
+  };
+
+  // ---- prologue: W[0], P[0], P[1], W[1] in flight (in this order: see "hazards"), W[0] and P[0] landed, first fragments requested ----------
+#pragma unroll
+  for (int i = 0; i < 3; ++i) issue_w(i, 0, 0);
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < K::PSLOTS; ++i)
+      if (i < K::PSLOTS - 1 || has_last) issue_p(i, q, K::POFF + q * K::PSTG);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) issue_w(i, 1, WSTG);
+  if (has_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + K::PSLOTS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + K::PSLOTS - 1) : "memory");
+  __builtin_amdgcn_s_barrier();
+  lds_read_tr<0>(fa[0], a_base[0]);
+  lds_read_tr<0>(fa[1], a_base[1]);
+  static_for<0, NPB>([&](auto jc) { lds_read16<decltype(jc)::value * 2048>(fb[decltype(jc)::value], lds0 + b_off); });
+  {
+    int s = 0;
+    // weight slots (byte offsets) of steps s, s + 1, s + 2; pixel slots (byte offsets inside the pixel ring) of stages S, S + 1, S + 2
+    uint32_t w0 = 0, w1 = WSTG, w2 = 2 * WSTG;
+    uint32_t p0 = 0, p1 = K::PSTG, p2 = 2 * K::PSTG;
+    while (true) {
+      step(std::integral_constant<int, 0>{}, lds0 + w0, lds0 + w1, lds0 + ((b_off + p0) ^ 64), s, s + 2 < nsteps, w2, K::POFF + p2);
+      if (++s == nsteps) break;
+      step(std::integral_constant<int, 1>{}, lds0 + w1, lds0 + w2, lds0 + b_off + p1, s, s + 2 < nsteps, w0, K::POFF + p2);
+      if (++s == nsteps) break;
+      { const uint32_t t = w0; w0 = w2; w2 = w1; w1 = t; }      // two steps on: (w0, w1, w2) <- (w2, w0, w1)
+      { const uint32_t t = p0; p0 = p1; p1 = p2; p2 = t; }      // one stage on
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the last step's look-ahead reads; the ring is reused below)
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue from the accumulator registers (igemm384.hip's) -------------------------------------------------------------------
+  // A lane holds, per MFMA tile (i, j), channels fg*4 .. +3 of channel block i for pixel fr of pixel block j.  Blocks 2 pr and 2 pr + 1 are the
+  // two halves of one 32-channel chunk pair: lanes l and l ^ 16 trade halves so that the even-fg lane keeps 8 consecutive channels of block
+  // 2 pr and the odd-fg lane 8 of block 2 pr + 1 (64 contiguous bytes per pixel and store instruction).
+  const bool odd = fg & 1;
+  bf16* __restrict__ yg = reinterpret_cast<bf16*>(p.y);
+  const bool do_stats = p.slab != nullptr;
+  float* red = reinterpret_cast<float*>(smem);      // [pixel group][sum, sum of squares][384]
+#pragma unroll
+  for (int pr = 0; pr < NCB / 2; ++pr) {
+    const int i0 = 2 * pr;
+    const int cpair = ((wc >> 1) + 2 * pr) * 64 + (wc & 1) * 32;                   // first channel of the pair inside the tile
+    const int chl = cpair + (odd ? 16 : 0) + (fg >> 1) * 8;                        // first of this lane's 8 channels after the trade
+    const int ch0 = n0 + chl;
+    const bool chok = ch0 < g.Cout;                                               // Cout is a multiple of 8: all or nothing
+    float ba[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};             // bias of the channels this lane COMPUTED
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ca = n0 + cpair + fg * 4 + r, cb = ca + 16;
+        if (ca < g.Cout) ba[r] = p.bias[ca];
+        if (cb < g.Cout) bb[r] = p.bias[cb];
+      }
+    }
+    float st[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st[0][e] = st[1][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+      const int m = m0 + grp * (NPB * 16) + j * 16 + fr;
+      const uint32_t a0 = pack2_bf16(acc[i0][j][0] + ba[0], acc[i0][j][1] + ba[1]);
+      const uint32_t a1 = pack2_bf16(acc[i0][j][2] + ba[2], acc[i0][j][3] + ba[3]);
+      const uint32_t b0 = pack2_bf16(acc[i0 + 1][j][0] + bb[0], acc[i0 + 1][j][1] + bb[1]);
+      const uint32_t b1 = pack2_bf16(acc[i0 + 1][j][2] + bb[2], acc[i0 + 1][j][3] + bb[3]);
+      const uint32_t r0 = swap_rows16(odd ? a0 : b0), r1 = swap_rows16(odd ? a1 : b1);
+      vec16 v;
+      v.w[0] = odd ? r0 : a0;
+      v.w[1] = odd ? r1 : a1;
+      v.w[2] = odd ? b0 : r0;
+      v.w[3] = odd ? b1 : r1;
+      if (m < p.M && chok) {
+        bf16* dst = yg + (size_t)m * p.ldy + ch0;
+        float f[8];
+        unpack(v, f, bf16());
+        if (p.accumulate) {
+          float o[8];
+          unpack(ldg16(dst), o, bf16());
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += o[e];
+          pack(v, f, bf16());
+          unpack(v, f, bf16());
+        }
+        stg16(dst, v);
+        if (do_stats) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            st[0][e] += f[e];
+            st[1][e] = fmaf(f[e], f[e], st[1][e]);
+          }
+        }
+      }
+    }
+    if (do_stats) {
+      // sums over the 16 pixel lanes of a DPP row; lane fr of the row keeps value fr (which = fr >> 3, channel e = fr & 7)
+      float mine = 0.f;
+#pragma unroll
+      for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = row_sum16(st[w][e]);
+          if (fr == w * 8 + e) mine = t;
+        }
+      red[(grp * 2 + (fr >> 3)) * TN + chl + (fr & 7)] = mine;
+    }
+  }
+  if (do_stats) {
+    __syncthreads();
+    // one slab row per tile: the pixel groups folded in a fixed order; slab rows no tile owns (the slab has a row per 128 pixels) are zeros
+    const int rows = p.mtiles, ntm = (p.M + K::TM - 1) / K::TM;
+    for (int i = tid; i < 2 * TN; i += 512) {
+      const int c = i % TN, which = i / TN;
+      if (n0 + c < g.Cout) {
+        float v = red[which * TN + c];
+#pragma unroll
+        for (int gq = 1; gq < GP; ++gq) v += red[(gq * 2 + which) * TN + c];
+        float* col = p.slab + (size_t)which * rows * g.Cout + n0 + c;
+        col[(size_t)tm * g.Cout] = v;
+        for (int r = tm + ntm; r < rows; r += ntm) col[(size_t)r * g.Cout] = 0.f;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool pw224_eligible(const IgemmParams& p) {
+  const GatherGeom& g = p.g;
+  return p.w_kn != nullptr && g.ntaps == 1 && g.os == 1 && g.is == 1 && g.taps[0].dy == 0 && g.taps[0].dx == 0 && p.m_beg == 0 && p.ngroup <= 1 &&
+         g.Cin >= 128 && g.Cin % 8 == 0 && g.Cout % 8 == 0 && (((uintptr_t)p.w_kn) & 15) == 0 &&
+         (size_t)p.M * p.ldx * 2 < (1ull << 32) && ((size_t)g.Cin + 32) * p.ldw_kn * 2 < (1ull << 32);      // 32-bit row offsets
+}
+
+int launch_pw224(const IgemmParams& p_in, hipStream_t st) {
+  static const void* zero_dev = nullptr;
+  static hipError_t init_err = hipSuccess;
+  typedef Cfg<2> C2;
+  auto k2 = &pw224_kernel<2>;
+  DC_ONCE({
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, C2::RING);
+    void* zp = nullptr;
+    init_err = hipGetSymbolAddress(&zp, HIP_SYMBOL(zero_page224));
+    zero_dev = zp;
+  });
+  if (init_err != hipSuccess) return dc_set_error(init_err, __FILE__, __LINE__);
+  IgemmParams p = p_in;
+  p.zero_page = zero_dev;
+  const long tiles = pw224_tiles(p);
+  hipLaunchKernelGGL(k2, dim3((unsigned)tiles), dim3(512), C2::RING, st, p);
+  DC_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace dc

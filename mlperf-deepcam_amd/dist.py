@@ -213,7 +213,9 @@ class GradReducer:
         self.hook(engine)
         self.launched = 0
         self.averaging_in_optimizer = False     # set by TrainStep.attach_reducer: the 1/world then rides in the optimizer kernel
+        self._owns_comm = False
         if self.collective == "library" and (self.comm is None or isinstance(self.comm, str)):
+            self._owns_comm = True
             # default: an RCCL communicator of the library's own; "callback" (or DC_GRAD_COLLECTIVE_TRANSPORT=callback): torch.distributed does
             # the reduction inside a host callback (gloo tests)
             transport = self.comm if isinstance(self.comm, str) else os.environ.get("DC_GRAD_COLLECTIVE_TRANSPORT", "rccl")
@@ -221,6 +223,19 @@ class GradReducer:
                 self.comm = LibraryComm.over_torch(self._resolve, group, sync_stream=engine.grads.is_cuda)
             else:
                 self.comm = LibraryComm.rccl(group)
+
+    def close(self) -> None:
+        """Give back the communicator this reducer created (an ncclComm_t, a stream and two events on the RCCL transport); one the caller
+        passed in stays the caller's."""
+        if self._owns_comm and isinstance(self.comm, LibraryComm):
+            self.comm.close()
+            self._owns_comm = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _resolve(self, ptr: int, count: int, dtype_code: int):
         """callback transport: the arena view an address handed to dc_grad_allreduce_enqueue refers to"""

@@ -141,8 +141,9 @@ def test_library_collective_two_ranks_callback_transport():
 
 
 def test_library_collective_rccl_single_rank():
-    """The library's RCCL transport with the one rank a one-GPU box allows: ncclGetUniqueId / ncclCommInitRank resolved at run time, in-place
-    ncclAllReduce of arena ranges on the library's communication stream behind the side stream, the wait in front of the optimizer."""
+    """The library's RCCL transport brought up with the one rank a one-GPU box allows: ncclGetUniqueId / ncclCommInitRank resolved at run time and
+    the reducer wired to it.  (At world size 1 the reducer has nothing to reduce and never reaches ncclAllReduce: that call is exercised by
+    test_library_rccl_allreduce_on_a_device_buffer below.)"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29630", os.path.join(ROOT, "tests", "dist_worker.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, DC_TEST_BACKEND="nccl", DC_GRAD_COLLECTIVE="lib"), capture_output=True, text=True, timeout=300)
@@ -161,3 +162,44 @@ def test_bench_two_ranks_replayed_from_the_launch_list():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["config"]["launch_list_replay"] is True and out["comm"]["collective"] == "library (callback)" and out["value"] > 0
     assert out["loss_last_step"] < 20
+
+
+def test_library_rccl_allreduce_on_a_device_buffer():
+    """the hand-declared RCCL ABI of csrc/comm.cpp, driven directly (no GradReducer, which skips the collective at world size 1):
+    dc_comm_create with a unique id at world 1 brings up a real ncclComm_t; dc_grad_allreduce_enqueue runs ncclAllReduce(SUM, in place) with the
+    library's dtype codes (fp32 = 7, bf16 = 9) on the library's communication stream BEHIND a kernel that fills the buffer on a non-default
+    compute stream, and dc_grad_allreduce_wait orders the compute stream behind it.  The sum over one rank is the buffer itself, so: values
+    unchanged, the fill visible to the collective (ev_in ordering), a kernel enqueued after the wait sees the result (ev_out ordering),
+    info()['enqueued'] advanced.  Runs in a child process: a communicator's teardown must not meet the test runner's other GPU state."""
+    code = r"""
+import ctypes as C, sys, torch
+sys.path.insert(0, %r)
+from mlperf_deepcam_amd import lib as L, dist as ddist
+comm = ddist.LibraryComm.rccl()
+assert comm.info()["transport"] == "rccl" and comm.info()["world"] == 1
+compute = torch.cuda.Stream()
+n = 1 << 22
+for dt, code in ((torch.float32, L.DC_F32), (torch.bfloat16, L.DC_BF16)):
+    buf = torch.zeros(n, dtype=dt, device="cuda")
+    out = torch.zeros(n, dtype=dt, device="cuda")
+    ref = (torch.arange(n, device="cuda") % 251).to(dt)
+    torch.cuda.synchronize()
+    before = comm.info()["enqueued"]
+    with torch.cuda.stream(compute):
+        for _ in range(20):                       # keep the compute stream busy so that an unordered collective would read zeros
+            buf.copy_(ref * 0)
+        buf.copy_(ref)
+        L.call("dc_grad_allreduce_enqueue", comm.h, C.c_void_p(buf.data_ptr()), C.c_size_t(n), code, C.c_void_p(compute.cuda_stream))
+        L.call("dc_grad_allreduce_wait", comm.h, C.c_void_p(compute.cuda_stream))
+        out.copy_(buf)                            # behind the wait: sees the reduced buffer
+    compute.synchronize()
+    torch.cuda.synchronize()
+    assert comm.info()["enqueued"] == before + 1
+    assert torch.equal(buf, ref) and torch.equal(out, ref), dt
+# an empty range is counted and skipped
+L.call("dc_grad_allreduce_enqueue", comm.h, None, C.c_size_t(0), L.DC_F32, C.c_void_p(compute.cuda_stream))
+comm.close()
+print("RCCL_DIRECT ok")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_DIRECT ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -174,6 +174,65 @@ def test_conv_pointwise_384_tile_kernel_same_bits(shape):
         np.testing.assert_allclose(got[0][2].numpy(), other[2].numpy(), rtol=2e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(728, 728, 3, 19, 17), (728, 728, 2, 48, 72), (136, 392, 2, 21, 13), (1536, 776, 1, 24, 20), (128, 384, 1, 16, 14),
+                                   (728, 728, 8, 48, 72)],
+                         ids=["ragged969", "middle_flow_b2", "one_and_a_bit_tiles", "long_k_three_tiles", "four_steps_one_tile", "middle_flow_b8"])
+def test_conv_pointwise_224_tile_kernel_same_bits(shape):
+    """dc_conv_fwd_kn / dc_conv_dgrad_kn on the 224 x 384 kernel (csrc/igemm224.hip: weight stages from the [k][n] packing through transposing
+    LDS reads, three-deep rings), forced on every eligible call, against the plain entry points without it: same MFMA instruction and K order,
+    so outputs are bit-equal (forward, forward with bias in accumulate mode, data gradient through padded views); the BatchNorm slab keeps its
+    dc_conv_stat_rows rows (one per tile filled, the rest zeros) and its column sums agree up to the order of the additions; pad channels and
+    the slab rows of other layers stay untouched.  Shapes: ragged pixel / channel / K tiles, Cin = 128 (the shortest K loop: four steps, the
+    prologue's stages and the no-issue tail meet), three channel tiles, the middle flow at local batch 2 and 8."""
+    cin, cout, N, H, W = shape
+    dtype = torch.bfloat16
+    d = desc(dtype, 1, 1, 0, 1, 0, cin, cout)
+    x = q(rnd(N, cin, H, W, seed=1), dtype)
+    w = rnd(cout, cin, 1, 1, seed=2, scale=cin ** -0.5)
+    bias = rnd(cout, seed=4).to(dev())
+    gy = q(rnd(N, cout, H, W, seed=3), dtype)
+    nwf, nwb = C.c_size_t(), C.c_size_t()
+    L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
+    wf = torch.empty(nwf.value, dtype=dtype, device=dev())
+    wb = torch.empty(nwb.value, dtype=dtype, device=dev())
+    L.call("dc_conv_pack_weights", C.byref(d), vptr(w.to(dev())), vptr(wf), vptr(wb), S())
+    _, xv = to_nhwc(x, dtype, ld=cin + 16, off=8)
+    _, gyv = to_nhwc(gy, dtype)
+    rows = L.load().dc_conv_stat_rows(C.byref(d), N, H, W)
+    got = []
+    try:
+        for kn in (False, True):
+            L.call("dc_set_option", b"pw384", 0 if not kn else 1)
+            L.call("dc_set_option", b"pw224", 2 if kn else 0)
+            ybuf, yv = empty_nhwc(N, H, W, cout, dtype, ld=cout + 24, off=16)
+            slab = torch.full((3, rows, cout), float("nan"), device=dev())       # [2]: a neighbour's rows, must stay NaN
+            _, gxv = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
+            if kn:
+                L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), vptr(wb), None, vptr(yv), cout + 24, vptr(slab), 0, S())
+                y0 = from_nhwc(yv).clone()
+                L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), vptr(wb), vptr(bias), vptr(yv), cout + 24, None, 1, S())
+                L.call("dc_conv_dgrad_kn", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(wf), vptr(gxv), cin + 8, 0, S())
+            else:
+                L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, vptr(slab), 0, S())
+                y0 = from_nhwc(yv).clone()
+                L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), vptr(bias), vptr(yv), cout + 24, None, 1, S())
+                L.call("dc_conv_dgrad", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(gxv), cin + 8, 0, S())
+            torch.cuda.synchronize()
+            assert torch.isnan(ybuf[..., :16].float()).all() and torch.isnan(ybuf[..., 16 + cout:].float()).all()
+            assert torch.isnan(slab[2]).all() and not torch.isnan(slab[:2]).any()
+            got.append((y0, from_nhwc(yv), slab[:2].cpu(), from_nhwc(gxv)))
+    finally:
+        L.call("dc_set_option", b"pw384", 1)
+        L.call("dc_set_option", b"pw224", 1)
+    assert_close(got[0][0], F.conv2d(x, q(w, dtype)), dtype)
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1]) and torch.equal(got[0][3], got[1][3])
+    M = N * H * W
+    ntm = (M + 223) // 224
+    slab = got[1][2]
+    assert (slab[:, ntm:] == 0).all() and (slab[1, :ntm] > 0).all()                 # one row per tile, zeros behind them
+    np.testing.assert_allclose(got[0][2].double().sum(1).numpy(), slab.double().sum(1).numpy(), rtol=2e-5, atol=1e-3)
+
+
 PERSIST_CASES = [
     # name, k, stride, pad, dil, transposed, cin, cout, N, H, W, workgroups
     ("pw_ragged", 1, 1, 0, 1, 0, 728, 728, 2, 40, 52, 8),          # ragged K (728 = 22.75 chunks), ragged channel and pixel tiles
