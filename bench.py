@@ -135,7 +135,7 @@ def torch_gpu_baseline(H, W, local_batch, dev, mode="nhwc", timed_steps=5):
 
 class KernelTimer:
     """HIP-event timing of every launch of the two MFMA kernel families on the stream they run on:
-       igemm  dc::igemm256_kernel / dc::igemm256p_kernel / dc::pw384_kernel / dc::pw192_kernel / dc::igemm_kernel<T> / dc::tiny_gemm_kernel<T>
+       igemm  dc::igemm256_kernel / dc::igemm256p_kernel / dc::pw224_kernel / dc::pw384_kernel / dc::pw192_kernel / dc::igemm_kernel<T> / dc::tiny_gemm_kernel<T>
               (dc_conv_fwd + dc_conv_dgrad: dense conv forward and data gradient; the library's planner picks the tile shape per layer)
        wgrad  dc::wgrad384_kernel / dc::wgrad256_kernel / dc::wgrad_dma_kernel<T>  (dc_conv_wgrad_partial: dense conv weight gradient, split-K
               partial sums; a grouped call is ONE launch of the kernel for up to sixteen layers and counts as one) + dc::fold_kernel (dc_fold_slabs: the
@@ -143,7 +143,7 @@ class KernelTimer:
        Not in either family (neither its time nor its flop): dc::pw_bn_bwd_kernel (dc_pw_bn_bwd), the HBM-bound pass that does the BatchNorm backward
        apply, the data gradient and the weight gradient of the entry flow's two thin pointwise layers at once."""
 
-    FAMILY = {"dc_conv_fwd": "igemm", "dc_conv_dgrad": "igemm", "dc_conv_dgrad_bnstats": "igemm", "dc_conv_wgrad": "wgrad",
+    FAMILY = {"dc_conv_fwd": "igemm", "dc_conv_dgrad": "igemm", "dc_conv_fwd_kn": "igemm", "dc_conv_dgrad_kn": "igemm", "dc_conv_dgrad_bnstats": "igemm", "dc_conv_wgrad": "wgrad",
               "dc_conv_wgrad_group": "wgrad", "dc_conv_wgrad_partial": "wgrad"}
 
     def __init__(self, lib_module):
@@ -454,8 +454,8 @@ def main():
     barrier()
     if rank == 0:
         peak = PEAK[a.dtype]
-        names = {"igemm": f"dc::igemm256_kernel + dc::igemm256p_kernel + dc::pw384_kernel + dc::pw192_kernel + dc::igemm_kernel<{a.dtype}> (dense conv "
-                          "forward + data gradient: gather-form implicit GEMM; 256x256 (one tile per workgroup or persistent) / 256x384 / 128x192 "
+        names = {"igemm": f"dc::igemm256_kernel + dc::igemm256p_kernel + dc::pw224_kernel + dc::pw384_kernel + dc::pw192_kernel + dc::igemm_kernel<{a.dtype}> (dense conv "
+                          "forward + data gradient: gather-form implicit GEMM; 256x256 (one tile per workgroup or persistent) / 224x384 / 256x384 / 128x192 "
                           "eight-wave or 128x128 four-wave tile per layer)",
                  "wgrad": f"dc::wgrad384_kernel + dc::wgrad256_kernel + dc::wgrad_dma_kernel<{a.dtype}> + dc::fold_kernel (dense conv weight gradient: "
                           "split-K partial sums on 256x384 tiles of the [tap][ci] axis (pointwise and stride-1 3x3 layers), 256x256 or 128x128 tiles "

@@ -27,7 +27,7 @@
 //   hazards   RAW: in-order vmcnt.  A wave's issue order is ... W[s+1] | P-part(s), W[s+2]; at the end of step s it waits
 //             vmcnt(3 + P-part(s)): W[s+1] and everything older (all of P[S+1]) have landed; then the barrier.  WAR: W[s+2] goes into the slot
 //             of W[s-1], P[S+2] into the slot of P[S-1]; their last reads were waited for (lgkmcnt(0)) before the barrier of step s-1 / 2S-1.
-//             The last two steps issue nothing and wait vmcnt(0); pixel stages past the K extent are filled from the zero page.
+//             The last two steps issue nothing and wait vmcnt(0); pixel stages past the K extent are filled with zeros (every lane out of range).
 //   slab      BatchNorm partial sums: ONE row per tile (row = the tile's pixel-tile index) in the layer's usual slab of cdiv(M, 128) rows; the
 //             rows no tile owns are written as zeros by the first tiles, so the finalize kernels need not know the tile shape.
 #include <type_traits>
@@ -43,7 +43,6 @@ constexpr int WSTG = 32 * TN * 2;            // one 32-deep weight stage: six qu
 constexpr int NWS = 3, NPS = 3;              // ring depths
 constexpr int NPB = 7;                       // pixel blocks of 16 per wave
 
-static __device__ __attribute__((aligned(256))) unsigned char zero_page224[256];
 typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
@@ -93,6 +92,16 @@ __device__ inline void static_for(F&& f) {
   }
 }
 
+// diagnostic build (make stamps224; scripts/pw224_stamps.py): wave 0 of every workgroup leaves the 100 MHz real-time counter at kernel entry,
+// behind the prologue's barrier, behind the K loop and behind the drained stores, and the shader clock around the loop
+#ifdef DC_PW224_STAMPS
+__device__ unsigned long long pw224_stamp_buf[1024][8];
+#define PW224_STAMP(i) do { if (threadIdx.x == 0) { pw224_stamp_buf[blockIdx.x & 1023][i] = __builtin_amdgcn_s_memrealtime(); \
+                                                   pw224_stamp_buf[blockIdx.x & 1023][4 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define PW224_STAMP(i)
+#endif
+
 template <int GP>
 struct Cfg {
   static constexpr int GC = 8 / GP;                       // channel groups: 4
@@ -114,6 +123,7 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GatherGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
+  PW224_STAMP(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave / GC;   // pixel group (112 pixels)
   const int wc = wave % GC;    // channel group: chunk pair wc & 1 of the quads (wc >> 1) + 2 u
@@ -134,36 +144,64 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
   // physical chunk piece >> 1, which holds logical chunk (piece >> 1) ^ key(row).
   // Pixel stage (28 instructions): id q fills pixel rows 8 q .. + 7; wave w issues q = w + 8 i (i = 3 only on waves < 4).  Lane: row 8 q +
   // (lane >> 3), physical slot lane & 7 holds logical slot (lane & 7) ^ ((row >> 1) & 7) (pw384's K64 swizzle).
-  const uintptr_t zp = (uintptr_t)p.zero_page;
-  const uintptr_t xbase = (uintptr_t)p.x, wbase = (uintptr_t)p.w_kn;
+  // Both operands travel as `buffer_load_dwordx4 ... offen lds`: a lane's constant 32-bit byte offset in a VGPR, the stage's K offset in an SGPR,
+  // bounds from the buffer resource -- no per-instruction vector arithmetic in the K loop (the 64-bit address + zero-page select of
+  // global_load_lds cost ~8 VALU instructions per LDS-DMA, 80 per step and SIMD, on a SIMD whose vector issue the MFMAs already half fill).
+  // A lane out of range (a pixel row past M: its offset is past the resource's extent) gets ZEROS written to its LDS bytes.  Weight columns past
+  // Cout need nothing: they only reach output channels that are never stored.  The K tail (k >= Cin: weight rows past the image, pad elements of
+  // a pixel row) lies in the LAST stage of either operand only; that stage's offsets are formed in VGPRs (the range check then sees the whole
+  // offset whatever it does with the SGPR part) and a pixel lane whose K slot is past Cin is sent out of range.
   const int krow = 8 * (wave & 3) + (lane >> 3);
   const int wkey = ((krow >> 1) & 1) | (((krow >> 3) & 1) << 1);
   unsigned srcw[3], srcp[K::PSLOTS];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int ncol = ((wave >> 2) + 2 * i) * 64 + ((((lane & 7) >> 1) ^ wkey) << 4) + (lane & 1) * 8;
-    srcw[i] = n0 + ncol < g.Cout ? (unsigned)(((size_t)krow * p.ldw_kn + n0 + ncol) * 2) : ~0u;
+    srcw[i] = (unsigned)(((size_t)krow * p.ldw_kn + n0 + ncol) * 2);
   }
   const int pslot = (lane & 7) ^ (((4 * wave) + (lane >> 4)) & 7);     // logical 16-byte K slot this lane fetches
 #pragma unroll
   for (int i = 0; i < K::PSLOTS; ++i) {
     const int m = m0 + 8 * (wave + 8 * i) + (lane >> 3);
-    srcp[i] = m < p.M ? (unsigned)(((size_t)m * p.ldx + pslot * 8) * 2) : ~0u;
+    srcp[i] = (unsigned)(((size_t)m * p.ldx + pslot * 8) * 2);          // m >= M: past the resource's extent
   }
   const bool has_last = wave + 8 * (K::PSLOTS - 1) < K::NPI;           // (wave-uniform) this wave owns a last pixel instruction
   const unsigned wstep = (unsigned)p.ldw_kn * 64u;                     // bytes between the k rows of consecutive steps (32 rows)
-  // wdst / pdst: LDS byte offset of the ring slot the stage goes to
+  const int last_S = (nsteps - 1) >> 1;
+  constexpr unsigned OOB = 0x80000000u;                                // resources are smaller than 2 GiB (eligibility)
+#if defined(__HIP_DEVICE_COMPILE__)     // (the buffer-resource builtins do not exist in the host pass)
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_kn, 0, (int)((size_t)g.Cin * p.ldw_kn * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((size_t)(p.M - 1) * p.ldx + g.Cin) * 2), 0x00020000);
+  // wdst / pdst: LDS byte offset of the ring slot the stage goes to.  The K offset of a stage rides in the SGPR operand, except in an operand's
+  // last stage (and past it), where it is added to the lane's offset: one scalar select per stage, one v_add per instruction, no branch.
+  const unsigned ptail = 64 * last_S + pslot * 8 < g.Cin ? 0u : OOB;    // last pixel stage: this lane's K slot is past Cin
   auto issue_w = [&](int i, int s, uint32_t wdst) {
-    const bool ok = (srcw[i] != ~0u) & (32 * s + krow < g.Cin);
-    const uintptr_t a = ok ? wbase + (srcw[i] + (unsigned)s * wstep) : zp;
-    __builtin_amdgcn_global_load_lds((gas_ptr)a, (lds_ptr)(smem + wdst + (wave + 8 * i) * 1024), 16, 0, 0);
+    const bool last = s >= nsteps - 1;
+    const unsigned kb = (unsigned)s * wstep;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + wdst + (wave + 8 * i) * 1024), 16, srcw[i] + (last ? kb : 0u), last ? 0u : kb, 0, 0);
   };
   auto issue_p = [&](int i, int S, uint32_t pdst) {
-    const bool ok = (srcp[i] != ~0u) & (64 * S + pslot * 8 < g.Cin);
-    const uintptr_t a = ok ? xbase + (srcp[i] + (unsigned)S * 128u) : zp;
-    __builtin_amdgcn_global_load_lds((gas_ptr)a, (lds_ptr)(smem + pdst + (wave + 8 * i) * 1024), 16, 0, 0);
+    const bool last = S >= last_S;
+    const unsigned kb = (unsigned)S * 128u;
+    const unsigned vk = (last ? kb : 0u) + (S > last_S ? OOB : 0u);     // (scalar) a stage past the K extent: every lane out of range
+    const unsigned vt = S == last_S ? ptail : 0u;
+#ifndef DC_PW224_AUXP
+#define DC_PW224_AUXP 0
+#endif
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(smem + pdst + (wave + 8 * i) * 1024), 16, srcp[i] + vk + vt, last ? 0u : kb, 0, DC_PW224_AUXP);
   };
+#else
+  auto issue_w = [&](int, int, uint32_t) {};
+  auto issue_p = [&](int, int, uint32_t) {};
+#endif
 
+#ifdef DC_PW224_PROBE
+  // diagnostic builds (make probes224), one library per COMPILE-TIME mask: bit 0 drops the K loop's LDS-DMA issues, bit 1 its LDS fragment reads,
+  // bit 2 its MFMAs -- what each costs in the loop.  Results are garbage by construction.
+  constexpr int probe = DC_PW224_PROBE;
+#else
+  constexpr int probe = 0;
+#endif
   f32x4 acc[NCB][NPB];   // [channel block][pixel block]
 #pragma unroll
   for (int i = 0; i < NCB; ++i)
@@ -189,6 +227,8 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
   // P[(s >> 1) + 2] during this step and wait for W[s+1] at its end; otherwise (the last two steps) issue nothing and wait for everything.
   // Outstanding LDS reads at the top of a step, oldest first: fa[0] (2 instructions), fa[1] (2), fb[0] .. fb[6].
   // wdst / pdst: the ring slots (LDS byte offsets) of W[s+2] and P[(s >> 1) + 2].
+  // The last step's look-ahead reads have no consumer: the wait behind the loop must be the FIRST instruction on both exit paths (no register may
+  // be handed to another value while an LDS read is still on its way to it) -- tests/test_kernel_isa_cpu.py checks the compiled kernel for it.
   auto step = [&](auto h_tag, uint32_t wcur, uint32_t wnxt, uint32_t bnxt, int s, bool dma, uint32_t wdst, uint32_t pdst) {
     constexpr int H = decltype(h_tag)::value;
     const int S = s >> 1;
@@ -197,19 +237,34 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
       constexpr int k = decltype(kc)::value;
       if constexpr (k < HP) {
         constexpr int slot = HP * H + k;
-        if (slot < K::PSLOTS - 1 || has_last) issue_p(slot, S + 2, pdst);
+        if constexpr (!(probe & 16)) { if (slot < K::PSLOTS - 1 || has_last) issue_p(slot, S + 2, pdst); }
       } else {
-        issue_w(k - HP, s + 2, wdst);
+        if constexpr (!(probe & 8)) issue_w(k - HP, s + 2, wdst);
       }
     };
     constexpr int ND = HP + 3;                         // 5
     // blocks in which the early waves (0..3) and the late waves (4..7) issue instruction k
+#ifndef DC_PW224_PLAN
+#define DC_PW224_PLAN 0
+#endif
+#if DC_PW224_PLAN == 0
     constexpr int EB[5] = {0, 0, 1, 1, 2}, LB[5] = {2, 3, 3, 4, 4};
+#elif DC_PW224_PLAN == 1
+    constexpr int EB[5] = {0, 1, 2, 3, 4}, LB[5] = {0, 1, 2, 3, 4};
+#elif DC_PW224_PLAN == 2
+    constexpr int EB[5] = {0, 0, 0, 1, 1}, LB[5] = {3, 3, 3, 4, 4};
+#elif DC_PW224_PLAN == 3
+    constexpr int EB[5] = {0, 0, 0, 0, 0}, LB[5] = {3, 3, 3, 3, 3};
+#elif DC_PW224_PLAN == 4
+    constexpr int EB[5] = {1, 1, 2, 2, 3}, LB[5] = {3, 4, 4, 5, 5};
+#else
+    constexpr int EB[5] = {0, 0, 1, 1, 2}, LB[5] = {0, 0, 1, 1, 2};
+#endif
     static_assert(ND == 5, "issue plan");
     static_for<0, NCB>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      if constexpr (i + 2 < NCB) lds_read_tr<((i + 2) >> 1) * 8192>(fa[(i + 2) % 3], wcur + a_base[(i + 2) & 1] - lds0);   // two blocks ahead
-      if (dma) {
+      if constexpr (i + 2 < NCB && !(probe & 2)) lds_read_tr<((i + 2) >> 1) * 8192>(fa[(i + 2) % 3], wcur + a_base[(i + 2) & 1] - lds0);   // two blocks ahead
+      if (dma && !(probe & 1)) {
         static_for<0, ND>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
           if constexpr (EB[k] == i) { if (!late) dma_k(kc); }
@@ -218,14 +273,17 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
       }
       if constexpr (i == NCB - 1) {
         // stage end: W[s+1] (and with it everything older) has landed for this wave; this step's own instructions stay in flight
-        if (dma) {
-          if (H == 0 || has_last) vm_lgkm0_wait<3 + HP>(); else vm_lgkm0_wait<3 + HP - 1>();
+        if (dma && !(probe & 1)) {
+          constexpr int NW = (probe & 8) ? 0 : 3, NP = (probe & 16) ? 0 : HP;      // (probe builds that drop one operand's LDS-DMAs)
+          if (H == 0 || has_last || NP == 0) vm_lgkm0_wait<NW + NP>(); else vm_lgkm0_wait<NW + NP - 1>();
         } else {
           vm_lgkm0_wait<0>();
         }
         __builtin_amdgcn_s_barrier();
-        lds_read_tr<0>(fa[0], wnxt + a_base[0] - lds0);                              // next step's first two weight fragments
-        lds_read_tr<0>(fa[1], wnxt + a_base[1] - lds0);
+        if constexpr (!(probe & 2)) {
+          lds_read_tr<0>(fa[0], wnxt + a_base[0] - lds0);                              // next step's first two weight fragments
+          lds_read_tr<0>(fa[1], wnxt + a_base[1] - lds0);
+        }
       }
       static_for<0, NPB>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -235,25 +293,30 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
         if constexpr (i == 0) lgkm_wait<NPB - 1 - j + 2>();
         else if constexpr (j == 0 && i < NCB - 2) lgkm_wait<4>();
         else if constexpr (j == 0 && i == NCB - 2) lgkm_wait<2>();
-        mfma_v(acc[i][j], __builtin_bit_cast(bf16x8, fa[i % 3]), fb[j]);
-        if constexpr (i == NCB - 1) lds_read16<j * 2048>(fb[j], bnxt);                // re-read in place for the next step
+        if constexpr (!(probe & 4)) mfma_v(acc[i][j], __builtin_bit_cast(bf16x8, fa[i % 3]), fb[j]);
+        if constexpr (i == NCB - 1 && !(probe & 2)) lds_read16<j * 2048>(fb[j], bnxt);   // re-read in place for the next step
       });
     });
   };
 
-  // ---- prologue: W[0], P[0], P[1], W[1] in flight (in this order: see "hazards"), W[0] and P[0] landed, first fragments requested ----------
+#ifndef DC_PW224_PRIO
+#define DC_PW224_PRIO 1      // the second-dispatched wave of every SIMD loses each arbitration at equal priority: 1 965 -> 1 924 cycles per step
+#endif
+  if (late) __builtin_amdgcn_s_setprio(DC_PW224_PRIO);
+  // ---- prologue: P[0] (the operand from beyond the L2 first), W[0], P[1], W[1] in flight (W[1] last: see "hazards"), P[0] and W[0] landed,
+  // first fragments requested
 #pragma unroll
-  for (int i = 0; i < 3; ++i) issue_w(i, 0, 0);
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
+  for (int q = 0; q < 2; ++q) {
 #pragma unroll
     for (int i = 0; i < K::PSLOTS; ++i)
       if (i < K::PSLOTS - 1 || has_last) issue_p(i, q, K::POFF + q * K::PSTG);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) issue_w(i, 1, WSTG);
+    for (int i = 0; i < 3; ++i) issue_w(i, q, q * WSTG);
+  }
   if (has_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + K::PSLOTS) : "memory");
   else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + K::PSLOTS - 1) : "memory");
   __builtin_amdgcn_s_barrier();
+  PW224_STAMP(1);
   lds_read_tr<0>(fa[0], a_base[0]);
   lds_read_tr<0>(fa[1], a_base[1]);
   static_for<0, NPB>([&](auto jc) { lds_read16<decltype(jc)::value * 2048>(fb[decltype(jc)::value], lds0 + b_off); });
@@ -262,17 +325,21 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
     // weight slots (byte offsets) of steps s, s + 1, s + 2; pixel slots (byte offsets inside the pixel ring) of stages S, S + 1, S + 2
     uint32_t w0 = 0, w1 = WSTG, w2 = 2 * WSTG;
     uint32_t p0 = 0, p1 = K::PSTG, p2 = 2 * K::PSTG;
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
     while (true) {
-      step(std::integral_constant<int, 0>{}, lds0 + w0, lds0 + w1, lds0 + ((b_off + p0) ^ 64), s, s + 2 < nsteps, w2, K::POFF + p2);
+      step(H0{}, lds0 + w0, lds0 + w1, lds0 + ((b_off + p0) ^ 64), s, s + 2 < nsteps, w2, K::POFF + p2);
       if (++s == nsteps) break;
-      step(std::integral_constant<int, 1>{}, lds0 + w1, lds0 + w2, lds0 + b_off + p1, s, s + 2 < nsteps, w0, K::POFF + p2);
+      step(H1{}, lds0 + w1, lds0 + w2, lds0 + b_off + p1, s, s + 2 < nsteps, w0, K::POFF + p2);
       if (++s == nsteps) break;
       { const uint32_t t = w0; w0 = w2; w2 = w1; w1 = t; }      // two steps on: (w0, w1, w2) <- (w2, w0, w1)
       { const uint32_t t = p0; p0 = p1; p1 = p2; p2 = t; }      // one stage on
     }
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the last step's look-ahead reads; the ring is reused below)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the ring is reused below)
+
   __builtin_amdgcn_s_barrier();
+  PW224_STAMP(2);
 
   // ---- epilogue from the accumulator registers (igemm384.hip's) -------------------------------------------------------------------
   // A lane holds, per MFMA tile (i, j), channels fg*4 .. +3 of channel block i for pixel fr of pixel block j.  Blocks 2 pr and 2 pr + 1 are the
@@ -365,6 +432,11 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
       }
     }
   }
+#ifdef DC_PW224_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  PW224_STAMP(3);
+#endif
 }
 
 }  // namespace
@@ -373,27 +445,22 @@ bool pw224_eligible(const IgemmParams& p) {
   const GatherGeom& g = p.g;
   return p.w_kn != nullptr && g.ntaps == 1 && g.os == 1 && g.is == 1 && g.taps[0].dy == 0 && g.taps[0].dx == 0 && p.m_beg == 0 && p.ngroup <= 1 &&
          g.Cin >= 128 && g.Cin % 8 == 0 && g.Cout % 8 == 0 && (((uintptr_t)p.w_kn) & 15) == 0 &&
-         (size_t)p.M * p.ldx * 2 < (1ull << 32) && ((size_t)g.Cin + 32) * p.ldw_kn * 2 < (1ull << 32);      // 32-bit row offsets
+         ((size_t)p.M + 224) * p.ldx * 2 < (1ull << 31) && ((size_t)g.Cin + 64) * p.ldw_kn * 2 < (1ull << 31);      // buffer resources < 2 GiB
 }
 
-int launch_pw224(const IgemmParams& p_in, hipStream_t st) {
-  static const void* zero_dev = nullptr;
-  static hipError_t init_err = hipSuccess;
+int launch_pw224(const IgemmParams& p, hipStream_t st) {
   typedef Cfg<2> C2;
   auto k2 = &pw224_kernel<2>;
-  DC_ONCE({
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, C2::RING);
-    void* zp = nullptr;
-    init_err = hipGetSymbolAddress(&zp, HIP_SYMBOL(zero_page224));
-    zero_dev = zp;
-  });
-  if (init_err != hipSuccess) return dc_set_error(init_err, __FILE__, __LINE__);
-  IgemmParams p = p_in;
-  p.zero_page = zero_dev;
-  const long tiles = pw224_tiles(p);
-  hipLaunchKernelGGL(k2, dim3((unsigned)tiles), dim3(512), C2::RING, st, p);
+  DC_ONCE({ (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, C2::RING); });
+  hipLaunchKernelGGL(k2, dim3((unsigned)pw224_tiles(p)), dim3(512), C2::RING, st, p);
   DC_CHECK_LAUNCH();
   return 0;
 }
 
 }  // namespace dc
+
+#ifdef DC_PW224_STAMPS
+extern "C" int dc_debug_pw224_stamps(void* host_out, int blocks) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dc::pw224_stamp_buf), (size_t)blocks * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -212,6 +212,7 @@ class Engine:
         self.fuse_pw_bn_bwd = os.environ.get("DC_FUSE_PW_BN_BWD", "1") != "0"
         self.fuse_head_wgrad = os.environ.get("DC_FUSE_HEAD_WGRAD", "1") != "0"
         self.fuse_bn_src_dw = os.environ.get("DC_FUSE_BN_SRC_DW", "1") != "0"       # a stored BatchNorm output's last depthwise reader takes its backward sums
+        self.conv_kn = os.environ.get("DC_CONV_KN", "1") != "0"                    # pointwise layers pass both packed weight images (dc_conv_fwd_kn / dc_conv_dgrad_kn)
         self.fuse_sep_fwd = os.environ.get("DC_FUSE_SEP_FWD", "1") != "0"           # depthwise + pointwise forward of the thin layers in one kernel
         # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
         # batch 2: 16.07 -> 15.42 ms/step with groups of 3, batch 4: 24.50 -> 24.11, batch 8: 40.31 -> 40.10 (round 3; 1 / 2 / 3 / 4 layers:
@@ -370,9 +371,17 @@ class Engine:
                                                   d.k * d.k, 1 if transposed else 0))
             self._keep += [wf] + ([wb] if wb is not None else [])
 
+        # a pointwise layer hands the library BOTH packed images: the 224 x 384 tile kernel streams its weight stages from the [k][n] one
+        # (csrc/igemm224.hip; dc_conv_fwd_kn / dc_conv_dgrad_kn fall back to the plain path for every shape it does not serve)
+        both = self.conv_kn and k == 1 and stride == 1 and not transposed and not f32 and wb is not None and dt == L.DC_BF16
+
         def fwd(train: bool):
-            L.call("dc_conv_fwd", C.byref(d), N, H, W, x.ptr, x.ld, L.dptr(wf), pb, y.ptr, y.ld,
-                   L.dptr(slab) if train else None, 0, self._st())
+            if both:
+                L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, x.ptr, x.ld, L.dptr(wf), L.dptr(wb), pb, y.ptr, y.ld,
+                       L.dptr(slab) if train else None, 0, self._st())
+            else:
+                L.call("dc_conv_fwd", C.byref(d), N, H, W, x.ptr, x.ld, L.dptr(wf), pb, y.ptr, y.ld,
+                       L.dptr(slab) if train else None, 0, self._st())
 
         if fwd_group is not None:
             assert k == 3 and stride == 1 and pad == dil and not transposed and bias is None and not f32
@@ -450,6 +459,8 @@ class Engine:
                     L.call("dc_conv_dgrad_bnstats", C.byref(d), N, H, W, dy.ptr, dy.ld, L.dptr(wb), dx.ptr, dx.ld, by.ptr, by.ld,
                            L.dptr(bsrc["mean"]), L.dptr(bsrc["invstd"]), L.dptr(bsrc["scale"]), L.dptr(bsrc["shift"]), bsrc["relu"],
                            L.dptr(sslab), self._st())
+                elif need_dx and both:
+                    L.call("dc_conv_dgrad_kn", C.byref(d), N, H, W, dy.ptr, dy.ld, L.dptr(wb), L.dptr(wf), dx.ptr, dx.ld, mode, self._st())
                 elif need_dx:
                     L.call("dc_conv_dgrad", C.byref(d), N, H, W, dy.ptr, dy.ld, L.dptr(wb), dx.ptr, dx.ld, mode, self._st())
             return bwd, ready

@@ -11,7 +11,7 @@ import csv, glob, json, os, sys
 
 import re
 
-FAMILIES = {"igemm": ("igemm_kernel", "igemm256_kernel", "igemm256p_kernel", "pw384_kernel", "pw192_kernel", "tiny_gemm_kernel"),
+FAMILIES = {"igemm": ("igemm_kernel", "igemm256_kernel", "igemm256p_kernel", "pw384_kernel", "pw224_kernel", "pw192_kernel", "tiny_gemm_kernel"),
             "wgrad": ("wgrad_dma_kernel", "wgrad256_kernel", "wgrad384_kernel", "wgrad_kernel", "wgrad_reduce_kernel", "fold_kernel")}
 # Every dispatched kernel that LOOKS like a member of one of the two families must be listed above: round 3's "1.05 x" for the implicit GEMMs
 # came from a table that silently lacked igemm256p_kernel.  Depthwise / thin-layer / slab-statistics kernels are other families.
@@ -19,7 +19,7 @@ FAMILY_LIKE = re.compile(r"(igemm\w*_kernel|pw\d+_kernel|tiny_gemm_kernel|(?<![a
 NOT_FAMILY = ("dw_wgrad", "dwt_wgrad", "dws2_wgrad", "thin_wgrad", "slab_fold", "head_")
 # launches of the C-ABI entry point = launches of the main kernel (the fold of the slabs rides along with each weight-gradient launch; since
 # round 4 it also folds the depthwise layers' rows, a few MB per launch)
-MAIN = {"igemm": ("igemm_kernel", "igemm256_kernel", "igemm256p_kernel", "pw384_kernel", "pw192_kernel", "tiny_gemm_kernel"),
+MAIN = {"igemm": ("igemm_kernel", "igemm256_kernel", "igemm256p_kernel", "pw384_kernel", "pw224_kernel", "pw192_kernel", "tiny_gemm_kernel"),
         "wgrad": ("wgrad_dma_kernel", "wgrad256_kernel", "wgrad384_kernel", "wgrad_kernel")}
 
 

@@ -173,7 +173,7 @@ def test_library_rccl_allreduce_on_a_device_buffer():
     info()['enqueued'] advanced.  Runs in a child process: a communicator's teardown must not meet the test runner's other GPU state."""
     code = r"""
 import ctypes as C, sys, torch
-sys.path.insert(0, %r)
+sys.path.insert(0, ROOT_DIR)
 from mlperf_deepcam_amd import lib as L, dist as ddist
 comm = ddist.LibraryComm.rccl()
 assert comm.info()["transport"] == "rccl" and comm.info()["world"] == 1
@@ -200,6 +200,6 @@ for dt, code in ((torch.float32, L.DC_F32), (torch.bfloat16, L.DC_BF16)):
 L.call("dc_grad_allreduce_enqueue", comm.h, None, C.c_size_t(0), L.DC_F32, C.c_void_p(compute.cuda_stream))
 comm.close()
 print("RCCL_DIRECT ok")
-""" % ROOT
+""".replace("ROOT_DIR", repr(ROOT))
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_DIRECT ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

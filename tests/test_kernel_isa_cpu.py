@@ -59,7 +59,7 @@ def test_persistent_gemm_k_loops_hold_no_spills(tmp_path):
 @pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
 @pytest.mark.parametrize("src,name,count", [("igemm384.hip", "pw384_kernel", 3), ("igemm256.hip", "igemm256_kernel", 1),
                                             ("wgrad256.hip", "wgrad256_kernel", 1), ("wgrad384.hip", "wgrad384_kernel", 3),
-                                            ("igemm192.hip", "pw192_kernel", 1)])
+                                            ("igemm192.hip", "pw192_kernel", 1), ("igemm224.hip", "pw224_kernel", 1)])
 def test_gemm_k_loops_hold_no_spills(tmp_path, src, name, count):
     """The other MFMA kernels that run at the register limit.  (This scan is what found the spills of the 128-byte-row mode of
     pw384_kernel: six scratch reloads, each behind a vmcnt(0), per K step -- the reason that mode first measured slower than 64-byte rows.)"""
@@ -159,3 +159,21 @@ def test_in_kernel_batchnorm_finalize_keeps_its_slab_loads_in_flight(tmp_path, s
     assert len(kernels) == 1, sorted(kernels)
     for kname, lines in kernels.items():
         assert _most_loads_outstanding(lines) >= 12, f"{kname}: at most {_most_loads_outstanding(lines)} slab loads in flight"
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src,name", [("igemm224.hip", "pw224_kernel"), ("igemm384.hip", "pw384_kernel")])
+def test_no_vector_register_is_written_between_the_last_look_ahead_read_and_its_wait(tmp_path, src, name):
+    """The hand-scheduled pointwise kernels request the NEXT step's fragments (inline-assembly ds_read) in the last block of every K step,
+    also of the last one, where nothing consumes them: for the compiler those destination registers are free from there on, while the reads
+    are still on their way.  Safe only as long as the `s_waitcnt vmcnt(0) lgkmcnt(0)` behind the loop comes before any instruction that
+    writes a vector register: this checks the path from the K loop's exit to that wait in the compiled kernel."""
+    for kname, lines in _kernels(_device_asm(src, tmp_path), name).items():
+        loops = [(a, b) for a, b in _loops(lines) if any("v_mfma" in x for x in lines[a:b])]
+        assert loops, kname
+        end = max(b for _, b in loops)
+        # the first full wait behind the outermost MFMA loop
+        wait = next(n for n in range(end, len(lines)) if re.search(r"s_waitcnt\s+vmcnt\(0\)\s+lgkmcnt\(0\)", lines[n]))
+        between = [l.strip() for l in lines[end + 1:wait] if l.strip() and not l.strip().startswith((";", ".", "//"))]
+        bad = [l for l in between if not re.match(r"s_", l)]
+        assert not bad, f"{kname}: vector / memory instructions between the K loop and its final wait: {bad[:4]}"
