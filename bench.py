@@ -520,7 +520,8 @@ def main():
         if world == 1 and not a.no_also and (B, a.dtype) == (8, "bf16"):
             # BASELINE.json configs[1] and configs[2]: the other two single-GPU configurations, timed the same way in this process
             out["also"] = []
-            for ab, adt, aopt in ((2, "fp32", "Adam"), (4, "bf16", a.optimizer)):
+            # ... and the per-rank shape of configs[3] (8 x MI355X, global batch 16, bf16): local batch 2 in bf16
+            for ab, adt, aopt in ((2, "fp32", "Adam"), (4, "bf16", a.optimizer), (2, "bf16", a.optimizer)):
                 try:
                     out["also"].append(also_config(dnn, ab, H, W, adt, aopt, a.steps, a.warmup, dev))
                 except Exception as e:  # never take the headline down

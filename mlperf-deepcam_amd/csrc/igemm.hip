@@ -572,7 +572,8 @@ static int pw384_plan(const IgemmParams& p) {
   if (g_pw192 && best >= 1e9 && t192 >= 160 && t192 <= 256 && p.g.Cin >= 128 && p.g.Cout * 10 >= (long)cdiv(p.g.Cout, 192) * 192 * 9) return 192;
   if (best >= 0.9 * c_old) return 0;
   // where the 256-pixel tile with 64-deep stages would run: the 224-pixel tile when it is ONE round too (728 -> 728 at M = 27 648: 248 tiles)
-  if (c8 < c4 && k64 && g_pw224 && pw224_eligible(p) && pw224_tiles(p) <= 256 && cdiv(t8, 256) == 1) return 224;
+  // (multi-round launches too: 728 -> 728 at M = 110 592 137 against 156 us, 256 -> 728 there 81 against 92: profiles/r06_pw224_bench.txt)
+  if (c8 < c4 && k64 && g_pw224 && pw224_eligible(p) && cdiv(pw224_tiles(p), 256) <= cdiv(t8, 256)) return 224;
   return c8 < c4 ? (k64 ? 64 : 8) : 4;
 }
 

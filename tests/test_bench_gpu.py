@@ -22,7 +22,8 @@ def test_bench_reports_the_torch_operator_baseline_when_asked():
 
 
 def test_default_line_carries_the_other_single_gpu_configurations():
-    """BASELINE.json configs[1] (local batch 2, fp32, Adam) and configs[2] (local batch 4, bf16) ride on the default line as `also`: each timed in the
+    """BASELINE.json configs[1] (local batch 2, fp32, Adam), configs[2] (local batch 4, bf16) and the per-rank shape of configs[3] (local batch 2,
+    bf16) ride on the default line as `also`: each timed in the
     same process the same way, with its whole-step and encoder-region fraction.  Small images here; the keys are what is asserted."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--height", "128", "--width", "192", "--no_cpu_baseline"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
@@ -30,7 +31,7 @@ def test_default_line_carries_the_other_single_gpu_configurations():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["config"]["local_batch"] == 8 and out["dtype"] == "bf16" and out["value"] > 0
     also = out["also"]
-    assert [(e["config"]["local_batch"], e["dtype"], e["config"]["optimizer"]) for e in also] == [(2, "fp32", "Adam"), (4, "bf16", "LAMB")]
+    assert [(e["config"]["local_batch"], e["dtype"], e["config"]["optimizer"]) for e in also] == [(2, "fp32", "Adam"), (4, "bf16", "LAMB"), (2, "bf16", "LAMB")]
     for e in also:
         assert e["value"] > 0 and e["unit"] == "samples/s" and e["steps"] == 2 and e["warmup"] == 1, e
         assert abs(e["ms_per_step"] * e["value"] - 1e3 * e["config"]["local_batch"]) < 1.0
