@@ -12,7 +12,7 @@ for (Cc, H, W, N, dil) in [(728, 48, 72, 8, 1), (256, 192, 288, 8, 1), (128, 384
     wp = torch.randn(9 * Cc, device=dev) * 0.2
     sc, sh, mean, invstd = [torch.rand(Cc, device=dev) + 0.5 for _ in range(4)]
     print(f"C={Cc} {H}x{W} N={N} dil={dil}: {T / 1e6:.1f} MB per tensor")
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         L.call("dc_set_option", b"dw_pipe", mode)
         rows = lib.dc_dwconv_dgrad_bnstats_rows(dt, Cc, 1, dil, N, H, W); wrows = lib.dc_dwconv_dgrad_wgrad_rows(dt, Cc, 1, dil, N, H, W)
         slab = torch.empty(2 * rows * Cc, device=dev); wslab = torch.empty(max(wrows, 1) * 9 * Cc, device=dev)
@@ -37,6 +37,6 @@ for (Cc, H, W, N, dil) in [(728, 48, 72, 8, 1), (256, 192, 288, 8, 1), (128, 384
             for i in range(REPS): fn(i % NB)
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / REPS
-            print(f"  {'pipelined' if mode else 'tiled    '} {name:28s} {us:8.1f} us  {nbytes / us / 1e6:5.2f} TB/s  (rows {rows})", flush=True)
+            print(f"  {['tiled    ', 'pipelined', 'pipe+fwd '][mode]} {name:28s} {us:8.1f} us  {nbytes / us / 1e6:5.2f} TB/s  (rows {rows})", flush=True)
     L.call("dc_set_option", b"dw_pipe", 1)
     del x, y, dy, dx, add
