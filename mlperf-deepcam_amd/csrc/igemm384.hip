@@ -174,6 +174,10 @@ __global__ __launch_bounds__(512) void pw384_kernel(const IgemmParams p) {
     if constexpr (!(probe & 1)) __builtin_amdgcn_global_load_lds((gas_ptr)a, (lds_ptr)(smem + (stage % K::NSTG) * K::STAGE + (8 * i + wave) * 1024), 16, 0, 0);
   };
 
+#ifndef DC_LATE_PRIO
+#define DC_LATE_PRIO 1      // the second-dispatched wave of every SIMD loses each arbitration at equal priority (igemm224.hip: 1 965 -> 1 924 cycles per step)
+#endif
+  if (DC_LATE_PRIO && late) __builtin_amdgcn_s_setprio(DC_LATE_PRIO);
   f32x4 acc[NCB][NPB];   // [channel block][pixel block]
 #pragma unroll
   for (int i = 0; i < NCB; ++i)

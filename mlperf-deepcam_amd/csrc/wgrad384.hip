@@ -211,6 +211,10 @@ __global__ __launch_bounds__(512) void wgrad384_kernel(const Wg384Params p) {
     }
   };
 
+#ifndef DC_LATE_PRIO
+#define DC_LATE_PRIO 1      // the second-dispatched wave of every SIMD loses each arbitration at equal priority (igemm224.hip: 1 965 -> 1 924 cycles per step)
+#endif
+  if (DC_LATE_PRIO && late) __builtin_amdgcn_s_setprio(DC_LATE_PRIO);
   f32x4 acc[NCB][NPB];   // [ci block][co block]
 #pragma unroll
   for (int i = 0; i < NCB; ++i)
