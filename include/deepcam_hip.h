@@ -343,12 +343,13 @@ int dc_sepconv_fwd(int dtype, int Cin, int Cout, int N, int H, int W, const void
  * data-gradient operand of dc_conv_pack_weights); wslab [rows][Cout][Cin] fp32 = one partial weight gradient per workgroup, rows =
  * dc_pw_bn_bwd_rows(...) (0: shape not served -- bf16, Cout 128 with Cin 64 / 128 or Cout 256 with Cin 128 / 256, at least 65 536 pixels: the entry flow's first two blocks, whose 226 - 453 MB
  * tensors make all three passes HBM-bound), summed by dc_fold_slabs (DC_FOLD_CONV, splits = rows, taps = 1).  dgamma / dbeta: the finished
- * parameter gradients (dc_bn_bwd_finalize).  Replaces autograd's batch_norm_backward + conv2d backward of SeparableConv2d_same.pointwise
+ * parameter gradients (dc_bn_bwd_finalize).  wslab_rows: the rows the caller allocated wslab (and planned its fold) for; the call fails if that is
+ * not what dc_pw_bn_bwd_rows returns for the shape now.  Replaces autograd's batch_norm_backward + conv2d backward of SeparableConv2d_same.pointwise
  * (deeplab_xception.py:62-66, 84-101; train_hdf5_ddp.py:363). */
 int dc_pw_bn_bwd_rows(int dtype, int Cin, int Cout, long M);
 int dc_pw_bn_bwd(int dtype, long M, int Cin, int Cout, long count, const void* dout, int lddo, const void* y, int ldy, int relu,
                  const float* gamma, const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta,
-                 const float* mscale, const float* mshift, const void* x, int ldx, const void* wb, void* dx, int lddx, float* wslab,
+                 const float* mscale, const float* mshift, const void* x, int ldx, const void* wb, void* dx, int lddx, float* wslab, int wslab_rows,
                  void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -517,8 +517,9 @@ static int bn_apply_impl(int dtype, long M, int C, const void* y, int ldy, const
   if (g_bn_apply_rows) {
     // bn_bwd_apply's block shape (a block as narrow as the tensor, rows per block growing with the row lanes)
     const int cgw = narrow_cg(C / kpv, g_bn_cgw);
-    const int APPLY_ROWS = (rows_per_block > 0 ? rows_per_block : g_bn_rows) * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
-    if (cdiv(M, APPLY_ROWS) <= 65535) {
+    int APPLY_ROWS = (rows_per_block > 0 ? rows_per_block : g_bn_rows) * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
+    while (cdiv(M, APPLY_ROWS) > 65535) APPLY_ROWS *= 2;      // (a block walks its rows in a loop: any row count per block is served)
+    {
       const dim3 blocks2(cdiv(C / kpv, cgw), cdiv(M, APPLY_ROWS));
 #define BN_AR(TT, W) do { if (finp != nullptr) hipLaunchKernelGGL((bn_apply_rows_kernel<TT, W, true>), blocks2, dim3(256), 0, st, M, C, APPLY_ROWS, (const TT*)y, ldy, scale, shift, (const TT*)residual, ldr, relu, (TT*)out, ldo, fin); \
                           else hipLaunchKernelGGL((bn_apply_rows_kernel<TT, W, false>), blocks2, dim3(256), 0, st, M, C, APPLY_ROWS, (const TT*)y, ldy, scale, shift, (const TT*)residual, ldr, relu, (TT*)out, ldo, fin); } while (0)
@@ -529,7 +530,12 @@ static int bn_apply_impl(int dtype, long M, int C, const void* y, int ldy, const
       return 0;
     }
   }
-  DC_REQUIRE(finp == nullptr, "dc_bn_apply_fin: shape not served by the row-block kernel");
+  if (finp != nullptr) {
+    // dc_bn_apply_fin where the row-block kernel does not run (option bn_apply_rows = 0, or more row blocks than one launch holds): the
+    // finalize as a launch of its own, then the grid-stride apply -- the two-call sequence, same results
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, st, fin);
+    DC_CHECK_LAUNCH();
+  }
   const int blocks = ew_blocks(M * (C / kpv));
   if (dtype == DC_BF16)
     hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(blocks), dim3(256), 0, st, M, C, (const bf16*)y, ldy, scale, shift, (const bf16*)residual, ldr, relu, (bf16*)out, ldo);
@@ -600,8 +606,8 @@ static int bn_bwd_apply_impl(int dtype, long M, int C, long count, const void* d
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   // a block as narrow as the tensor (see narrow_cg); the rows per block grow with the row lanes so that every thread has its four rows
   const int cgw = narrow_cg(C / kpv, g_bn_cgw);
-  const int APPLY_ROWS = g_bn_rows * (fin_slab != nullptr ? g_bn_fin_mul_b : 1) * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
-  DC_REQUIRE(cdiv(M, APPLY_ROWS) <= 65535, "dc_bn_bwd_apply: too many rows for one launch");
+  int APPLY_ROWS = g_bn_rows * (fin_slab != nullptr ? g_bn_fin_mul_b : 1) * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
+  while (cdiv(M, APPLY_ROWS) > 65535) APPLY_ROWS *= 2;      // (a block walks its rows in a loop: any row count per block is served)
   const dim3 blocks(cdiv(C / kpv, cgw), cdiv(M, APPLY_ROWS));
   const float inv = 1.0f / (float)count;
 #define BN_BA(TT, W) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, W>), blocks, dim3(256), 0, st, M, C, APPLY_ROWS, inv, (const TT*)dout, lddo, (const TT*)y, ldy, (const TT*)out, ldout, relu, gamma, save_mean, save_invstd, dgamma, dbeta, (TT*)dy, lddy, (TT*)g_out, ldg, mscale, mshift, fin_slab, fin_rows, dgamma_out, dbeta_out)

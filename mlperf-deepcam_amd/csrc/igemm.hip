@@ -921,11 +921,7 @@ extern "C" int dc_pack_all(int dtype, const void* table_dev, int nentries, void*
 extern "C" int dc_wgrad_set_target_blocks(int n);
 extern "C" int dc_wgrad_set_mode(int m);
 extern "C" int dc_wgrad_set_min_steps(int n);
-extern "C" int dc_wgrad_set_256(int m);
-extern "C" int dc_wgrad_set_pad(int pct);
 extern "C" int dc_wgrad_set_thin(int m);
-extern "C" int dc_wgrad_set_slots(int n);
-extern "C" int dc_wgrad_set_min_stages(int n);
 extern "C" int dc_wgrad_set_384(int m);
 extern "C" int dc_wgrad_set_384_slots(int n);
 extern "C" int dc_wgrad_set_384_fill(int pct);
@@ -959,11 +955,7 @@ extern "C" int dc_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "wgrad_target_blocks") == 0) return dc_wgrad_set_target_blocks(value);
   if (name != nullptr && strcmp(name, "wgrad_mode") == 0) return dc_wgrad_set_mode(value);
   if (name != nullptr && strcmp(name, "wgrad_min_steps") == 0) return dc_wgrad_set_min_steps(value);
-  if (name != nullptr && strcmp(name, "wgrad256") == 0) return dc_wgrad_set_256(value);
-  if (name != nullptr && strcmp(name, "wgrad256_pad") == 0) return dc_wgrad_set_pad(value);
   if (name != nullptr && strcmp(name, "thin_wgrad") == 0) return dc_wgrad_set_thin(value);
-  if (name != nullptr && strcmp(name, "wgrad256_slots") == 0) return dc_wgrad_set_slots(value);
-  if (name != nullptr && strcmp(name, "wgrad256_min_stages") == 0) return dc_wgrad_set_min_stages(value);
   if (name != nullptr && strcmp(name, "wgrad384") == 0) return dc_wgrad_set_384(value);
   if (name != nullptr && strcmp(name, "wgrad384_slots") == 0) return dc_wgrad_set_384_slots(value);
   if (name != nullptr && strcmp(name, "wgrad384_fill") == 0) return dc_wgrad_set_384_fill(value);
@@ -983,7 +975,7 @@ static const struct { const char* name; int value; } kOptionDefaults[] = {
     {"igemm_mode", 2}, {"igemm256", 1}, {"pw384", 1}, {"pw384_k64", 1}, {"pw224", 1}, {"pw192", 1}, {"igemm256p", 1}, {"igemm256p_wgs", 0}, {"igemm256p_min", 257},
     {"thin_fwd", 1}, {"thin_tile", 1}, {"igemm256_rel", 0}, {"pack_blocks", 2048},
     {"igemm256_phase_fast", 1}, {"wgrad_target_blocks", 768},
-    {"wgrad_mode", 1}, {"wgrad_min_steps", 16}, {"wgrad256", 1}, {"wgrad256_pad", 115}, {"thin_wgrad", 1}, {"wgrad256_slots", 192}, {"wgrad256_min_stages", 96},
+    {"wgrad_mode", 1}, {"wgrad_min_steps", 16}, {"thin_wgrad", 1}, 
     {"wgrad384", 1}, {"wgrad384_slots", 192}, {"wgrad384_fill", 66}, {"wgrad384_min_stages", 96}, {"head_fused", 1},
     {"head_dgrad_fused", 1}, {"head_wgrad_fused", 1}, {"igemm256_splitk", 1}, {"igemm_zfill", 1}, {"pw_bn_bwd", 3}, {"sep_fwd", 1}, {"dw_tile", 1}, {"dw_wgrad_tpb", 0}, {"dw_cg", 0}, {"dw_pipe", 1}, {"bn_cgw", 32}, {"bn_rows", 32}, {"bn_apply_rows", 1}, {"bn_fin_mul_fwd", 2}, {"bn_fin_mul_bwd", 2},
 };

@@ -463,9 +463,12 @@ extern "C" int dc_pw_bn_bwd_rows(int dtype, int Cin, int Cout, long M) {
 extern "C" int dc_pw_bn_bwd(int dtype, long M, int Cin, int Cout, long count, const void* dout, int lddo, const void* y, int ldy, int relu,
                             const float* gamma, const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta,
                             const float* mscale, const float* mshift, const void* x, int ldx, const void* wb, void* dx, int lddx, float* wslab,
-                            void* stream) {
+                            int wslab_rows, void* stream) {
   const int rows = dc_pw_bn_bwd_rows(dtype, Cin, Cout, M);
   DC_REQUIRE(rows > 0, "dc_pw_bn_bwd: shape not served (dc_pw_bn_bwd_rows)");
+  // the caller sized its slab (and the fold that follows) from an earlier dc_pw_bn_bwd_rows call: a planner that has changed its mind since
+  // (another device, a switch flipped in between) must not write past it or leave rows the fold then sums as garbage
+  DC_REQUIRE(wslab_rows == rows, "dc_pw_bn_bwd: wslab_rows is not what dc_pw_bn_bwd_rows returns for this shape now");
   DC_REQUIRE(relu == 0 || relu == 2, "dc_pw_bn_bwd: the ReLU mask is recomputed from y (relu 0 or 2)");
   DC_REQUIRE(count > 0 && gamma && save_mean && save_invstd && dgamma && dbeta && wslab && wb, "dc_pw_bn_bwd: null argument");
   DC_REQUIRE(relu == 0 || (mscale && mshift), "dc_pw_bn_bwd: the mask needs the forward scale / shift");

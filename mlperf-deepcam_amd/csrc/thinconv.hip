@@ -1,5 +1,5 @@
 // Weight gradient of the two thin 3x3 convolutions of the entry stem (16 -> 32 stride 2 on 768x1152, 32 -> 64 stride 1 on
-// 384x576; deeplab_xception.py:145,149).  With so few channels the tiled GEMM kernels (wgrad.hip / wgrad256.hip) launch one
+// 384x576; deeplab_xception.py:145,149).  With so few channels the tiled GEMM kernels (wgrad.hip / wgrad384.hip) launch one
 // workgroup set PER TAP, each re-reading dy, and fill 1/8 of their MFMA tile: 0.67-0.68 ms per layer against ~0.07 ms of
 // compulsory traffic.  Here ONE pass produces all nine taps:
 //

@@ -1,4 +1,4 @@
-// Shared by the weight-gradient kernels (wgrad.hip: 128 x 128 tile, 4 waves; wgrad256.hip: 256 x 256 tile, 8 waves).
+// Shared by the weight-gradient kernels (wgrad.hip: 128 x 128 tile, 4 waves; wgrad384.hip: 256 x 384 tile, 8 waves).
 #pragma once
 #include "conv_geom.h"
 
@@ -20,21 +20,13 @@ struct WgradParams {
   int xrelu = 0;
 };
 
-// 256 x 256 tile kernel (bf16 only): split plan and launch.  The slab layout [split][tap][Co][Ci] is the same as the small
-// kernel's, so wgrad_reduce_kernel serves both.
 // dc_conv_wgrad on a lazily applied BatchNorm output: the gathered operand is act(y * xscale + xshift) (stem_head.hip: the head's weight gradient)
 int conv_wgrad_bnin(const dc_conv_desc* d, int N, int Hi, int Wi, const void* y, int ldy, const float* xscale, const float* xshift, int xrelu,
                     const void* dy, int lddy, void* workspace, size_t workspace_bytes, float* grad_w, void* stream);
-constexpr int WG_MAXGROUP = 4;   // layers of one geometry per grouped launch (dc_conv_wgrad_group)
-void wgrad256_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group = 1);
-void wgrad256_set_min_stages(int n);   // fewest 32-pixel stages a split of the 256-tile kernel may have (default 96)
-void wgrad256_set_slots(int n);   // workgroups a launch of the 256-tile kernel aims for (default 256 = one per CU)
-// group > 1: xs / dys / slabs hold `group` pointers (entry 0 repeats p.x / p.dy / p.slab)
-int launch_wgrad256(const WgradParams& p, hipStream_t st, int group = 1, const void* const* xs = nullptr, const void* const* dys = nullptr,
-                    float* const* slabs = nullptr);
 
-// wgrad384.hip: pointwise (1x1, stride 1) layers on a 256 (co) x 384 (ci) tile; up to WG384_MAXL layers of one geometry per launch; outs[l] is
-// layer l's [splits][Co][Ci] slab or, with splits == 1, its gradient tensor
+// wgrad384.hip: pointwise, stride-1 3 x 3 and transposed layers on a 256 (co) x 384 (ci) tile; up to WG384_MAXL layers of one geometry per launch
+// (group > 1: xs / dys / outs hold `group` pointers, entry 0 repeats p.x / p.dy / p.slab); outs[l] is layer l's [splits][tap][Co][Ci] slab -- the
+// small kernel's layout, so wgrad_reduce_kernel and dc_fold_slabs serve both -- or, with splits == 1, its gradient tensor
 constexpr int WG384_MAXL = 16;
 bool wgrad384_eligible(const GatherGeom& g, int ldx, int lddy, long M);
 bool wgrad384_is_tconv(const GatherGeom& g);

@@ -455,10 +455,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 static int g_wgrad_mode = 1;               // 1 = LDS-DMA 3-stage kernel, 0 = register-staged kernel
 static int g_thin_wgrad = 1;               // one-pass kernel for the two thin stem convolutions (thinconv.hip)
-static int g_wgrad256_pad = 115;           // tuning switch "wgrad256_pad"
 static int g_wgrad384_fill = 66;           // fewest percent of a 384-wide tile row a pointwise layer's input channels must fill ("wgrad384_fill")
 static int g_wgrad384 = 1;                 // 256 x 384 pointwise kernel: 0 never, 1 planner, 2 wherever eligible (tests)
-static int g_wgrad256 = 1;                 // 0: 128-tile kernel only, 1: planner, 2: 256-tile kernel wherever eligible (bf16)
 static int g_wgrad_target_blocks = 768;    // resident capacity: 256 CUs x 3 workgroups (48 KiB LDS, 146 registers)
 
 // Fewest K steps (of BP pixels) a pixel split may have (tuning switch "wgrad_min_steps").  Every split costs a 64 KiB fp32 slab
@@ -494,22 +492,6 @@ extern "C" int dc_wgrad_set_mode(int m) {
   return 0;
 }
 
-extern "C" int dc_wgrad_set_256(int m) {
-  g_wgrad256 = m;
-  return 0;
-}
-
-extern "C" int dc_wgrad_set_min_stages(int n) {
-  if (n < 1) return dc_fail("dc_set_option: wgrad256_min_stages must be positive", __FILE__, __LINE__);
-  wgrad256_set_min_stages(n);
-  return 0;
-}
-
-extern "C" int dc_wgrad_set_slots(int n) {
-  if (n < 1) return dc_fail("dc_set_option: wgrad256_slots must be positive", __FILE__, __LINE__);
-  wgrad256_set_slots(n);
-  return 0;
-}
 
 extern "C" int dc_wgrad_set_384(int m) {
   g_wgrad384 = m;
@@ -530,25 +512,13 @@ extern "C" int dc_wgrad_set_384_min_stages(int n) {
   return 0;
 }
 
-extern "C" int dc_wgrad_set_pad(int pct) {
-  g_wgrad256_pad = pct < 100 ? 100 : pct;
-  return 0;
-}
-
 extern "C" int dc_wgrad_set_thin(int m) {
   g_thin_wgrad = m ? 1 : 0;
   return 0;
 }
 
-// Tile-shape planner (bf16): the 256-tile kernel when both channel extents fill at least most of a 256 tile.
-static bool wgrad256_wins(const GatherGeom& g) {
-  if (g_wgrad256 == 2) return true;
-  if (g_wgrad256 == 0) return false;
-  const long pad256 = (long)cdiv(g.Cin, 256) * 256 * cdiv(g.Cout, 256) * 256;
-  const long pad128 = (long)cdiv(g.Cin, 128) * 128 * cdiv(g.Cout, 128) * 128;
-  return pad256 * 100 <= pad128 * g_wgrad256_pad;   // at most (g_wgrad256_pad - 100) % more padded work than the small tile
-}
-
+// (Round 6: the 256 x 256 weight-gradient kernel of rounds 2 - 4, wgrad256.hip, served one launch per step after wgrad384.hip took the pointwise,
+// 3 x 3 and transposed layers; with that launch on the 128-tile kernel the step is the same -- 31.14 against 31.17 ms -- and the file is gone.)
 // Pointwise layers whose input-channel extent pads no more on 384-wide tiles than on 256-wide ones go to the 256 x 384 kernel (wgrad384.hip)
 static bool wgrad384_wins(const GatherGeom& g) {
   if (g_wgrad384 == 0 || !wgrad384_eligible(g, 0, 0, 0)) return false;
@@ -565,15 +535,11 @@ static bool wgrad384_wins(const GatherGeom& g) {
   const long nq = cdiv(g.Cin, 64), nxt = cdiv(nq, 6);
   return nq * 100 >= nxt * 6 * g_wgrad384_fill && (long)cdiv(g.Cout, 256) * 256 * 3 <= (long)g.Cout * 4;
 }
-// the "big tile" plan and launch of a layer the 256-tile planner accepts: 256 x 384 where it wins, else 256 x 256
-static void wgrad_big_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group = 1) {
-  if (wgrad384_wins(g)) wgrad384_plan(g, M, splits, chunk, group);
-  else wgrad256_plan(g, M, splits, chunk, group);
-}
+// the "big tile" plan and launch of a layer the 256 x 384 planner accepts
+static void wgrad_big_plan(const GatherGeom& g, long M, int* splits, int* chunk, int group = 1) { wgrad384_plan(g, M, splits, chunk, group); }
 static int launch_wgrad_big(const WgradParams& p, hipStream_t st, int group = 1, const void* const* xs = nullptr, const void* const* dys = nullptr,
                             float* const* slabs = nullptr) {
-  if (wgrad384_wins(p.g)) return launch_wgrad384(p, st, group, xs, dys, slabs);
-  return launch_wgrad256(p, st, group, xs, dys, slabs);
+  return launch_wgrad384(p, st, group, xs, dys, slabs);
 }
 
 static int launch_wgrad_reduce(const float* slab, float* grad_w, int splits, const GatherGeom& g, int transposed, hipStream_t st) {
@@ -616,8 +582,8 @@ static int plan_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, bool transfo
   DC_REQUIRE(M < (1L << 31) - 256, "dc_conv_wgrad: too many pixels for 32-bit indexing");
   p->N = N; p->M = (int)M;
   if (count > 1) {
-    DC_REQUIRE(!transform && d->dtype == DC_BF16 && !(g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi)) && (wgrad256_wins(p->g) || wgrad384_wins(p->g)) &&
-                   count <= (wgrad384_wins(p->g) ? WG384_MAXL : WG_MAXGROUP),
+    DC_REQUIRE(!transform && d->dtype == DC_BF16 && !(g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi)) && wgrad384_wins(p->g) &&
+                   count <= WG384_MAXL,
                "dc_conv_wgrad: this layer is not served by the grouped launch");
     *kind = WK_256;
     wgrad_big_plan(p->g, M, &p->splits, &p->chunk, count);
@@ -625,7 +591,7 @@ static int plan_wgrad(const dc_conv_desc* d, int N, int Hi, int Wi, bool transfo
   }
   const int BP = d->dtype == DC_BF16 ? 64 : 32;    // chunk granularity (a multiple of both kernels' pixels per stage)
   const bool thin = !transform && g_thin_wgrad && thin_wgrad_eligible(*d, Hi, Wi);
-  const bool big = !transform && !thin && d->dtype == DC_BF16 && (wgrad256_wins(p->g) || wgrad384_wins(p->g));
+  const bool big = !transform && !thin && d->dtype == DC_BF16 && wgrad384_wins(p->g);
   if (thin) { p->splits = thin_wgrad_splits(*d, N, Hi, Wi); p->chunk = 0; *kind = WK_THIN; }
   else if (big) { wgrad_big_plan(p->g, M, &p->splits, &p->chunk); *kind = WK_256; }
   else { plan_splits(p->g, M, BP, &p->splits, &p->chunk); *kind = (g_wgrad_mode == 1 && !transform) ? WK_DMA : WK_REG; }
@@ -699,14 +665,14 @@ int conv_wgrad_bnin(const dc_conv_desc* d, int N, int Hi, int Wi, const void* y,
 // Grouped form: `count` layers of ONE geometry (same descriptor, extents and row strides) in one launch of the 256-tile
 // kernel and one reduction per layer.  Layers the 256-tile kernel does not serve fall back to `count` plain calls.
 static bool wgrad_group_eligible(const dc_conv_desc& d, const GatherGeom& g, int Hi, int Wi) {
-  return d.dtype == DC_BF16 && !(g_thin_wgrad && thin_wgrad_eligible(d, Hi, Wi)) && (wgrad256_wins(g) || wgrad384_wins(g));
+  return d.dtype == DC_BF16 && !(g_thin_wgrad && thin_wgrad_eligible(d, Hi, Wi)) && wgrad384_wins(g);
 }
 
 extern "C" size_t dc_conv_wgrad_group_workspace(const dc_conv_desc* d, int N, int Hi, int Wi, int count) {
   GatherGeom g;
   if (d == nullptr || count < 1 || !build_geom(*d, Hi, Wi, kFwd, &g)) return 0;
   const size_t single = dc_conv_wgrad_workspace(d, N, Hi, Wi);
-  if (count == 1 || !wgrad_group_eligible(*d, g, Hi, Wi) || count > (wgrad384_wins(g) ? WG384_MAXL : WG_MAXGROUP)) return single;
+  if (count == 1 || !wgrad_group_eligible(*d, g, Hi, Wi) || count > WG384_MAXL) return single;
   int splits, chunk;
   wgrad_big_plan(g, (long)N * g.Qh * g.Qw, &splits, &chunk, count);
   const size_t grouped = (size_t)count * splits * g.ntaps * g.Cout * g.Cin * sizeof(float);
@@ -720,7 +686,7 @@ extern "C" int dc_conv_wgrad_group(const dc_conv_desc* d, int N, int Hi, int Wi,
   DC_REQUIRE(count >= 1, "dc_conv_wgrad_group: empty group");
   WgradParams p;
   if (!build_geom(*d, Hi, Wi, kFwd, &p.g)) return dc_fail("dc_conv_wgrad_group: unsupported geometry", __FILE__, __LINE__);
-  if (count == 1 || !wgrad_group_eligible(*d, p.g, Hi, Wi) || count > (wgrad384_wins(p.g) ? WG384_MAXL : WG_MAXGROUP)) {
+  if (count == 1 || !wgrad_group_eligible(*d, p.g, Hi, Wi) || count > WG384_MAXL) {
     for (int l = 0; l < count; ++l)
       if (int e = dc_conv_wgrad(d, N, Hi, Wi, xs[l], ldx, dys[l], lddy, workspace, workspace_bytes, grad_ws[l], stream)) return e;
     return 0;
@@ -736,7 +702,6 @@ extern "C" int dc_conv_wgrad_group(const dc_conv_desc* d, int N, int Hi, int Wi,
   const size_t per_layer = (size_t)p.splits * p.g.ntaps * p.g.Cout * p.g.Cin;   // floats
   DC_REQUIRE(workspace_bytes >= per_layer * count * sizeof(float), "dc_conv_wgrad_group: workspace too small");
   float* slabs[WG384_MAXL];
-  static_assert(WG384_MAXL >= WG_MAXGROUP, "slab pointer array");
   for (int l = 0; l < count; ++l) slabs[l] = (float*)workspace + per_layer * l;
   p.x = xs[0]; p.dy = dys[0]; p.slab = slabs[0];
   p.N = N; p.ldx = ldx; p.lddy = lddy; p.M = (int)M;

@@ -2,7 +2,7 @@
 //
 //     dW[co][ci] = sum over pixels m of dy[m][co] * x[m][ci]
 //
-// Why a second tile shape.  wgrad256.hip streams BOTH operands of its 256 x 256 tile from beyond the L2 (activations and their
+// Why a second tile shape.  The 256 x 256 kernel of rounds 2 - 4 (wgrad256.hip, retired in round 6) streamed BOTH operands of its 256 x 256 tile from beyond the L2 (activations and their
 // gradients are each read once per channel tile and nothing else), and a CU takes those bytes in at ~24 GB/s whatever the ring depth
 // (profiles/r04_wgrad_group_probe.txt: 170 us for the three-layer 728 launch, 109 with L2-resident operands, 84 MFMA only).  What is
 // left is bytes per flop: a 256 x 384 tile needs 40 KiB per 32-pixel stage for 3.1 M MACs against 32 KiB for 2.1 M (-17 %), and the

@@ -408,7 +408,7 @@ class Engine:
                 def bwd_fused():
                     L.call("dc_pw_bn_bwd", dt, y.M, x.C, cout, y.M, do.ptr, do.ld, y.ptr, y.ld, pwf["relu"], pwf["gam"], L.dptr(pwf["mean"]),
                            L.dptr(pwf["invstd"]), pwf["dgam"], pwf["dbet"], L.dptr(pwf["scale"]), L.dptr(pwf["shift"]), x.ptr, x.ld, L.dptr(wb),
-                           dx.ptr, dx.ld, L.dptr(fslab), self._st())
+                           dx.ptr, dx.ld, L.dptr(fslab), frows, self._st())
                 return bwd_fused, ready
             dy = y.grad
             mode = x.take_grad_mode() if need_dx else 0

@@ -112,7 +112,7 @@ _SIGS = {
     "dc_sepconv_fwd_rows": (I, [I, I, I, I, I, I, I, I]),
     "dc_sepconv_fwd": (I, [I, I, I, I, I, I, P, I, P, P, I, P, P, I, P, P, I, P, I, P]),
     "dc_pw_bn_bwd_rows": (I, [I, I, I, L]),
-    "dc_pw_bn_bwd": (I, [I, L, I, I, L, P, I, P, I, I, P, P, P, P, P, P, P, P, I, P, P, I, P, P]),
+    "dc_pw_bn_bwd": (I, [I, L, I, I, L, P, I, P, I, I, P, P, P, P, P, P, P, P, I, P, P, I, P, I, P]),
     "dc_bn_bwd_apply_fin": (I, [I, L, I, L, P, I, P, I, P, I, I, P, P, P, P, I, P, P, P, I, P, I, P, P, P]),
     "dc_stem_stat_rows": (I, [I, I, I]),
     "dc_stem_fwd": (I, [I, I, I, I, I, P, P, P, I, P, P]),

@@ -1,6 +1,6 @@
 """A/B of whole-step time under tuning switches: every configuration runs in its own process (the switches are read at load).
 
-    python scripts/ab_step.py --batch 8 --steps 15 "" "DEEPCAM_HIP_OPTIONS=wgrad256=0" "DC_WGRAD_GROUP=3 DEEPCAM_HIP_OPTIONS=wgrad256_slots=128"
+    python scripts/ab_step.py --batch 8 --steps 15 "" "DEEPCAM_HIP_OPTIONS=wgrad384=0" "DC_WGRAD_GROUP=3 DEEPCAM_HIP_OPTIONS=wgrad384_slots=128"
 
 Prints ms/step per configuration (min and median over three interleaved rounds, since boxes drift by a few percent)."""
 import argparse, json, os, statistics, subprocess, sys

@@ -44,11 +44,11 @@ for (cin, cout, H, W) in ((128, 128, 384, 576), (64, 128, 384, 576), (256, 256, 
     ent2 = (L.FoldEntry * 1)(L.FoldEntry(slab2.data_ptr(), gw2.data_ptr(), L.DC_FOLD_CONV, rows, 1, cout, cin))
     def fused():
         L.call("dc_pw_bn_bwd", L.DC_BF16, M, cin, cout, M, P(do), cout, P(y), cout, 2, P(gamma), P(mean), P(invstd), P(dg), P(db), P(sc), P(sh),
-               P(x), cin, P(wb), P(dx2), cin, P(slab2), S())
+               P(x), cin, P(wb), P(dx2), cin, P(slab2), rows, S())
         L.call("dc_fold_slabs", ent2, 1, S())
     t_fused = timed(fused)
     t_k = timed(lambda: L.call("dc_pw_bn_bwd", L.DC_BF16, M, cin, cout, M, P(do), cout, P(y), cout, 2, P(gamma), P(mean), P(invstd), P(dg), P(db), P(sc), P(sh),
-               P(x), cin, P(wb), P(dx2), cin, P(slab2), S()))
+               P(x), cin, P(wb), P(dx2), cin, P(slab2), rows, S()))
     byts = M * (2 * cout + 2 * cin) * 2
     print(f"{cin:3d} -> {cout} at {N} x {H} x {W} (M = {M}): apply {t_apply:6.1f} + data gradient {t_dgrad:6.1f} + weight gradient (+ fold, {splits.value} splits) {t_wgrad:6.1f} = "
           f"{t_apply + t_dgrad + t_wgrad:6.1f} us | one pass {t_k:6.1f} (+ fold of {rows} rows: {t_fused:6.1f}) us = {byts / t_k / 1e6:5.2f} TB/s of (dout, y, x, dx) | "

@@ -45,7 +45,7 @@ def read(d, counters):
                 continue
             k = key_of(r["Kernel_Name"])
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            if any(f in k for f in ("igemm", "pw384", "wgrad256", "wgrad_dma")):
+            if any(f in k for f in ("igemm", "pw384", "pw224", "pw192", "wgrad384", "wgrad_dma")):
                 sk = (k, int(r["Grid_Size"]) // max(int(r.get("Workgroup_Size", 0) or 0), 1))
                 SHAPES[sk][r["Counter_Name"]] += float(r["Counter_Value"])
                 if (r["Dispatch_Id"], r["Counter_Name"]) not in seen and r["Counter_Name"] in ("FETCH_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):

@@ -105,16 +105,6 @@ def test_conv_256_tile_kernel(case):
         L.call("dc_set_option", b"igemm256", 1)
 
 
-@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_256_tile_wgrad_kernel(case):
-    """The eight-wave 256 x 256 weight-gradient kernel, forced on every layer, passes the same checks."""
-    L.call("dc_set_option", b"wgrad256", 2)
-    try:
-        test_conv_fwd_dgrad_wgrad(case, torch.bfloat16)
-    finally:
-        L.call("dc_set_option", b"wgrad256", 1)
-
-
 PW_CASES = [c for c in CONV_CASES if c[1] == 1 and c[2] == 1 and c[6] >= 64 and c[8] * c[9] * c[10] > 16]
 
 
@@ -707,7 +697,6 @@ def test_conv_wgrad_384_tile_kernel(case):
     outs = {}
     for mode in (2, 0):
         L.call("dc_set_option", b"wgrad384", mode)
-        L.call("dc_set_option", b"wgrad256", 2)
         for kk, v in opts.items():
             L.call("dc_set_option", kk.encode(), v)
         wsb = lib.dc_conv_wgrad_group_workspace(C.byref(d), N, H, W, layers)
@@ -732,7 +721,7 @@ TCONV384_CASES = [
 @pytest.mark.parametrize("case", TCONV384_CASES, ids=[c[0] for c in TCONV384_CASES])
 def test_conv_transpose_wgrad_384_tile_kernel(case):
     """ConvTranspose2d(k 3, stride 2, pad 1, output_padding 1) weight gradient on the 256 x 384 kernel (wgrad384.hip, MODE 2: x is the linear
-    operand, dy is gathered at stride 2) against autograd and against the 256 x 256 kernel."""
+    operand, dy is gathered at stride 2) against autograd and against the 128 x 128 kernel."""
     name, cin, cout, N, H, W, opts = case
     dtype = torch.bfloat16
     d = desc(dtype, 3, 2, 1, 1, 1, cin, cout)
@@ -746,7 +735,6 @@ def test_conv_transpose_wgrad_384_tile_kernel(case):
     outs = {}
     for mode in (2, 0):
         L.call("dc_set_option", b"wgrad384", mode)
-        L.call("dc_set_option", b"wgrad256", 2)
         for kk, v in opts.items():
             L.call("dc_set_option", kk.encode(), v)
         wsb = lib.dc_conv_wgrad_workspace(C.byref(d), N, H, W)
@@ -1087,6 +1075,18 @@ def test_batchnorm_finalize_inside_its_consumer(case):
             torch.cuda.synchronize()
             assert torch.equal(o_got.float(), o_ref.float()) and torch.isnan(ob[..., :8].float()).all() and torch.isnan(ob[..., 8 + Cc:].float()).all()
             same_state(ref, got)
+    # with the row-block kernel switched off (option bn_apply_rows = 0) dc_bn_apply_fin is the finalize launch followed by the grid-stride apply
+    # instead of an error: same outputs, same state
+    L.call("dc_set_option", b"bn_apply_rows", 0)
+    try:
+        got = state()
+        ob, o_fb = empty_nhwc(N, H, W, Cc, dtype, ld=Cc + 16, off=8)
+        L.call("dc_bn_apply_fin", dt, M, Cc, M, vptr(yv), ld, *fin_args(got), None, Cc, prelu, vptr(o_fb), Cc + 16, S())
+        torch.cuda.synchronize()
+    finally:
+        L.call("dc_set_option", b"bn_apply_rows", 1)
+    assert torch.equal(o_fb.float(), o_got.float()) and torch.isnan(ob[..., :8].float()).all()
+    same_state(ref, got)
     # against torch on the real statistics
     o = F.batch_norm(from_nhwc(yv).float().cpu(), None, None, gamma.cpu(), beta.cpu(), True, 0.1, 1e-5)
     assert_close(from_nhwc(o_got), o, dtype, bf16=2e-2)
@@ -1980,7 +1980,7 @@ def test_pointwise_bn_backward_in_one_pass(name, cin, cout, N, H, W, relu):
     slab = torch.full((rows, cout, cin), float("nan"), device=dev())
     gw = torch.full((cout, cin, 1, 1), float("nan"), device=dev())
     L.call("dc_pw_bn_bwd", dt, M, cin, cout, M, vptr(dodev), cout, vptr(yv), cout + 8, relu, vptr(gamma), vptr(mean), vptr(invstd), vptr(dg), vptr(db),
-           vptr(sc), vptr(sh), vptr(xv), cin + 16, vptr(wb), vptr(dx), cin + 8, vptr(slab), S())
+           vptr(sc), vptr(sh), vptr(xv), cin + 16, vptr(wb), vptr(dx), cin + 8, vptr(slab), rows, S())
     ents = [L.FoldEntry(slab.data_ptr(), gw.data_ptr(), L.DC_FOLD_CONV, rows, 1, cout, cin)]
     L.call("dc_fold_slabs", (L.FoldEntry * 1)(*ents), 1, S())
     torch.cuda.synchronize()

@@ -422,14 +422,18 @@ def test_golden_full_size_two_adam_steps(golden_dir, B, fixture, dtype):
     """768x1152 at local batch 2 (configs[1]), 4 (configs[2]) and 8 (configs[4] per GPU: the benched shape, where the batch-8-only kernel
     choices are the defaults): loss, IoU and argmax histogram of TWO Adam steps against the reference's own run.  Step 0 is a pure function of identical weights.  Step 1 follows an Adam update of lr*sign(g) on every
     weight: measured (scripts/grad_check.py, profiles/r02_grad_check.txt) fp32 1.6e-4 / 1.8e-4 off the reference at B=2 / 4 --
-    inside north_star's 1e-3 -- and bf16 3.4e-3 / 1.6e-3 (its gradient is noisier, see above), held to 1e-2."""
+    inside north_star's 1e-3 -- and bf16 2.3e-3 / 7.6e-4 / 6.3e-3 at B = 2 / 4 / 8 (its gradient is noisier, see above), held to the envelope per
+    fixture below."""
     g = json.load(open(os.path.join(golden_dir, fixture)))
     # [b8-adamw]: AdamW with weight decay 1e-2 (train_hdf5_ddp.py:215-216), the decoupled-decay half of the benched LAMB path, at the benched shape
     key, optname, wd = ("adamw_wd1e-2", "AdamW", 1e-2) if "adamw_wd1e-2" in g else ("adam_wd1e-6", "Adam", 1e-6)
     ref = g[key]["steps"]
     got, net = _full_steps(B, dtype, 2, optname, wd)
     f32 = dtype == torch.float32
-    ltol = ((2e-5, 1e-3) if f32 else (1e-3, 1e-2))
+    # bf16 behind ONE update: the measured envelope per fixture instead of a blanket 1e-2 (profiles/r06_third_step.txt: B=2 2.3e-3, B=4 7.6e-4,
+    # B=8 6.3e-3, B=8 AdamW 6.3e-3; the runs are deterministic, the bounds sit 30 - 60 % outside)
+    bf16_step1 = {"model_full.json": 4e-3, "model_full_b4.json": 2e-3, "model_full_b8.json": 8e-3, "model_full_b8_adamw.json": 8e-3}[fixture]
+    ltol = ((2e-5, 1e-3) if f32 else (1e-3, bf16_step1))
     itol = ((1e-3, 5e-3) if f32 else (5e-3, 1e-2))
     for s in range(2):
         loss, iou, hist = got[s]
