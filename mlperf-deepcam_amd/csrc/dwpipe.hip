@@ -9,8 +9,8 @@
 //   * every input of a tile -- the (8+2d) x (8+2d) halo tile AND, for the data gradient, the BatchNorm input / layer input and the
 //     addend at the tile's own pixels -- arrives by LDS-DMA into a ring of 2 - 4 stages, requested NS-1 tiles ahead; the loop holds no
 //     VGPR-destination load, so the in-order vmcnt can be counted exactly: "tile i has landed" = all but the youngest
-//     (NS-1) x stores + (NS-2) x DMAs of this wave are done (every wave issues the same number of each per tile; lanes without work read
-//     the zero page / store nothing but the instruction is issued);
+//     (NS-1) x stores + (NS-2) x DMAs of this wave are done (every wave issues the same number of each per tile; lanes without work are
+//     out of their buffer resource's range -- zeros land in LDS -- / store nothing, but the instruction is issued);
 //   * a thread owns ONE 4-pixel strip of half a channel group per tile: 32 half-groups x 16 strips; its nine taps live in registers for
 //     the whole launch;
 //   * BatchNorm sums and weight-gradient products stay in registers across ALL tiles of the workgroup and are folded once at the end:
@@ -76,10 +76,8 @@ struct DwpArgs {
   const float* invstd2;
   int relu2;
   float* slab2;         // [2][st.rows][C]
-  const void* zero_page;
 };
 
-static __device__ __attribute__((aligned(256))) unsigned char dwp_zero_page[256];
 #ifdef DWP_STAMPS
 static __device__ unsigned long long dwp_stamp_buf[256 * 8 * 4];
 #endif
@@ -112,13 +110,38 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
   const int row = sl >> 1, xs = (sl & 1) * DT_PX;
   const bool cok = cg0 + (h >> 1) < ngroups;
   const int ch0 = cok ? cg0 * 8 + h * KH : 0;
-  // DMA side: this lane's 16-byte slots all belong to channel group g
+  // DMA side: this lane's 16-byte slots all belong to channel group g.  Every staged tensor travels as `buffer_load_dwordx4 ... offen lds`
+  // through a resource that covers ONE image: a lane's offset is its constant place in the tile (relative to the tile's first pixel, negative
+  // in the halo's first rows and columns) plus the tile's origin, formed in a VGPR -- the range check takes the sum as unsigned, so rows above the
+  // image (negative) and below it (past the image's bytes) come back as zeros, as do dummy requests past the last tile and channel groups past
+  // C (marker offsets); columns left / right of the image are the one case the check cannot see: a lane of the halo's first / last DIL columns is
+  // sent out of range when the tile touches that edge.  (Round 5's form computed a 64-bit address, two range tests and a zero-page select per
+  // instruction: ~17 vector instructions each, a tenth of the loop's.)
   const int g = tid & 15;
   const bool gok = cg0 + g < ngroups;
-  const size_t goff = (size_t)(cg0 + g) * 8;
-  const uintptr_t zp = (uintptr_t)a.zero_page;
+  constexpr unsigned OOB = 0x80000000u;                   // an image is smaller than 2 GiB (dw_pipe_rows)
+  unsigned hoff[K::HIT];                                  // byte offset of this lane's halo slot from the tile's first pixel (two's complement)
+  unsigned hedge = 0;                                     // 2 bits per halo instruction: 1 = in the halo's first DIL columns, 2 = in its last
+#pragma unroll
+  for (int it = 0; it < K::HIT; ++it) {
+    const int hp = (it * P_THREADS + tid) >> 4;
+    const int hy = hp / K::HW, hx = hp - hy * K::HW;
+    hoff[it] = (gok && hp < K::HP) ? (unsigned)((((hy - DIL) * W + (hx - DIL)) * a.ldin + (cg0 + g) * 8) * 2) : OOB;
+    hedge |= ((hx < DIL ? 1u : 0u) | (hx >= K::HW - DIL ? 2u : 0u)) << (2 * it);
+  }
+  // own-pixel tiles (BatchNorm input, addend, second BatchNorm input): pixel (it * 512 + tid) >> 4 of the 8 x 8 tile, never past an edge
+  unsigned yoff[2], aoff[2], y2off[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int pp = (it * P_THREADS + tid) >> 4;
+    const int py = pp >> 3, px = pp & 7;
+    yoff[it] = gok && S::Y ? (unsigned)(((py * W + px) * a.st.ldy + (cg0 + g) * 8) * 2) : OOB;
+    aoff[it] = gok && S::A ? (unsigned)(((py * W + px) * a.ldadd + (cg0 + g) * 8) * 2) : OOB;
+    y2off[it] = gok && S::Y2 ? (unsigned)(((py * W + px) * a.ldy2 + (cg0 + g) * 8) * 2) : OOB;
+  }
 
   auto issue = [&](int t, int stage) {
+#if defined(__HIP_DEVICE_COMPILE__)     // (the buffer-resource builtins do not exist in the host pass)
     char* sb = smem + stage * S::BYTES;
     const bool live = t < t1;
     const int tt = live ? t : t0;
@@ -126,47 +149,41 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
     const int r = tt / a.ntx;
     const int ty = r % a.nty, n = r / a.nty;
     const int y0 = ty * P_TH, x0 = tx * P_TW;
-    const bf16* base = a.in + (size_t)n * H * W * a.ldin + goff;
+    const int live_mask = live ? -1 : 0;                                     // (scalar) a dummy request: a resource of zero bytes, every lane out of range
+    const unsigned emask = (x0 == 0 ? 0x55555555u : 0u) | (x0 + P_TW == W ? 0xAAAAAAAAu : 0u);
+    {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * H * W * a.ldin), 0, (H * W * a.ldin * 2) & live_mask, 0x00020000);
+      const unsigned torg = (unsigned)((y0 * W + x0) * a.ldin * 2);
 #pragma unroll
-    for (int it = 0; it < K::HIT; ++it) {
-      if (it == K::HIT - 1 && wv >= K::LASTW) break;      // wave-uniform: this wave's slots of the last instruction lie past the halo tile
-      const int hp = (it * P_THREADS + tid) >> 4;
-      const int hy = hp / K::HW, hx = hp - hy * K::HW;
-      const int iy = y0 - DIL + hy, ix = x0 - DIL + hx;
-      const bool ok = live && gok && hp < K::HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const uintptr_t src = ok ? (uintptr_t)(base + ((size_t)iy * W + ix) * a.ldin) : zp;
-      __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
+      for (int it = 0; it < K::HIT; ++it) {
+        if (it == K::HIT - 1 && wv >= K::LASTW) break;      // wave-uniform: this wave's slots of the last instruction lie past the halo tile
+        const unsigned vo = ((hedge & emask) >> (2 * it)) & 3u ? OOB : hoff[it] + torg;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sb + (it * P_THREADS + wv * 64) * 16), 16, vo, 0, 0, 0);
+      }
     }
     if constexpr (S::Y) {
-      const bf16* yb = reinterpret_cast<const bf16*>(a.st.y) + (size_t)n * H * W * a.st.ldy + goff;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const bf16*>(a.st.y) + (size_t)n * H * W * a.st.ldy), 0,
+                                                                          (H * W * a.st.ldy * 2) & live_mask, 0x00020000);
+      const unsigned torg = (unsigned)((y0 * W + x0) * a.st.ldy * 2);
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int p = (it * P_THREADS + tid) >> 4;
-        const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
-        const uintptr_t src = (live && gok) ? (uintptr_t)(yb + ((size_t)oy * W + ox) * a.st.ldy) : zp;
-        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + K::HALO + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
-      }
+      for (int it = 0; it < 2; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sb + K::HALO + (it * P_THREADS + wv * 64) * 16), 16, yoff[it] + torg, 0, 0, 0);
     }
     if constexpr (S::A) {
-      const bf16* ab = a.addend + (size_t)n * H * W * a.ldadd + goff;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.addend + (size_t)n * H * W * a.ldadd), 0, (H * W * a.ldadd * 2) & live_mask, 0x00020000);
+      const unsigned torg = (unsigned)((y0 * W + x0) * a.ldadd * 2);
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int p = (it * P_THREADS + tid) >> 4;
-        const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
-        const uintptr_t src = (live && gok) ? (uintptr_t)(ab + ((size_t)oy * W + ox) * a.ldadd) : zp;
-        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + S::OFF_A + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
-      }
+      for (int it = 0; it < 2; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sb + S::OFF_A + (it * P_THREADS + wv * 64) * 16), 16, aoff[it] + torg, 0, 0, 0);
     }
     if constexpr (S::Y2) {
-      const bf16* yb = a.y2 + (size_t)n * H * W * a.ldy2 + goff;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y2 + (size_t)n * H * W * a.ldy2), 0, (H * W * a.ldy2 * 2) & live_mask, 0x00020000);
+      const unsigned torg = (unsigned)((y0 * W + x0) * a.ldy2 * 2);
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int p = (it * P_THREADS + tid) >> 4;
-        const int oy = y0 + (p >> 3), ox = x0 + (p & 7);
-        const uintptr_t src = (live && gok) ? (uintptr_t)(yb + ((size_t)oy * W + ox) * a.ldy2) : zp;
-        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(sb + S::OFF_Y2 + (it * P_THREADS + wv * 64) * 16), 16, 0, 0);
-      }
+      for (int it = 0; it < 2; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(sb + S::OFF_Y2 + (it * P_THREADS + wv * 64) * 16), 16, y2off[it] + torg, 0, 0, 0);
     }
+#endif
   };
 
   // ---- prologue: tiles 0 .. NS-2 requested FIRST, so that the taps and coefficients below travel beside them (the compiler's wait for
@@ -418,6 +435,12 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
       if (++stage == NS) stage = 0;
     }
   }
+#ifdef DWP_STAMPS
+  if ((tid & 63) == 0 && blockIdx.x < 256) {
+    unsigned long long* o = dwp_stamp_buf + ((size_t)blockIdx.x * 8 + wv) * 4;
+    o[0] = tw; o[1] = ti; o[2] = tx_; o[3] = tc;
+  }
+#endif
   // the ring drains (dummy requests past the last tile included) before its memory becomes the fold's scratch
   wait_vm<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -514,6 +537,7 @@ int dw_pipe_rows(int dtype, int C, int dil, int N, int H, int W) {
   // (64 channels -- block 1's first depthwise layer, 226 MB of gradient at local batch 8 -- fill half of a 128-channel block: the idle lanes
   // cost nothing beside one pass over dy that also takes the BatchNorm sums and the weight gradient)
   if (!g_dw_pipe || dtype != DC_BF16 || C < P_CH / 2 || (C & 7) || (H % P_TH) || (W % P_TW) || (dil != 1 && dil != 2)) return 0;
+  if ((long)H * W * ((C + 63) / 64 * 64 + 64) * 2 >= (1L << 30)) return 0;      // an image per buffer resource: offsets and marker below 2 GiB
   const int ncb = cdiv(C / 8, P_CG);
   const long ptiles = (long)N * (H / P_TH) * (W / P_TW);
   long wc = 256 / ncb;               // one workgroup per CU
@@ -531,14 +555,6 @@ int launch_dw_pipe(int dil, bool flip, const void* in, int ldin, const float* wp
                    const DwResStats* res) {
   const int wc = dw_pipe_rows(DC_BF16, C, dil, N, H, W);
   DC_REQUIRE(wc > 0, "launch_dw_pipe: shape not served");
-  static const void* zero_dev = nullptr;
-  static hipError_t init_err = hipSuccess;
-  DC_ONCE({
-    void* zp = nullptr;
-    init_err = hipGetSymbolAddress(&zp, HIP_SYMBOL(dwp_zero_page));
-    zero_dev = zp;
-  });
-  if (init_err != hipSuccess) return dc_set_error(init_err, __FILE__, __LINE__);
   DwpArgs a;
   a.in = (const bf16*)in; a.ldin = ldin; a.wp = wp; a.addend = (const bf16*)addend; a.ldadd = ldadd; a.out = (bf16*)out; a.ldout = ldout;
   a.H = H; a.W = W; a.C = C;
@@ -551,7 +567,6 @@ int launch_dw_pipe(int dil, bool flip, const void* in, int ldin, const float* wp
   if (res != nullptr) {
     a.y2 = (const bf16*)res->y; a.ldy2 = res->ldy; a.mean2 = res->mean; a.invstd2 = res->invstd; a.relu2 = res->relu; a.slab2 = res->slab;
   }
-  a.zero_page = zero_dev;
   const int grid = a.ncb * wc;
   const bool stats = flip && a.st.slab != nullptr, wg = flip && a.st.wslab != nullptr, add = flip && addend != nullptr;
   const bool xf = !flip && pscale != nullptr;

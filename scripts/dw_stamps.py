@@ -7,7 +7,7 @@ from mlperf_deepcam_amd import lib as L
 dev = torch.device("cuda", 0); dt = L.DC_BF16; lib = L.load(); st = L.stream_ptr(); P = L.dptr
 lib.dc_debug_dwp_stamps.argtypes = [C.c_void_p]; lib.dc_debug_dwp_stamps.restype = C.c_int
 Cc, H, W, N, dil = 728, 48, 72, 8, 1
-ld = (Cc + 31) // 32 * 32
+ld = (Cc + 63) // 64 * 64
 act = lambda: torch.randn(N, H, W, ld, device=dev).to(torch.bfloat16)
 x, y, dy, dx, add = act(), act(), act(), act(), act()
 wp = torch.randn(9 * Cc, device=dev) * 0.2
