@@ -383,6 +383,7 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
         else if (i == 1) wait_vm<S::STORES + (NS - 2) * (S::DMAS - 1)>();
         else wait_vm<2 * S::STORES + (NS - 2) * (S::DMAS - 1)>();
       }
+      STAMP(tx_);                       // (stamp builds, non-XFORM modes: the vmcnt wait alone goes to the "transform" column)
       __builtin_amdgcn_s_barrier();     // everybody's pieces of tile i have landed; everybody is done with the stage tile i-1 used
       STAMP(tw);
       {
