@@ -92,8 +92,8 @@ inline long pw384_tiles(const IgemmParams& p, int npb) { return (long)((p.g.Cout
 
 // igemm224.hip: pointwise layers on a 224 x 384 tile with 32-deep weight stages from the [k][n] packing (p.w_kn) and three-deep operand rings
 bool pw224_eligible(const IgemmParams& p);
-int launch_pw224(const IgemmParams& p, hipStream_t st);
-inline long pw224_tiles(const IgemmParams& p) { return (long)((p.g.Cout + 383) / 384) * ((p.M + 223) / 224); }
+int launch_pw224(const IgemmParams& p, int tn, hipStream_t st);      // tn: channels per tile, 384 or 192
+inline long pw224_tiles(const IgemmParams& p, int tn = 384) { return (long)((p.g.Cout + tn - 1) / tn) * ((p.M + 223) / 224); }
 
 // igemm192.hip: pointwise layers with few pixels (local batch 2) on a 128 x 192 tile, eight waves, four 64-deep ring stages
 long pw192_tiles(const IgemmParams& p);

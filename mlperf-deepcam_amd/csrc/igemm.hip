@@ -552,6 +552,7 @@ static int g_pw384_k64 = 1;         // 256 x 384 tiles with 128-byte K rows wher
 static int g_pw224 = 1;             // 224 x 384 tiles with weights from the [k][n] packing where the caller passes it ("pw224"; 2: whenever eligible)
 static int pw384_plan(const IgemmParams& p) {
   if (g_pw224 == 2 && pw224_eligible(p)) return 224;
+  if (g_pw224 == 3 && pw224_eligible(p)) return 226;      // 224 x 192 tiles wherever eligible (tests)
   if (g_pw384 == 0 || !pw384_eligible(p)) return 0;
   if (g_pw384 == 2) return 8;
   if (g_pw384 == 3) return 4;
@@ -574,6 +575,11 @@ static int pw384_plan(const IgemmParams& p) {
   // where the 256-pixel tile with 64-deep stages would run: the 224-pixel tile when it is ONE round too (728 -> 728 at M = 27 648: 248 tiles)
   // (multi-round launches too: 728 -> 728 at M = 110 592 137 against 156 us, 256 -> 728 there 81 against 92: profiles/r06_pw224_bench.txt)
   if (c8 < c4 && k64 && g_pw224 && pw224_eligible(p) && cdiv(pw224_tiles(p), 256) <= cdiv(t8, 256)) return 224;
+  // where 128-pixel tiles would run (half as many pixels: local batch 4): 224 x 192 tiles when they are one round of nearly the whole chip
+  // (13 824 pixels x 728 channels: 62 x 4 = 248 tiles, 26 KiB of operands per 32-deep step instead of 32)
+  if (!(c8 < c4) && g_pw224 && pw224_eligible(p) && pw224_tiles(p, 192) > 192 && pw224_tiles(p, 192) <= 256 &&
+      p.g.Cout * 10 >= (long)cdiv(p.g.Cout, 192) * 192 * 9)
+    return 226;
   return c8 < c4 ? (k64 ? 64 : 8) : 4;
 }
 
@@ -638,7 +644,7 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   if (bst == nullptr && g_thin_fwd && thin_fwd_eligible(p.g, d->dtype, bias != nullptr, accumulate, out32))
     return launch_thin_fwd(p.g, N, in, ldin, w, p.ldw, out, ldout, slab, p.mtiles * p.g.os * p.g.os, st);
   if (d->dtype == DC_BF16 && !out32 && bst == nullptr) {      // (the BatchNorm-backward epilogue lives in the LDS-epilogue kernels)
-    if (const int npb = pw384_plan(p)) return npb == 192 ? launch_pw192(p, st) : npb == 224 ? launch_pw224(p, st) : launch_pw384(p, npb, st);
+    if (const int npb = pw384_plan(p)) return npb == 192 ? launch_pw192(p, st) : npb == 224 ? launch_pw224(p, 384, st) : npb == 226 ? launch_pw224(p, 192, st) : launch_pw384(p, npb, st);
   }
   if (d->dtype == DC_BF16 && !out32 && g_igemm256 != 0) {
     if (g_igemm256 == 2 || igemm256_wins(p)) {

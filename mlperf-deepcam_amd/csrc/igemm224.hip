@@ -38,8 +38,6 @@ namespace dc {
 
 namespace {
 
-constexpr int TN = 384;                      // channels per workgroup
-constexpr int WSTG = 32 * TN * 2;            // one 32-deep weight stage: six quads of [32 k][64 n] = 24 KiB
 constexpr int NWS = 3, NPS = 3;              // ring depths
 constexpr int NPB = 7;                       // pixel blocks of 16 per wave
 
@@ -102,31 +100,41 @@ __device__ unsigned long long pw224_stamp_buf[1024][8];
 #define PW224_STAMP(i)
 #endif
 
-template <int GP>
+// TN: channels per workgroup, 384 (six quads of 64; a wave owns 96 = six blocks of 16) or 192 (three quads; a wave owns 48 = three blocks):
+// 224 x 192 is the tile for HALF as many pixels (local batch 4: 13 824 pixels x 728 channels = 62 x 4 = 248 tiles), 26 KiB of operands per
+// 32-deep step instead of the 32 KiB of 128 x 384.
+template <int TN_>
 struct Cfg {
+  static constexpr int TN = TN_;
+  static constexpr int GP = 2;                            // pixel groups of 112
   static constexpr int GC = 8 / GP;                       // channel groups: 4
-  static constexpr int NCB = TN / 16 / GC;                // channel blocks per wave: 6
+  static constexpr int NCB = TN / 16 / GC;                // channel blocks per wave: 6 / 3
   static constexpr int TM = GP * NPB * 16;                // pixels per workgroup: 224
+  static constexpr int WSTG = 32 * TN * 2;                // one 32-deep weight stage: TN / 64 quads of [32 k][64 n] = 24 / 12 KiB
+  static constexpr int NWI = WSTG / 1024;                 // LDS-DMA instructions per weight stage: 24 / 12
+  static constexpr int WSLOTS = (NWI + 7) / 8;            // per wave: 3 / 2 (the last one only on waves < NWI - 8 * (WSLOTS - 1))
+  static constexpr int WDEF = (NWI % 8) ? 1 : 0;          // waves 4..7 own one weight instruction fewer
   static constexpr int PSTG = TM * 128;                   // one 64-deep pixel stage: 28 KiB
   static constexpr int NPI = PSTG / 1024;                 // LDS-DMA instructions per pixel stage: 28
-  static constexpr int PSLOTS = (NPI + 7) / 8;            // per wave: 4 (the last one only on waves < NPI - 8 * (PSLOTS - 1))
+  static constexpr int PSLOTS = (NPI + 7) / 8;            // per wave: 4 (the last one only on waves < NPI - 8 * (PSLOTS - 1) = 4)
   static constexpr int HP = PSLOTS / 2;                   // per wave and 32-deep step: 2
   static constexpr int POFF = NWS * WSTG;                 // LDS offset of the pixel ring
-  static constexpr int RING = NWS * WSTG + NPS * PSTG;    // 156 KiB
-  static_assert(PSLOTS % 2 == 0 && NCB % 3 == 0 && NCB % 2 == 0 && RING <= 160 * 1024, "plan");
+  static constexpr int RING = NWS * WSTG + NPS * PSTG;    // 156 / 120 KiB
+  static_assert(PSLOTS % 2 == 0 && NCB % 3 == 0 && RING <= 160 * 1024, "plan");
+  static_assert(NPI - 8 * (PSLOTS - 1) == 4 && (WDEF == 0 || NWI - 8 * (WSLOTS - 1) == 4), "waves 0..3 own every last slot");
 };
 
-template <int GP>
+template <int TNT>
 __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
-  typedef Cfg<GP> K;
-  constexpr int NCB = K::NCB, GC = K::GC, HP = K::HP;
+  typedef Cfg<TNT> K;
+  constexpr int NCB = K::NCB, GC = K::GC, HP = K::HP, TN = K::TN, WSTG = K::WSTG, GP = K::GP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GatherGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
   PW224_STAMP(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave / GC;   // pixel group (112 pixels)
-  const int wc = wave % GC;    // channel group: chunk pair wc & 1 of the quads (wc >> 1) + 2 u
+  const int wc = wave % GC;    // channel group.  TN 384: chunk pair wc & 1 of the quads (wc >> 1) + 2 u; TN 192: the chunks 3 wc .. 3 wc + 2
   const bool late = wave >= 4; // the second wave of its SIMD: issues its LDS-DMAs in later blocks of a step
 
   // XCD-aware tile order: consecutive tiles of an XCD are the channel tiles of one pixel tile (they share its pixel rows in L2)
@@ -153,9 +161,9 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
   // offset whatever it does with the SGPR part) and a pixel lane whose K slot is past Cin is sent out of range.
   const int krow = 8 * (wave & 3) + (lane >> 3);
   const int wkey = ((krow >> 1) & 1) | (((krow >> 3) & 1) << 1);
-  unsigned srcw[3], srcp[K::PSLOTS];
+  unsigned srcw[K::WSLOTS], srcp[K::PSLOTS];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < K::WSLOTS; ++i) {
     const int ncol = ((wave >> 2) + 2 * i) * 64 + ((((lane & 7) >> 1) ^ wkey) << 4) + (lane & 1) * 8;
     srcw[i] = (unsigned)(((size_t)krow * p.ldw_kn + n0 + ncol) * 2);
   }
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
     const int m = m0 + 8 * (wave + 8 * i) + (lane >> 3);
     srcp[i] = (unsigned)(((size_t)m * p.ldx + pslot * 8) * 2);          // m >= M: past the resource's extent
   }
-  const bool has_last = wave + 8 * (K::PSLOTS - 1) < K::NPI;           // (wave-uniform) this wave owns a last pixel instruction
+  const bool has_last = wave < 4;      // (wave-uniform) this wave owns the last pixel instruction and, where a weight stage is 12, the last weight one
   const unsigned wstep = (unsigned)p.ldw_kn * 64u;                     // bytes between the k rows of consecutive steps (32 rows)
   const int last_S = (nsteps - 1) >> 1;
   constexpr unsigned OOB = 0x80000000u;                                // resources are smaller than 2 GiB (eligibility)
@@ -213,9 +221,16 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
   const int akey = ((fr >> 3) & 1) | ((fg & 1) << 1);
   const int arow = 8 * fg + (fr >> 2);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem;
-  uint32_t a_base[2];
+  // TN 384: two lane-constant bases (block parity) + the immediate (i >> 1) * 8192.  TN 192: block i is chunk 3 wc + i, i.e. quad (3 wc + i) >> 2,
+  // position (3 wc + i) & 3: one base per block.
+  constexpr int NAB = TN == 384 ? 2 : NCB;
+  uint32_t a_base[NAB];
 #pragma unroll
-  for (int e = 0; e < 2; ++e) a_base[e] = lds0 + (wc >> 1) * 4096 + arow * 128 + (((2 * (wc & 1) + e) ^ akey) << 5) + (fr & 3) * 8;
+  for (int e = 0; e < NAB; ++e) {
+    const int quad = TN == 384 ? (wc >> 1) : (3 * wc + e) >> 2;
+    const int pos = TN == 384 ? 2 * (wc & 1) + e : (3 * wc + e) & 3;
+    a_base[e] = lds0 + quad * 4096 + arow * 128 + ((pos ^ akey) << 5) + (fr & 3) * 8;
+  }
   // B fragment of pixel block j, K half h: row grp * 112 + 16 j + fr, logical slot 4 h + fg
   const uint32_t b_off = K::POFF + (grp * (NPB * 16) + fr) * 128 + ((fg ^ ((fr >> 1) & 7)) << 4);      // (without lds0: K half 1 is b_off ^ 64)
   static_assert(NCB % 3 == 0, "fa ring");
@@ -232,38 +247,30 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
   auto step = [&](auto h_tag, uint32_t wcur, uint32_t wnxt, uint32_t bnxt, int s, bool dma, uint32_t wdst, uint32_t pdst) {
     constexpr int H = decltype(h_tag)::value;
     const int S = s >> 1;
-    // this step's LDS-DMAs in issue order: pixel slots 2 H, 2 H + 1, then the three weight instructions
+    // this step's LDS-DMAs in issue order: pixel slots 2 H, 2 H + 1, then the weight instructions (the last slot of either only on waves 0..3)
     auto dma_k = [&](auto kc) {
       constexpr int k = decltype(kc)::value;
       if constexpr (k < HP) {
         constexpr int slot = HP * H + k;
         if constexpr (!(probe & 16)) { if (slot < K::PSLOTS - 1 || has_last) issue_p(slot, S + 2, pdst); }
       } else {
-        if constexpr (!(probe & 8)) issue_w(k - HP, s + 2, wdst);
+        constexpr int wi = k - HP;
+        if constexpr (!(probe & 8)) { if (wi < K::WSLOTS - K::WDEF || has_last) issue_w(wi, s + 2, wdst); }
       }
     };
-    constexpr int ND = HP + 3;                         // 5
+    constexpr int ND = HP + K::WSLOTS;                 // 5 / 4
     // blocks in which the early waves (0..3) and the late waves (4..7) issue instruction k
 #ifndef DC_PW224_PLAN
 #define DC_PW224_PLAN 0
 #endif
-#if DC_PW224_PLAN == 0
-    constexpr int EB[5] = {0, 0, 1, 1, 2}, LB[5] = {2, 3, 3, 4, 4};
-#elif DC_PW224_PLAN == 1
-    constexpr int EB[5] = {0, 1, 2, 3, 4}, LB[5] = {0, 1, 2, 3, 4};
-#elif DC_PW224_PLAN == 2
-    constexpr int EB[5] = {0, 0, 0, 1, 1}, LB[5] = {3, 3, 3, 4, 4};
-#elif DC_PW224_PLAN == 3
-    constexpr int EB[5] = {0, 0, 0, 0, 0}, LB[5] = {3, 3, 3, 3, 3};
-#elif DC_PW224_PLAN == 4
-    constexpr int EB[5] = {1, 1, 2, 2, 3}, LB[5] = {3, 4, 4, 5, 5};
-#else
-    constexpr int EB[5] = {0, 0, 1, 1, 2}, LB[5] = {0, 0, 1, 1, 2};
-#endif
-    static_assert(ND == 5, "issue plan");
+    constexpr int EB[5] = {0, 0, 1, 1, NCB == 6 ? 2 : 1}, LB[5] = {NCB == 6 ? 2 : 1, NCB == 6 ? 3 : 1, NCB == 6 ? 3 : 2, NCB == 6 ? 4 : 2, NCB == 6 ? 4 : 2};
+    static_assert(ND <= 5, "issue plan");
     static_for<0, NCB>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      if constexpr (i + 2 < NCB && !(probe & 2)) lds_read_tr<((i + 2) >> 1) * 8192>(fa[(i + 2) % 3], wcur + a_base[(i + 2) & 1] - lds0);   // two blocks ahead
+      if constexpr (i + 2 < NCB && !(probe & 2)) {      // two blocks ahead
+        if constexpr (TN == 384) lds_read_tr<((i + 2) >> 1) * 8192>(fa[(i + 2) % 3], wcur + a_base[(i + 2) & 1] - lds0);
+        else lds_read_tr<0>(fa[(i + 2) % 3], wcur + a_base[i + 2] - lds0);
+      }
       if (dma && !(probe & 1)) {
         static_for<0, ND>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
@@ -274,8 +281,10 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
       if constexpr (i == NCB - 1) {
         // stage end: W[s+1] (and with it everything older) has landed for this wave; this step's own instructions stay in flight
         if (dma && !(probe & 1)) {
-          constexpr int NW = (probe & 8) ? 0 : 3, NP = (probe & 16) ? 0 : HP;      // (probe builds that drop one operand's LDS-DMAs)
-          if (H == 0 || has_last || NP == 0) vm_lgkm0_wait<NW + NP>(); else vm_lgkm0_wait<NW + NP - 1>();
+          // (all but this step's own instructions: pixel slots + weight slots, one fewer of each kind where waves 4..7 own no last slot)
+          constexpr int NW = (probe & 8) ? 0 : K::WSLOTS, NP = (probe & 16) ? 0 : HP;      // (probe builds that drop one operand's LDS-DMAs)
+          constexpr int DW = (probe & 8) ? 0 : K::WDEF, DP = (probe & 16) || H == 0 ? 0 : 1;
+          if (has_last) vm_lgkm0_wait<NW + NP>(); else vm_lgkm0_wait<NW + NP - DW - DP>();
         } else {
           vm_lgkm0_wait<0>();
         }
@@ -311,10 +320,11 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
     for (int i = 0; i < K::PSLOTS; ++i)
       if (i < K::PSLOTS - 1 || has_last) issue_p(i, q, K::POFF + q * K::PSTG);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) issue_w(i, q, q * WSTG);
+    for (int i = 0; i < K::WSLOTS; ++i)
+      if (i < K::WSLOTS - K::WDEF || has_last) issue_w(i, q, q * WSTG);
   }
-  if (has_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + K::PSLOTS) : "memory");
-  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + K::PSLOTS - 1) : "memory");
+  if (has_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K::WSLOTS + K::PSLOTS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K::WSLOTS - K::WDEF + K::PSLOTS - 1) : "memory");
   __builtin_amdgcn_s_barrier();
   PW224_STAMP(1);
   lds_read_tr<0>(fa[0], a_base[0]);
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
   {
     int s = 0;
     // weight slots (byte offsets) of steps s, s + 1, s + 2; pixel slots (byte offsets inside the pixel ring) of stages S, S + 1, S + 2
-    uint32_t w0 = 0, w1 = WSTG, w2 = 2 * WSTG;
+    uint32_t w0 = 0, w1 = WSTG, w2 = 2 * WSTG;      // (WSTG = K::WSTG)
     uint32_t p0 = 0, p1 = K::PSTG, p2 = 2 * K::PSTG;
     typedef std::integral_constant<int, 0> H0;
     typedef std::integral_constant<int, 1> H1;
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
 #pragma unroll
   for (int pr = 0; pr < NCB / 2; ++pr) {
     const int i0 = 2 * pr;
-    const int cpair = ((wc >> 1) + 2 * pr) * 64 + (wc & 1) * 32;                   // first channel of the pair inside the tile
+    const int cpair = TN == 384 ? ((wc >> 1) + 2 * pr) * 64 + (wc & 1) * 32 : 48 * wc;   // first channel of the pair inside the tile
     const int chl = cpair + (odd ? 16 : 0) + (fg >> 1) * 8;                        // first of this lane's 8 channels after the trade
     const int ch0 = n0 + chl;
     const bool chok = ch0 < g.Cout;                                               // Cout is a multiple of 8: all or nothing
@@ -416,6 +426,75 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
       red[(grp * 2 + (fr >> 3)) * TN + chl + (fr & 7)] = mine;
     }
   }
+  if constexpr (NCB & 1) {
+    // TN 192: the wave's third block (16 channels) has no partner block.  Lanes l and l ^ 16 trade PIXEL blocks instead: the even-fg lane keeps 8
+    // consecutive channels of pixel block 2 jj, the odd-fg lane the same 8 channels of pixel block 2 jj + 1 (the last pixel block: even lanes only).
+    constexpr int i2 = NCB - 1;
+    const int chl = 48 * wc + 32 + (fg >> 1) * 8;
+    const int ch0 = n0 + chl;
+    const bool chok = ch0 < g.Cout;
+    float ba[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ca = n0 + 48 * wc + 32 + fg * 4 + r;
+        if (ca < g.Cout) ba[r] = p.bias[ca];
+      }
+    }
+    float st[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st[0][e] = st[1][e] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < (NPB + 1) / 2; ++jj) {
+      const int j0 = 2 * jj, j1 = 2 * jj + 1 < NPB ? 2 * jj + 1 : 2 * jj;       // (no partner pixel block: j1 repeats j0, the odd lanes store nothing)
+      const bool has1 = 2 * jj + 1 < NPB;
+      const uint32_t a0 = pack2_bf16(acc[i2][j0][0] + ba[0], acc[i2][j0][1] + ba[1]);
+      const uint32_t a1 = pack2_bf16(acc[i2][j0][2] + ba[2], acc[i2][j0][3] + ba[3]);
+      const uint32_t b0 = pack2_bf16(acc[i2][j1][0] + ba[0], acc[i2][j1][1] + ba[1]);
+      const uint32_t b1 = pack2_bf16(acc[i2][j1][2] + ba[2], acc[i2][j1][3] + ba[3]);
+      const uint32_t r0 = swap_rows16(odd ? a0 : b0), r1 = swap_rows16(odd ? a1 : b1);
+      vec16 v;
+      v.w[0] = odd ? r0 : a0;
+      v.w[1] = odd ? r1 : a1;
+      v.w[2] = odd ? b0 : r0;
+      v.w[3] = odd ? b1 : r1;
+      const int m = m0 + grp * (NPB * 16) + (odd ? j1 : j0) * 16 + fr;
+      if (m < p.M && chok && (!odd || has1)) {
+        bf16* dst = yg + (size_t)m * p.ldy + ch0;
+        float f[8];
+        unpack(v, f, bf16());
+        if (p.accumulate) {
+          float o[8];
+          unpack(ldg16(dst), o, bf16());
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += o[e];
+          pack(v, f, bf16());
+          unpack(v, f, bf16());
+        }
+        stg16(dst, v);
+        if (do_stats) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            st[0][e] += f[e];
+            st[1][e] = fmaf(f[e], f[e], st[1][e]);
+          }
+        }
+      }
+    }
+    if (do_stats) {
+      // the two lanes of a pair hold sums of the SAME 8 channels over different pixel blocks: add them, then sum over the 16 pixel lanes
+      float mine = 0.f;
+#pragma unroll
+      for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float both = st[w][e] + __uint_as_float(swap_rows16(__float_as_uint(st[w][e])));
+          const float t = row_sum16(both);
+          if (fr == w * 8 + e) mine = t;
+        }
+      if (!odd) red[(grp * 2 + (fr >> 3)) * TN + chl + (fr & 7)] = mine;
+    }
+  }
   if (do_stats) {
     __syncthreads();
     // one slab row per tile: the pixel groups folded in a fixed order; slab rows no tile owns (the slab has a row per 128 pixels) are zeros
@@ -448,11 +527,16 @@ bool pw224_eligible(const IgemmParams& p) {
          ((size_t)p.M + 224) * p.ldx * 2 < (1ull << 31) && ((size_t)g.Cin + 64) * p.ldw_kn * 2 < (1ull << 31);      // buffer resources < 2 GiB
 }
 
-int launch_pw224(const IgemmParams& p, hipStream_t st) {
-  typedef Cfg<2> C2;
-  auto k2 = &pw224_kernel<2>;
-  DC_ONCE({ (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, C2::RING); });
-  hipLaunchKernelGGL(k2, dim3((unsigned)pw224_tiles(p)), dim3(512), C2::RING, st, p);
+// tn: channels per tile, 384 or 192
+int launch_pw224(const IgemmParams& p, int tn, hipStream_t st) {
+  auto k384 = &pw224_kernel<384>;
+  auto k192 = &pw224_kernel<192>;
+  DC_ONCE({
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k384), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<384>::RING);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k192), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<192>::RING);
+  });
+  if (tn == 192) hipLaunchKernelGGL(k192, dim3((unsigned)pw224_tiles(p, 192)), dim3(512), Cfg<192>::RING, st, p);
+  else hipLaunchKernelGGL(k384, dim3((unsigned)pw224_tiles(p, 384)), dim3(512), Cfg<384>::RING, st, p);
   DC_CHECK_LAUNCH();
   return 0;
 }

@@ -7,10 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from mlperf_deepcam_amd import lib as L
 dev = torch.device("cuda", 0); dt = torch.bfloat16
 r64 = lambda c: (c + 63) // 64 * 64
-shapes = [(728, 728, 8, 48, 72), (728, 728, 4, 48, 72), (728, 1024, 8, 48, 72), (1024, 1536, 8, 24, 36), (1536, 1536, 8, 24, 36), (1536, 2048, 8, 24, 36),
+shapes = [(728, 728, 8, 48, 72), (728, 728, 4, 48, 72), (728, 728, 2, 48, 72), (728, 1024, 8, 48, 72), (728, 1024, 4, 48, 72), (1024, 1536, 8, 24, 36), (1536, 1536, 8, 24, 36), (1536, 2048, 8, 24, 36),
           (256, 728, 8, 96, 144), (728, 728, 8, 96, 144), (728, 728, 3, 47, 71)]
 if len(sys.argv) > 1 and sys.argv[1] == "small":
-    shapes = shapes[:2]
+    shapes = shapes[:3]
 lib = L.load()
 NSET = 6
 for (cin, cout, N, H, W) in shapes:
@@ -26,7 +26,7 @@ for (cin, cout, N, H, W) in shapes:
     slab = torch.zeros(2 * rows * cout, device=dev)
     outs, res = [], []
     # (label, options, entry point)
-    for label, opts, kn in (("planner w/o 384/224", {"pw384": 0, "pw224": 0}, False), ("256x384 K64", {"pw384": 4, "pw224": 0}, False), ("224x384 kn", {"pw384": 1, "pw224": 2}, True)):
+    for label, opts, kn in (("planner w/o 384/224", {"pw384": 0, "pw224": 0}, False), ("256x384 K64", {"pw384": 4, "pw224": 0}, False), ("224x384 kn", {"pw384": 1, "pw224": 2}, True), ("224x192 kn", {"pw384": 1, "pw224": 3}, True), ("planner", {"pw384": 1, "pw224": 1}, True)):
         for k, v in opts.items():
             L.call("dc_set_option", k.encode(), v)
         def once(i):

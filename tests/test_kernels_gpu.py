@@ -167,7 +167,8 @@ def test_conv_pointwise_384_tile_kernel_same_bits(shape):
 @pytest.mark.parametrize("shape", [(728, 728, 3, 19, 17), (728, 728, 2, 48, 72), (136, 392, 2, 21, 13), (1536, 776, 1, 24, 20), (128, 384, 1, 16, 14),
                                    (728, 728, 8, 48, 72)],
                          ids=["ragged969", "middle_flow_b2", "one_and_a_bit_tiles", "long_k_three_tiles", "four_steps_one_tile", "middle_flow_b8"])
-def test_conv_pointwise_224_tile_kernel_same_bits(shape):
+@pytest.mark.parametrize("tile", [2, 3], ids=["224x384", "224x192"])
+def test_conv_pointwise_224_tile_kernel_same_bits(shape, tile):
     """dc_conv_fwd_kn / dc_conv_dgrad_kn on the 224 x 384 kernel (csrc/igemm224.hip: weight stages from the [k][n] packing through transposing
     LDS reads, three-deep rings), forced on every eligible call, against the plain entry points without it: same MFMA instruction and K order,
     so outputs are bit-equal (forward, forward with bias in accumulate mode, data gradient through padded views); the BatchNorm slab keeps its
@@ -193,7 +194,7 @@ def test_conv_pointwise_224_tile_kernel_same_bits(shape):
     try:
         for kn in (False, True):
             L.call("dc_set_option", b"pw384", 0 if not kn else 1)
-            L.call("dc_set_option", b"pw224", 2 if kn else 0)
+            L.call("dc_set_option", b"pw224", tile if kn else 0)
             ybuf, yv = empty_nhwc(N, H, W, cout, dtype, ld=cout + 24, off=16)
             slab = torch.full((3, rows, cout), float("nan"), device=dev())       # [2]: a neighbour's rows, must stay NaN
             _, gxv = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
