@@ -119,9 +119,13 @@ int dc_conv_fwd(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int
  * take; its rows are [k][n] for the GEMM in question, so a pointwise layer's weight stages can be 32-deep slabs of whole L2 lines
  * (csrc/igemm224.hip: 224 x 384 tiles, three-deep operand rings).  Layers that kernel does not serve run exactly as through the plain entry
  * points.  Outputs are bit-identical to the plain calls; the BatchNorm partial sums come in another summation order (one slab row per
- * 224-pixel tile, the slab's other rows written as zeros: the slab keeps dc_conv_stat_rows rows). */
+ * 224-pixel tile; with slab_rows = 0 the slab keeps dc_conv_stat_rows rows, the other rows written as zeros). */
 int dc_conv_fwd_kn(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf, const void* wb,
-                   const float* bias, void* y, int ldy, float* stat_slab, int accumulate, void* stream);
+                   const float* bias, void* y, int ldy, float* stat_slab, int slab_rows, int accumulate, void* stream);
+/* Rows of the slab dc_conv_fwd_kn writes when slab_rows carries this value: one per 224-pixel tile where igemm224.hip serves the layer
+ * (fewer, and none of them zeros), dc_conv_stat_rows elsewhere.  slab_rows = 0: the dc_conv_stat_rows layout whatever kernel runs.  The call
+ * fails if slab_rows is not what the launch writes (the planner's answer changed between the query and the call). */
+int dc_conv_stat_rows_kn(const dc_conv_desc* d, int N, int Hi, int Wi);
 int dc_conv_dgrad_kn(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb, const void* wf,
                      void* dx, int lddx, int accumulate, void* stream);
 

@@ -599,7 +599,7 @@ static int check_view(const void* ptr, int ld, int c, int dtype, const char* wha
 
 static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int Wi, const void* in, int ldin,
                       const void* w, const float* bias, void* out, int ldout, float* slab, int accumulate,
-                      void* stream, bool out32 = false, const BnBwdEpi* bst = nullptr, const void* w_kn = nullptr) {
+                      void* stream, bool out32 = false, const BnBwdEpi* bst = nullptr, const void* w_kn = nullptr, int slab_rows = 0) {
   DC_REQUIRE(d != nullptr, "dc_conv: null descriptor");
   DC_REQUIRE(d->dtype == DC_F32 || d->dtype == DC_BF16, "dc_conv: bad dtype");
   DC_REQUIRE(d->transposed || d->k == 1 || d->k == 3, "dc_conv: kernel size must be 1 or 3");
@@ -644,8 +644,21 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   if (bst == nullptr && g_thin_fwd && thin_fwd_eligible(p.g, d->dtype, bias != nullptr, accumulate, out32))
     return launch_thin_fwd(p.g, N, in, ldin, w, p.ldw, out, ldout, slab, p.mtiles * p.g.os * p.g.os, st);
   if (d->dtype == DC_BF16 && !out32 && bst == nullptr) {      // (the BatchNorm-backward epilogue lives in the LDS-epilogue kernels)
-    if (const int npb = pw384_plan(p)) return npb == 192 ? launch_pw192(p, st) : npb == 224 ? launch_pw224(p, 384, st) : npb == 226 ? launch_pw224(p, 192, st) : launch_pw384(p, npb, st);
+    if (const int npb = pw384_plan(p)) {
+      if (npb == 224 || npb == 226) {
+        // the 224-pixel tiles leave ONE slab row per tile: a caller that sized its slab by dc_conv_stat_rows_kn gets exactly those rows (no
+        // zero rows behind them); any larger slab is padded with zero rows
+        if (slab != nullptr && slab_rows > 0) {
+          DC_REQUIRE(slab_rows >= cdiv(p.M, 224), "dc_conv_fwd_kn: slab_rows is smaller than the rows this launch writes (dc_conv_stat_rows_kn)");
+          p.mtiles = slab_rows;
+        }
+        return launch_pw224(p, npb == 224 ? 384 : 192, st);
+      }
+      DC_REQUIRE(slab == nullptr || slab_rows <= 0 || slab_rows == p.mtiles, "dc_conv_fwd_kn: slab_rows is not what this launch writes now (dc_conv_stat_rows_kn)");
+      return npb == 192 ? launch_pw192(p, st) : launch_pw384(p, npb, st);
+    }
   }
+  DC_REQUIRE(slab == nullptr || slab_rows <= 0 || slab_rows == p.mtiles * p.g.os * p.g.os, "dc_conv_fwd_kn: slab_rows is not what this launch writes now (dc_conv_stat_rows_kn)");
   if (d->dtype == DC_BF16 && !out32 && g_igemm256 != 0) {
     if (g_igemm256 == 2 || igemm256_wins(p)) {
       // several rounds of tiles: the persistent form keeps the operand ring full across tiles (igemm256p.hip)
@@ -1022,8 +1035,29 @@ extern "C" int dc_conv_fwd(const dc_conv_desc* d, int N, int Hi, int Wi, const v
 // data gradient: wf), whose rows are [k][n].  Pointwise layers may then run on the 224 x 384 tile kernel (igemm224.hip), which streams its weight
 // stages from w_kn; every other layer ignores it.  Same results as the plain entry points, bit for bit (BatchNorm sums: another summation order).
 extern "C" int dc_conv_fwd_kn(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, int ldx, const void* wf, const void* wb,
-                              const float* bias, void* y, int ldy, float* stat_slab, int accumulate, void* stream) {
-  return run_gather(d, kFwd, N, Hi, Wi, x, ldx, wf, bias, y, ldy, stat_slab, accumulate, stream, false, nullptr, wb);
+                              const float* bias, void* y, int ldy, float* stat_slab, int slab_rows, int accumulate, void* stream) {
+  return run_gather(d, kFwd, N, Hi, Wi, x, ldx, wf, bias, y, ldy, stat_slab, accumulate, stream, false, nullptr, wb, slab_rows);
+}
+// Rows of the slab dc_conv_fwd_kn writes for this layer when it is handed both weight images: one per 224-pixel tile where the planner gives
+// the layer to igemm224.hip (27 648 pixels: 124 rows instead of the 216 of dc_conv_stat_rows; 13 824 pixels: 62, short enough for the kernels
+// that run the BatchNorm finalize themselves), dc_conv_stat_rows everywhere else.  Pass the value as slab_rows.
+extern "C" int dc_conv_stat_rows_kn(const dc_conv_desc* d, int N, int Hi, int Wi) {
+  const int plain = dc_conv_stat_rows(d, N, Hi, Wi);
+  if (plain <= 0 || d->dtype != DC_BF16) return plain;
+  IgemmParams p;
+  if (!build_geom(*d, Hi, Wi, kFwd, &p.g)) return plain;
+  const long M = (long)N * p.g.Qh * p.g.Qw;
+  if (M >= (1L << 31) - BM) return plain;
+  p.x = nullptr; p.w = nullptr; p.y = nullptr; p.bias = nullptr; p.slab = nullptr;
+  p.N = N; p.ldx = weight_ld(p.g.Cin); p.ldy = weight_ld(p.g.Cout); p.ldw = weight_ld(p.g.Cin);
+  alignas(16) static const char some_image[16] = {0};
+  p.w_kn = some_image;                       // (any 16-byte aligned non-null pointer: eligibility only looks at it)
+  p.ldw_kn = weight_ld(p.g.Cout);
+  p.M = (int)M; p.m_beg = 0; p.phase_fast = 0; p.zero_page = nullptr; p.ngroup = 0; p.ksplit = 0; p.kslab = nullptr; p.zfill = 0;
+  p.bst = BnBwdEpi{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
+  p.mtiles = cdiv(M, BM); p.accumulate = 0;
+  const int npb = pw384_plan(p);
+  return (npb == 224 || npb == 226) ? cdiv(M, 224) : plain;
 }
 extern "C" int dc_conv_dgrad_kn(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb, const void* wf,
                                 void* dx, int lddx, int accumulate, void* stream) {

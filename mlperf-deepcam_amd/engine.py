@@ -352,7 +352,10 @@ class Engine:
         L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
         wf = torch.empty(nwf.value, dtype=tdtype, device=self.device)
         wb = torch.empty(nwb.value, dtype=tdtype, device=self.device) if need_dx else None
-        rows = lib.dc_conv_stat_rows(C.byref(d), x.N, x.H, x.W) if stats else 0
+        # (a pointwise layer that hands the library both weight images gets the 224-pixel tiles' compact slab: one row per tile, no zero rows --
+        # at local batch 4 that is 62 rows, short enough for the kernels that run the BatchNorm finalize themselves)
+        both = self.conv_kn and k == 1 and stride == 1 and not transposed and not f32 and need_dx and dt == L.DC_BF16
+        rows = (lib.dc_conv_stat_rows_kn if both else lib.dc_conv_stat_rows)(C.byref(d), x.N, x.H, x.W) if stats else 0
         slab = self._f32(2 * rows * cout) if stats else None
         y.pw_fuse = None
         if (bn_fuse and self.fuse_pw_bn_bwd and k == 1 and stride == 1 and not transposed and bias is None and not f32 and need_dx
@@ -373,12 +376,12 @@ class Engine:
 
         # a pointwise layer hands the library BOTH packed images: the 224 x 384 tile kernel streams its weight stages from the [k][n] one
         # (csrc/igemm224.hip; dc_conv_fwd_kn / dc_conv_dgrad_kn fall back to the plain path for every shape it does not serve)
-        both = self.conv_kn and k == 1 and stride == 1 and not transposed and not f32 and wb is not None and dt == L.DC_BF16
+        assert both == (self.conv_kn and k == 1 and stride == 1 and not transposed and not f32 and wb is not None and dt == L.DC_BF16)
 
         def fwd(train: bool):
             if both:
                 L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, x.ptr, x.ld, L.dptr(wf), L.dptr(wb), pb, y.ptr, y.ld,
-                       L.dptr(slab) if train else None, 0, self._st())
+                       L.dptr(slab) if train else None, rows, 0, self._st())
             else:
                 L.call("dc_conv_fwd", C.byref(d), N, H, W, x.ptr, x.ld, L.dptr(wf), pb, y.ptr, y.ld,
                        L.dptr(slab) if train else None, 0, self._st())

@@ -65,7 +65,8 @@ _SIGS = {
     "dc_pack_all": (I, [I, P, I, P]),
     "dc_conv_stat_rows": (I, [CD, I, I, I]),
     "dc_conv_fwd": (I, [CD, I, I, I, P, I, P, P, P, I, P, I, P]),
-    "dc_conv_fwd_kn": (I, [CD, I, I, I, P, I, P, P, P, P, I, P, I, P]),
+    "dc_conv_fwd_kn": (I, [CD, I, I, I, P, I, P, P, P, P, I, P, I, I, P]),
+    "dc_conv_stat_rows_kn": (I, [CD, I, I, I]),
     "dc_conv_dgrad_kn": (I, [CD, I, I, I, P, I, P, P, P, I, I, P]),
     "dc_conv_fwd_f32out": (I, [CD, I, I, I, P, I, P, P, I, P]),
     "dc_conv_fwd_dilated_group": (I, [CD, I, I, I, I, P, P, I, P, P, I, P, P]),

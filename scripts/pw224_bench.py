@@ -32,7 +32,7 @@ for (cin, cout, N, H, W) in shapes:
         def once(i):
             x, y = xs[i % NSET], ys[i % NSET]
             if kn:
-                L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, L.dptr(x), r64(cin), L.dptr(wf), L.dptr(wb), None, L.dptr(y), r64(cout), L.dptr(slab), 0, L.stream_ptr())
+                L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, L.dptr(x), r64(cin), L.dptr(wf), L.dptr(wb), None, L.dptr(y), r64(cout), L.dptr(slab), 0, 0, L.stream_ptr())
             else:
                 L.call("dc_conv_fwd", C.byref(d), N, H, W, L.dptr(x), r64(cin), L.dptr(wf), None, L.dptr(y), r64(cout), L.dptr(slab), 0, L.stream_ptr())
         t = []

@@ -22,7 +22,7 @@ for (cin, cout, N, H, W) in [(728, 728, 8, 48, 72), (728, 728, 8, 96, 144), (153
     rows = lib.dc_conv_stat_rows(C.byref(d), N, H, W)
     slab = torch.zeros(2 * rows * cout, device=dev)
     for i in range(12):
-        L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, L.dptr(xs[i % NSET]), r64(cin), L.dptr(wf), L.dptr(wb), None, L.dptr(ys[i % NSET]), r64(cout), L.dptr(slab), 0, L.stream_ptr())
+        L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, L.dptr(xs[i % NSET]), r64(cin), L.dptr(wf), L.dptr(wb), None, L.dptr(ys[i % NSET]), r64(cout), L.dptr(slab), 0, 0, L.stream_ptr())
     torch.cuda.synchronize()
     tiles = ((cout + 383) // 384) * ((N * H * W + 223) // 224)
     nb = min(tiles, 1024)

@@ -171,9 +171,9 @@ def test_conv_pointwise_384_tile_kernel_same_bits(shape):
 def test_conv_pointwise_224_tile_kernel_same_bits(shape, tile):
     """dc_conv_fwd_kn / dc_conv_dgrad_kn on the 224 x 384 kernel (csrc/igemm224.hip: weight stages from the [k][n] packing through transposing
     LDS reads, three-deep rings), forced on every eligible call, against the plain entry points without it: same MFMA instruction and K order,
-    so outputs are bit-equal (forward, forward with bias in accumulate mode, data gradient through padded views); the BatchNorm slab keeps its
-    dc_conv_stat_rows rows (one per tile filled, the rest zeros) and its column sums agree up to the order of the additions; pad channels and
-    the slab rows of other layers stay untouched.  Shapes: ragged pixel / channel / K tiles, Cin = 128 (the shortest K loop: four steps, the
+    so outputs are bit-equal (forward, forward with bias in accumulate mode, data gradient through padded views); the BatchNorm slab is the
+    compact one of dc_conv_stat_rows_kn (one row per tile) or, with slab_rows = 0, the dc_conv_stat_rows layout with zero rows behind the tiles'
+    own; its column sums agree up to the order of the additions; pad channels and the slab rows of other layers stay untouched.  Shapes: ragged pixel / channel / K tiles, Cin = 128 (the shortest K loop: four steps, the
     prologue's stages and the no-issue tail meet), three channel tiles, the middle flow at local batch 2 and 8."""
     cin, cout, N, H, W = shape
     dtype = torch.bfloat16
@@ -190,19 +190,31 @@ def test_conv_pointwise_224_tile_kernel_same_bits(shape, tile):
     _, xv = to_nhwc(x, dtype, ld=cin + 16, off=8)
     _, gyv = to_nhwc(gy, dtype)
     rows = L.load().dc_conv_stat_rows(C.byref(d), N, H, W)
+    M = N * H * W
+    ntm = (M + 223) // 224
     got = []
     try:
         for kn in (False, True):
             L.call("dc_set_option", b"pw384", 0 if not kn else 1)
             L.call("dc_set_option", b"pw224", tile if kn else 0)
+            # the compact slab of the 224-pixel tiles: one row per tile (dc_conv_stat_rows_kn under the forced planner), none of them zeros
+            krows = L.load().dc_conv_stat_rows_kn(C.byref(d), N, H, W) if kn else rows
+            assert krows == (ntm if kn else rows)
             ybuf, yv = empty_nhwc(N, H, W, cout, dtype, ld=cout + 24, off=16)
-            slab = torch.full((3, rows, cout), float("nan"), device=dev())       # [2]: a neighbour's rows, must stay NaN
+            slab = torch.full((3 * krows, cout), float("nan"), device=dev())     # [2 * krows ..]: a neighbour's rows, must stay NaN
             _, gxv = empty_nhwc(N, H, W, cin, dtype, ld=cin + 8, off=0)
             if kn:
-                L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), vptr(wb), None, vptr(yv), cout + 24, vptr(slab), 0, S())
+                L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), vptr(wb), None, vptr(yv), cout + 24, vptr(slab), krows, 0, S())
                 y0 = from_nhwc(yv).clone()
-                L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), vptr(wb), vptr(bias), vptr(yv), cout + 24, None, 1, S())
+                L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), vptr(wb), vptr(bias), vptr(yv), cout + 24, None, 0, 1, S())
                 L.call("dc_conv_dgrad_kn", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(wf), vptr(gxv), cin + 8, 0, S())
+                # slab_rows = 0: the dc_conv_stat_rows layout, zero rows behind the tiles' own
+                wide = torch.full((2, rows, cout), float("nan"), device=dev())
+                _, y2 = empty_nhwc(N, H, W, cout, dtype)
+                L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), vptr(wb), None, vptr(y2), cout, vptr(wide), 0, 0, S())
+                # a slab shorter than the launch writes is refused
+                with pytest.raises(L.DeepcamHipError):
+                    L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), vptr(wb), None, vptr(y2), cout, vptr(wide), ntm - 1, 0, S()) if ntm > 1 else L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin + 16, None, vptr(wb), None, vptr(y2), cout, vptr(wide), 0, 0, S())
             else:
                 L.call("dc_conv_fwd", C.byref(d), N, H, W, vptr(xv), cin + 16, vptr(wf), None, vptr(yv), cout + 24, vptr(slab), 0, S())
                 y0 = from_nhwc(yv).clone()
@@ -210,17 +222,19 @@ def test_conv_pointwise_224_tile_kernel_same_bits(shape, tile):
                 L.call("dc_conv_dgrad", C.byref(d), N, H, W, vptr(gyv), cout, vptr(wb), vptr(gxv), cin + 8, 0, S())
             torch.cuda.synchronize()
             assert torch.isnan(ybuf[..., :16].float()).all() and torch.isnan(ybuf[..., 16 + cout:].float()).all()
-            assert torch.isnan(slab[2]).all() and not torch.isnan(slab[:2]).any()
-            got.append((y0, from_nhwc(yv), slab[:2].cpu(), from_nhwc(gxv)))
+            assert torch.isnan(slab[2 * krows:]).all() and not torch.isnan(slab[:2 * krows]).any()
+            got.append((y0, from_nhwc(yv), slab[:2 * krows].view(2, krows, cout).cpu(), from_nhwc(gxv)))
+            if kn:
+                assert torch.equal(from_nhwc(y2), y0)
+                w_ = wide.cpu()
+                assert (w_[:, ntm:] == 0).all() and torch.equal(w_[:, :ntm], got[-1][2])
     finally:
         L.call("dc_set_option", b"pw384", 1)
         L.call("dc_set_option", b"pw224", 1)
     assert_close(got[0][0], F.conv2d(x, q(w, dtype)), dtype)
     assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1]) and torch.equal(got[0][3], got[1][3])
-    M = N * H * W
-    ntm = (M + 223) // 224
     slab = got[1][2]
-    assert (slab[:, ntm:] == 0).all() and (slab[1, :ntm] > 0).all()                 # one row per tile, zeros behind them
+    assert slab.shape[1] == ntm and (slab[1] > 0).all()                              # one row per tile
     np.testing.assert_allclose(got[0][2].double().sum(1).numpy(), slab.double().sum(1).numpy(), rtol=2e-5, atol=1e-3)
 
 
