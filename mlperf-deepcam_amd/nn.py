@@ -135,13 +135,16 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         eng = ctx.eng
-        if eng.grads_live[0] and not getattr(ctx.module, "_warned_no_accumulation", False):
-            # the reference's loop calls optimizer.zero_grad() before every backward (train_hdf5_ddp.py:358-364); a caller that relies on
-            # p.grad accumulating over several backward calls would silently train on the LAST micro-batch only
-            import warnings
-            warnings.warn("loss.backward() was called again without optimizer.zero_grad() / step() in between: this engine OVERWRITES the "
-                          "gradients (every backward writes each parameter's gradient exactly once), it does not accumulate them", RuntimeWarning)
-            ctx.module._warned_no_accumulation = True
+        # torch semantics: a backward() that arrives without an optimizer.zero_grad() / step() since the previous one ACCUMULATES into p.grad.
+        # The engine's backward program writes every parameter's gradient exactly once (it overwrites), so the gradients of the earlier
+        # backward calls are set aside first and added back behind this one -- a 226 MB copy and add on the micro-batch path only; the
+        # reference's loop (zero_grad before every backward, train_hdf5_ddp.py:358-364) never takes it.
+        stash = None
+        if eng.grads_live[0]:
+            if getattr(ctx.module, "_grad_stash", None) is None:      # (one per module: its engines share the arena)
+                ctx.module._grad_stash = torch.empty_like(eng.grads)
+            stash = ctx.module._grad_stash
+            stash.copy_(eng.grads)
         eng.grads_live[0] = True
         _ops.OPS.net_backward(dlogits, _ops.engine_handle(eng))
         red = ctx.module._ddp_reducer
@@ -151,6 +154,8 @@ class _NetFn(torch.autograd.Function):
             # has taken over averages inside the optimizer kernel: finish(average=True) refuses (the gradients would otherwise be
             # scaled twice, or -- had the reference been dropped -- the buckets launched by this backward would never be waited for)
             red.finish(average=True)
+        if stash is not None:
+            eng.grads.add_(stash)
         ctx.module._attach_grads()
         return None, None, None
 
@@ -309,8 +314,9 @@ class ArenaOptimizer:
         self.state = {}
 
     def zero_grad(self, set_to_none: bool = True):
-        # every backward overwrites the whole gradient arena (each parameter exactly once): nothing to clear.  (Gradient ACCUMULATION over
-        # several backward calls is not supported: _NetFn.backward warns when a second backward arrives without a zero_grad() / step().)
+        # every backward overwrites the whole gradient arena (each parameter exactly once): nothing to clear.  What this call does is end the
+        # accumulation window: a backward() behind it starts from its own gradients, one that arrives WITHOUT it adds to the previous ones
+        # (_NetFn.backward)
         self.engine.grads_live[0] = False
         return None
 

@@ -51,6 +51,13 @@ def test_host_side_geometry_without_gpu():
     d = L.ConvDesc(L.DC_BF16, 1, 1, 0, 1, 0, 728, 728)
     assert lib.dc_conv_wgrad_workspace(C.byref(d), 2, 48, 72) >= 728 * 728 * 4
     assert lib.dc_conv_stat_rows(C.byref(d), 2, 48, 72) == 54
+    # the compact slab of the 224-pixel tiles (a host-side plan, no device needed): one row per tile where igemm224.hip serves the layer --
+    # 224 x 384 tiles at local batch 8, 224 x 192 at 4 --, the 128-pixel rows where another kernel does (local batch 2: 128 x 192 tiles)
+    assert lib.dc_conv_stat_rows_kn(C.byref(d), 8, 48, 72) == 124 and lib.dc_conv_stat_rows(C.byref(d), 8, 48, 72) == 216
+    assert lib.dc_conv_stat_rows_kn(C.byref(d), 4, 48, 72) == 62
+    assert lib.dc_conv_stat_rows_kn(C.byref(d), 2, 48, 72) == 54
+    d32 = L.ConvDesc(L.DC_F32, 1, 1, 0, 1, 0, 728, 728)
+    assert lib.dc_conv_stat_rows_kn(C.byref(d32), 8, 48, 72) == 216
     # a failed call leaves a message behind
     d = L.ConvDesc(L.DC_BF16, 1, 2, 0, 1, 0, 64, 64)
     assert lib.dc_conv_stat_rows(C.byref(d), 1, 5, 5) == 1

@@ -348,28 +348,45 @@ def test_program_slots_and_errors():
         bad.run()
 
 
-def test_second_backward_without_zero_grad_warns():
-    """The engine overwrites gradients, it never accumulates them (INTEGRATION level 1): a loss.backward() that arrives without
-    an optimizer.zero_grad() / step() since the previous one says so (once per module) instead of silently training on the last micro-batch."""
-    import warnings
+def test_backward_without_zero_grad_accumulates():
+    """torch semantics through the module surface: a loss.backward() that arrives without an optimizer.zero_grad() /
+    step() since the previous one ADDS to p.grad (the engine's backward overwrites, so the earlier gradients are set aside and added back);
+    zero_grad() or step() ends the window.  Checked on two micro-batches: grad after (backward A, backward B) == grad A + grad B, the same
+    after a zero_grad() in between is grad B alone, and the reference's own order is unaffected."""
     B, H, W = 2, 64, 96
-    x, y = make_inputs(B, H, W)
     dev = torch.device("cuda", 0)
-    net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=torch.bfloat16, seed=333)
+    xa, ya = make_inputs(B, H, W)
+    xb = torch.flip(xa, dims=(0,)) * 0.5 + 0.25
+    yb = torch.flip(ya, dims=(0,))
+    net = dnn.DeepLabv3_plus(16, 3, os=16, _print=False, dtype=torch.float32, seed=333)
     net.materialize(B, H, W)
     net.train()
     opt = dnn.make_optimizer("AdamW", net, 1e-3, 1e-8, 1e-2)
     cw = olm.class_weights(-0.125)
-    with warnings.catch_warnings(record=True) as rec:
-        warnings.simplefilter("always")
-        for _ in range(2):                               # the reference's order: no warning
+
+    def grad_of(x, y, zero):
+        if zero:
             opt.zero_grad()
-            dnn.fp_loss(net(x.to(dev)), y.to(dev), cw).backward()
-            opt.step()
-        assert not [w for w in rec if "does not accumulate" in str(w.message)]
         dnn.fp_loss(net(x.to(dev)), y.to(dev), cw).backward()
-        dnn.fp_loss(net(x.to(dev)), y.to(dev), cw).backward()      # a second backward in the same window
-        assert len([w for w in rec if "does not accumulate" in str(w.message)]) == 1
+        torch.cuda.synchronize()
+        return net.engine.grads.clone()
+
+    ga = grad_of(xa, ya, True)
+    gb = grad_of(xb, yb, True)
+    assert not torch.equal(ga, gb)
+    g1 = grad_of(xa, ya, True)
+    gab = grad_of(xb, yb, False)                 # no zero_grad: accumulates
+    assert torch.equal(g1, ga)
+    # (BatchNorm running statistics move between the calls, the batch statistics that enter the gradient do not: same bits)
+    torch.testing.assert_close(gab, ga + gb, rtol=0, atol=0)
+    gabb = grad_of(xb, yb, False)                # a third micro-batch in the same window
+    torch.testing.assert_close(gabb, (ga + gb) + gb, rtol=0, atol=0)
+    assert torch.equal(grad_of(xb, yb, True), gb)      # zero_grad ends the window
+    p = dict(net.named_parameters())["upsample.last_deconv.0.weight"]
+    assert p.grad is not None and torch.equal(p.grad.flatten(), net.engine.grad_view("upsample.last_deconv.0.weight").flatten())
+    opt.step()
+    after_step = grad_of(xa, ya, False)                # ... and so does step(): the first backward behind it stands alone
+    assert torch.equal(after_step, grad_of(xa, ya, True)) and not torch.equal(after_step, ga)
 
 
 def test_steps_enqueued_ahead_match_synchronised_steps():
