@@ -126,6 +126,13 @@ int dc_conv_fwd_kn(const dc_conv_desc* d, int N, int Hi, int Wi, const void* x, 
  * (fewer, and none of them zeros), dc_conv_stat_rows elsewhere.  slab_rows = 0: the dc_conv_stat_rows layout whatever kernel runs.  The call
  * fails if slab_rows is not what the launch writes (the planner's answer changed between the query and the call). */
 int dc_conv_stat_rows_kn(const dc_conv_desc* d, int N, int Hi, int Wi);
+/* 1 where dc_conv_fwd_kn takes slab_rows = -1 for this layer (the pointwise tile kernels igemm224.hip and igemm192.hip): stat_slab is then a SUM ROW -- double[2][Cout] (sum, sum of squares), zeroed by
+ * the caller -- that every tile of the launch adds its channel sums to with fp64 atomics, instead of one fp32 row per tile.  (The addends
+ * are the fp32 sums a row slab would hold; their fp64 sum is exact, hence independent of the arrival order and equal to what dc_bn_finalize
+ * computes from the rows.)  dc_bn_finalize, dc_bn_apply_fin and dc_dwconv_fwd_fin take such a slab with rows = -1: two numbers per channel to
+ * read, so the consumer of the coefficients runs the finalize itself at any tensor size and the finalize launch leaves the dependent chain
+ * (nn.BatchNorm2d in training mode behind every pointwise conv of the middle flow, deeplab_xception.py:62-66,104-119). */
+int dc_conv_sum_row_kn(const dc_conv_desc* d, int N, int Hi, int Wi);
 int dc_conv_dgrad_kn(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb, const void* wf,
                      void* dx, int lddx, int accumulate, void* stream);
 
@@ -273,6 +280,19 @@ int dc_dwconv_dgrad_wgrad_bnres(int dtype, int C, int stride, int dil, int N, in
                                 const float* w_packed, const void* addend, int ldadd, void* dx, int lddx, const void* x, int ldx,
                                 float* wslab, const void* ybn, int ldybn, const float* save_mean, const float* save_invstd, int relu,
                                 float* slab, void* stream);
+/* The two data gradients above that take BatchNorm sums, with the sums added to a SUM ROW (see dc_conv_sum_row_kn): `slab` is double[2][C]
+ * (sum g, sum g*xhat), zeroed by the caller; every workgroup of the persistent kernel adds its two sums per channel with fp64 atomics (exact,
+ * hence the bits of the row slab's column sums in any arrival order).  dc_bn_bwd_finalize and dc_bn_bwd_apply_fin take the row with rows = -1,
+ * so the BatchNorm-backward apply runs the finalize itself at any tensor size.  dc_dwconv_dgrad_sum_row_ok: 1 where both are served. */
+int dc_dwconv_dgrad_sum_row_ok(int dtype, int C, int stride, int dil, int N, int Hi, int Wi);
+int dc_dwconv_dgrad_bnstats_wgrad_sum(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                      const float* w_packed, void* dx, int lddx, const void* ybn, int ldybn, const float* save_mean,
+                                      const float* save_invstd, const float* mscale, const float* mshift, int relu, float* slab,
+                                      float* wslab, void* stream);
+int dc_dwconv_dgrad_wgrad_bnres_sum(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                    const float* w_packed, const void* addend, int ldadd, void* dx, int lddx, const void* x, int ldx,
+                                    float* wslab, const void* ybn, int ldybn, const float* save_mean, const float* save_invstd, int relu,
+                                    float* slab, void* stream);
 int dc_dwconv_wgrad_reduce(int C, int rows, const float* wslab, float* grad_w, void* stream);
 size_t dc_dwconv_wgrad_workspace(int C, int N, int Hi, int Wi, int stride);
 int dc_dwconv_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* x, int ldx,

@@ -290,8 +290,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, const float
                                                               float* dbeta) {
   __shared__ double red[2][FIN_RL][FIN_CH];
   const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
-  double s, q;
-  slab_colsum2(SlabLoad{slab, slab + (size_t)rows * C, C, c, parts}, parts ? parts : rows, c < C, red, s, q, slab_is_short(rows, parts));
+  double s = 0.0, q = 0.0;
+  if (rows == SUM_ROW) {
+    if (c < C) sum_row_load(slab, C, c, s, q);
+  } else {
+    slab_colsum2(SlabLoad{slab, slab + (size_t)rows * C, C, c, parts}, parts ? parts : rows, c < C, red, s, q, slab_is_short(rows, parts));
+  }
   if (threadIdx.x >= FIN_CH || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
@@ -484,9 +488,10 @@ extern "C" int dc_colsum(int dtype, long M, int C, const void* dy, int lddy, flo
 extern "C" int dc_bn_finalize(int C, long count, float* slab, int rows, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                               float eps, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
-  DC_REQUIRE(C > 0 && rows > 0 && slab && gamma && beta && scale && shift, "dc_bn_finalize: bad argument");
+  DC_REQUIRE(C > 0 && (rows > 0 || rows == SUM_ROW) && slab && gamma && beta && scale && shift, "dc_bn_finalize: bad argument");
+  DC_REQUIRE(rows != SUM_ROW || ((uintptr_t)slab & 7) == 0, "dc_bn_finalize: a sum row is double[2][C]");
   if (count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
-  const int parts = fold_large_slab(slab, rows, C, (hipStream_t)stream);
+  const int parts = rows == SUM_ROW ? 0 : fold_large_slab(slab, rows, C, (hipStream_t)stream);
   const BnFinArgs a = bn_fin_args(C, count, slab, rows, parts, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
                                   shift, save_mean, save_invstd);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, (hipStream_t)stream, a);
@@ -557,13 +562,13 @@ extern "C" int dc_bn_apply_fin(int dtype, long M, int C, long count, const void*
                                const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                                float eps, float* scale, float* shift, float* save_mean, float* save_invstd, const void* residual, int ldr,
                                int relu, void* out, int ldo, void* stream) {
-  DC_REQUIRE(C > 0 && slab && gamma && beta && scale && shift && rows > 0 && rows <= FIN_RL,
-             "dc_bn_apply_fin: needs a slab of at most dc_bn_bwd_apply_fin_max_rows() rows");
+  DC_REQUIRE(C > 0 && slab && gamma && beta && scale && shift && ((rows > 0 && rows <= FIN_RL) || rows == SUM_ROW),
+             "dc_bn_apply_fin: needs a slab of at most dc_bn_bwd_apply_fin_max_rows() rows, or a sum row (rows = -1)");
   DC_REQUIRE(((uintptr_t)slab & 15) == 0 && C % 4 == 0, "dc_bn_apply_fin: the slab is read with 16-byte loads (16-byte aligned, C a multiple of 4)");
   if (count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
   const BnFinArgs a = bn_fin_args(C, count, slab, rows, 0, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
                                   shift, save_mean, save_invstd);
-  return bn_apply_impl(dtype, M, C, y, ldy, scale, shift, residual, ldr, relu, out, ldo, stream, &a, g_bn_fin_mul_f * g_bn_rows);
+  return bn_apply_impl(dtype, M, C, y, ldy, scale, shift, residual, ldr, relu, out, ldo, stream, &a, (rows == SUM_ROW ? 1 : g_bn_fin_mul_f) * g_bn_rows);
 }
 
 extern "C" int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int lddo, const void* y, int ldy,
@@ -581,8 +586,9 @@ extern "C" int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int 
 }
 
 extern "C" int dc_bn_bwd_finalize(int C, float* slab, int rows, float* dgamma, float* dbeta, void* stream) {
-  DC_REQUIRE(C > 0 && rows > 0 && slab && dgamma && dbeta, "dc_bn_bwd_finalize: bad argument");
-  const int parts = fold_large_slab(slab, rows, C, (hipStream_t)stream);
+  DC_REQUIRE(C > 0 && (rows > 0 || rows == SUM_ROW) && slab && dgamma && dbeta, "dc_bn_bwd_finalize: bad argument");
+  DC_REQUIRE(rows != SUM_ROW || ((uintptr_t)slab & 7) == 0, "dc_bn_bwd_finalize: a sum row is double[2][C]");
+  const int parts = rows == SUM_ROW ? 0 : fold_large_slab(slab, rows, C, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(256), 0, (hipStream_t)stream, C, (const float*)slab, rows, parts, dgamma, dbeta);
   DC_CHECK_LAUNCH();
   return 0;
@@ -606,7 +612,7 @@ static int bn_bwd_apply_impl(int dtype, long M, int C, long count, const void* d
   const int kpv = dtype == DC_BF16 ? 8 : 4;
   // a block as narrow as the tensor (see narrow_cg); the rows per block grow with the row lanes so that every thread has its four rows
   const int cgw = narrow_cg(C / kpv, g_bn_cgw);
-  int APPLY_ROWS = g_bn_rows * (fin_slab != nullptr ? g_bn_fin_mul_b : 1) * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
+  int APPLY_ROWS = g_bn_rows * (fin_slab != nullptr && fin_rows != SUM_ROW ? g_bn_fin_mul_b : 1) * (g_bn_cgw > cgw ? g_bn_cgw / cgw : 1);
   while (cdiv(M, APPLY_ROWS) > 65535) APPLY_ROWS *= 2;      // (a block walks its rows in a loop: any row count per block is served)
   const dim3 blocks(cdiv(C / kpv, cgw), cdiv(M, APPLY_ROWS));
   const float inv = 1.0f / (float)count;
@@ -632,7 +638,8 @@ extern "C" int dc_bn_bwd_apply_fin(int dtype, long M, int C, long count, const v
                                    const void* out, int ldout, int relu, const float* gamma, const float* save_mean,
                                    const float* save_invstd, const float* slab, int rows, float* dgamma, float* dbeta, void* dy, int lddy,
                                    void* g_out, int ldg, const float* mscale, const float* mshift, void* stream) {
-  DC_REQUIRE(slab != nullptr && rows > 0 && rows <= FIN_RL && dgamma && dbeta, "dc_bn_bwd_apply_fin: needs a slab of at most dc_bn_bwd_apply_fin_max_rows() rows");
+  DC_REQUIRE(slab != nullptr && ((rows > 0 && rows <= FIN_RL) || rows == SUM_ROW) && dgamma && dbeta,
+             "dc_bn_bwd_apply_fin: needs a slab of at most dc_bn_bwd_apply_fin_max_rows() rows, or a sum row (rows = -1)");
   DC_REQUIRE(((uintptr_t)slab & 15) == 0 && C % 4 == 0, "dc_bn_bwd_apply_fin: the slab is read with 16-byte loads (16-byte aligned, C a multiple of 4)");
   return bn_bwd_apply_impl(dtype, M, C, count, dout, lddo, y, ldy, out, ldout, relu, gamma, save_mean, save_invstd, nullptr, nullptr, dy, lddy, g_out, ldg,
                            mscale, mshift, stream, slab, rows, dgamma, dbeta);

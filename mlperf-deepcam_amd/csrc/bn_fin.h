@@ -7,8 +7,21 @@
 
 namespace dc {
 
+// A SUM ROW (rows == SUM_ROW = -1): instead of one fp32 row per producing workgroup the slab is ONE row of fp64 sums, double[2][C], that the
+// caller zeroes and the producing launch adds to with global fp64 atomics (igemm224.hip; dwpipe.hip's BatchNorm-backward sums).  The
+// addends are the same per-workgroup fp32 sums a row slab would hold; an fp64 sum of a few hundred fp32 numbers of one channel is exact
+// (53 bits against 24 + the spread of their exponents), i.e. independent of the order the atomics arrive in, and equal to what the
+// finalize kernels compute from the row slab.  The consumer then reads two numbers per channel, so it can run the finalize itself at
+// any size (dc_dwconv_fwd_fin / dc_bn_apply_fin / dc_bn_bwd_apply_fin) and the finalize launch leaves the dependent chain.
+constexpr int SUM_ROW = -1;
+__device__ inline void sum_row_load(const float* slab, int C, int c, double& s, double& q) {
+  const double* d = reinterpret_cast<const double*>(slab);
+  s = d[c];
+  q = d[(size_t)C + c];
+}
+
 struct BnFinArgs {
-  const float* slab;      // [2][rows][C]: sum, sum of squares
+  const float* slab;      // [2][rows][C]: sum, sum of squares; rows == SUM_ROW: double[2][C]
   int rows, C, parts;     // parts > 0: the slab went through slab_fold_kernel (stage-one results in place)
   double inv_count, unbias;
   const float* gamma;
@@ -158,8 +171,12 @@ __device__ inline void bn_fin_coefs(const BnFinArgs& a, int c, double s, double 
 __device__ inline void bn_finalize_block(const BnFinArgs& a, int cblock, double (&red)[2][FIN_RL][FIN_CH]) {
   const int C = a.C;
   const int c = cblock * FIN_CH + (threadIdx.x & (FIN_CH - 1));
-  double s, q;
-  slab_colsum2(SlabLoad{a.slab, a.slab + (size_t)a.rows * C, C, c, a.parts}, a.parts ? a.parts : a.rows, c < C, red, s, q, slab_is_short(a.rows, a.parts));
+  double s = 0.0, q = 0.0;
+  if (a.rows == SUM_ROW) {
+    if (c < C) sum_row_load(a.slab, C, c, s, q);
+  } else {
+    slab_colsum2(SlabLoad{a.slab, a.slab + (size_t)a.rows * C, C, c, a.parts}, a.parts ? a.parts : a.rows, c < C, red, s, q, slab_is_short(a.rows, a.parts));
+  }
   if (cblock == 0 && threadIdx.x == 0 && a.nbt != nullptr) *a.nbt += 1;
   if (threadIdx.x >= FIN_CH || c >= C) return;
   float sc, sh;
@@ -177,6 +194,11 @@ __device__ inline void bn_finalize_block(const BnFinArgs& a, int cblock, double 
 template <int CW>
 __device__ inline void slab_quad_sum2(const float* __restrict__ slab, int rows, int C, int cbase, double (&red)[2][4][CW], double& s, double& q) {
   static_assert(CW % 4 == 0 && CW <= 256, "one channel quad per thread and row sequence");
+  if (rows == SUM_ROW) {      // (uniform) the sums are there already
+    s = q = 0.0;
+    if (threadIdx.x < CW && cbase + (int)threadIdx.x < C) sum_row_load(slab, C, cbase + threadIdx.x, s, q);
+    return;
+  }
   constexpr int NQ = CW / 4;
   const int qd = threadIdx.x % NQ, j = threadIdx.x / NQ;
   if (j < 4) {
@@ -218,6 +240,10 @@ __device__ inline void slab_quad_sum2(const float* __restrict__ slab, int rows, 
 }
 // The same sums by ONE thread for channel c (blocks of more than 256 channels): the four row sequences in turn.
 __device__ inline void slab_quad_sum2_thread(const float* __restrict__ slab, int rows, int C, int c, double& s, double& q) {
+  if (rows == SUM_ROW) {
+    sum_row_load(slab, C, c, s, q);
+    return;
+  }
   const float* s0 = slab + c;
   const float* s1 = slab + (size_t)rows * C + c;
   double pa[4] = {0.0, 0.0, 0.0, 0.0}, pb[4] = {0.0, 0.0, 0.0, 0.0};

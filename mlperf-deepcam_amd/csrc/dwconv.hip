@@ -515,7 +515,7 @@ extern "C" int dc_dwconv_fwd_fin(int dtype, int C, int stride, int dil, int N, i
   if (int e = dw_check(dtype, C, stride, dil, N, Hi, Wi)) return e;
   if (int e = dc_check_view(x, ldx, C, dtype, "dc_dwconv_fwd_fin x")) return e;
   if (int e = dc_check_view(y, ldy, C, dtype, "dc_dwconv_fwd_fin y")) return e;
-  DC_REQUIRE(w && slab && gamma && beta && scale && shift && rows > 0, "dc_dwconv_fwd_fin: null argument");
+  DC_REQUIRE(w && slab && gamma && beta && scale && shift && (rows > 0 || rows == SUM_ROW), "dc_dwconv_fwd_fin: null argument");
   DC_REQUIRE(((uintptr_t)slab & 15) == 0, "dc_dwconv_fwd_fin: the slab is read with 16-byte loads (16-byte aligned)");
   DC_REQUIRE(dc_dwconv_fwd_fin_ok(dtype, C, stride, dil, N, Hi, Wi), "dc_dwconv_fwd_fin: shape not served (dc_dwconv_fwd_fin_ok)");
   if (count <= 1) return dc_fail("Expected more than 1 value per channel when training", __FILE__, __LINE__);
@@ -589,21 +589,46 @@ extern "C" int dc_dwconv_dgrad_wgrad_rows(int dtype, int C, int stride, int dil,
   return rows <= DWT_MAX_ROWS ? rows : 0;
 }
 
-extern "C" int dc_dwconv_dgrad_bnstats_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
-                                             const float* w, void* dx, int lddx, const void* ybn, int ldybn, const float* save_mean,
-                                             const float* save_invstd, const float* mscale, const float* mshift, int relu, float* slab,
-                                             float* wslab, void* stream) {
+// 1: the data gradients that take BatchNorm sums (dc_dwconv_dgrad_bnstats_wgrad_sum, dc_dwconv_dgrad_wgrad_bnres_sum) serve this shape: the
+// persistent pipelined kernel (dwpipe.hip), whose workgroups add their sums to ONE fp64 row (bn_fin.h: SUM_ROW)
+extern "C" int dc_dwconv_dgrad_sum_row_ok(int dtype, int C, int stride, int dil, int N, int Hi, int Wi) {
+  if (!g_dw_tile || stride != 1 || (dil != 1 && dil != 2) || C <= 0 || N <= 0 || (long)N * Hi * Wi >= (1L << 31)) return 0;
+  return dw_pipe_rows(dtype, C, dil, N, Hi, Wi) > 0 && dc_dwconv_dgrad_wgrad_rows(dtype, C, stride, dil, N, Hi, Wi) > 0 ? 1 : 0;
+}
+
+static int dgrad_bnstats_wgrad_impl(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                    const float* w, void* dx, int lddx, const void* ybn, int ldybn, const float* save_mean,
+                                    const float* save_invstd, const float* mscale, const float* mshift, int relu, float* slab,
+                                    float* wslab, void* stream, bool sum_row) {
   if (int e = dw_check(dtype, C, stride, dil, N, Hi, Wi)) return e;
   if (int e = dc_check_view(dy, lddy, C, dtype, "dc_dwconv_dgrad_bnstats_wgrad dy")) return e;
   if (int e = dc_check_view(dx, lddx, C, dtype, "dc_dwconv_dgrad_bnstats_wgrad dx")) return e;
   if (int e = dc_check_view(ybn, ldybn, C, dtype, "dc_dwconv_dgrad_bnstats_wgrad y")) return e;
   DC_REQUIRE(w && save_mean && save_invstd && slab && wslab && mscale && mshift, "dc_dwconv_dgrad_bnstats_wgrad: null argument");
   DC_REQUIRE(dc_dwconv_dgrad_wgrad_rows(dtype, C, stride, dil, N, Hi, Wi) > 0, "dc_dwconv_dgrad_bnstats_wgrad: shape not served");
+  DC_REQUIRE(!sum_row || (dc_dwconv_dgrad_sum_row_ok(dtype, C, stride, dil, N, Hi, Wi) && ((uintptr_t)slab & 7) == 0),
+             "dc_dwconv_dgrad_bnstats_wgrad_sum: shape not served (dc_dwconv_dgrad_sum_row_ok), or the sum row is not double[2][C]");
   DwBnStats bs;
   bs.y = ybn; bs.ldy = ldybn; bs.mean = save_mean; bs.invstd = save_invstd; bs.mscale = mscale; bs.mshift = mshift; bs.relu = relu ? 1 : 0;
-  bs.slab = slab; bs.rows = 0; bs.wslab = wslab;
+  bs.slab = slab; bs.rows = sum_row ? SUM_ROW : 0; bs.wslab = wslab;
   if (stride == 2) return launch_dw_tile_s2(dtype, 1, N, Hi, Wi, C, dy, lddy, w, nullptr, 0, dx, lddx, nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, 0, &bs);
   return launch_dw_tile(dtype, dil, true, dy, lddy, w, nullptr, 0, dx, lddx, N, Hi, Wi, C, (hipStream_t)stream, nullptr, nullptr, 0, &bs);
+}
+extern "C" int dc_dwconv_dgrad_bnstats_wgrad(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                             const float* w, void* dx, int lddx, const void* ybn, int ldybn, const float* save_mean,
+                                             const float* save_invstd, const float* mscale, const float* mshift, int relu, float* slab,
+                                             float* wslab, void* stream) {
+  return dgrad_bnstats_wgrad_impl(dtype, C, stride, dil, N, Hi, Wi, dy, lddy, w, dx, lddx, ybn, ldybn, save_mean, save_invstd, mscale, mshift, relu, slab,
+                                  wslab, stream, false);
+}
+// ... with the two BatchNorm sums added to a SUM ROW: `slab` is double[2][C] (sum g, sum g*xhat), zeroed by the caller; dc_bn_bwd_finalize and
+// dc_bn_bwd_apply_fin take it with rows = -1
+extern "C" int dc_dwconv_dgrad_bnstats_wgrad_sum(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                                 const float* w, void* dx, int lddx, const void* ybn, int ldybn, const float* save_mean,
+                                                 const float* save_invstd, const float* mscale, const float* mshift, int relu, float* slab,
+                                                 float* wslab, void* stream) {
+  return dgrad_bnstats_wgrad_impl(dtype, C, stride, dil, N, Hi, Wi, dy, lddy, w, dx, lddx, ybn, ldybn, save_mean, save_invstd, mscale, mshift, relu, slab,
+                                  wslab, stream, true);
 }
 
 // dc_dwconv_dgrad_bnstats_wgrad when this layer is not the only reader of the BatchNorm's output: the data gradient is added onto what the
@@ -659,10 +684,10 @@ extern "C" int dc_dwconv_dgrad_wgrad_bnres_rows(int dtype, int C, int stride, in
   return dw_pipe_rows(dtype, C, dil, N, Hi, Wi);
 }
 
-extern "C" int dc_dwconv_dgrad_wgrad_bnres(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
-                                           const float* w, const void* addend, int ldadd, void* dx, int lddx, const void* x, int ldx,
-                                           float* wslab, const void* ybn, int ldybn, const float* save_mean, const float* save_invstd,
-                                           int relu, float* slab, void* stream) {
+static int dgrad_wgrad_bnres_impl(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                  const float* w, const void* addend, int ldadd, void* dx, int lddx, const void* x, int ldx,
+                                  float* wslab, const void* ybn, int ldybn, const float* save_mean, const float* save_invstd,
+                                  int relu, float* slab, void* stream, bool sum_row) {
   if (int e = dw_check(dtype, C, stride, dil, N, Hi, Wi)) return e;
   if (int e = dc_check_view(dy, lddy, C, dtype, "dc_dwconv_dgrad_wgrad_bnres dy")) return e;
   if (int e = dc_check_view(dx, lddx, C, dtype, "dc_dwconv_dgrad_wgrad_bnres dx")) return e;
@@ -676,8 +701,24 @@ extern "C" int dc_dwconv_dgrad_wgrad_bnres(int dtype, int C, int stride, int dil
   bs.y = x; bs.ldy = ldx; bs.mean = bs.invstd = nullptr; bs.mscale = nullptr; bs.mshift = nullptr; bs.relu = 0;
   bs.slab = nullptr; bs.rows = 0; bs.wslab = wslab;
   DwResStats rs;
-  rs.y = ybn; rs.ldy = ldybn; rs.mean = save_mean; rs.invstd = save_invstd; rs.relu = relu ? 1 : 0; rs.slab = slab;
+  DC_REQUIRE(!sum_row || ((uintptr_t)slab & 7) == 0, "dc_dwconv_dgrad_wgrad_bnres_sum: a sum row is double[2][C]");
+  rs.y = ybn; rs.ldy = ldybn; rs.mean = save_mean; rs.invstd = save_invstd; rs.relu = relu ? 1 : 0; rs.slab = slab; rs.sum_row = sum_row ? 1 : 0;
   return launch_dw_pipe(dil, true, dy, lddy, w, addend, ldadd, dx, lddx, N, Hi, Wi, C, (hipStream_t)stream, nullptr, nullptr, 0, &bs, &rs);
+}
+extern "C" int dc_dwconv_dgrad_wgrad_bnres(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                           const float* w, const void* addend, int ldadd, void* dx, int lddx, const void* x, int ldx,
+                                           float* wslab, const void* ybn, int ldybn, const float* save_mean, const float* save_invstd,
+                                           int relu, float* slab, void* stream) {
+  return dgrad_wgrad_bnres_impl(dtype, C, stride, dil, N, Hi, Wi, dy, lddy, w, addend, ldadd, dx, lddx, x, ldx, wslab, ybn, ldybn, save_mean, save_invstd,
+                                relu, slab, stream, false);
+}
+// ... with the residual BatchNorm's two sums added to a SUM ROW (double[2][C], zeroed by the caller; served wherever the plain form is)
+extern "C" int dc_dwconv_dgrad_wgrad_bnres_sum(int dtype, int C, int stride, int dil, int N, int Hi, int Wi, const void* dy, int lddy,
+                                               const float* w, const void* addend, int ldadd, void* dx, int lddx, const void* x, int ldx,
+                                               float* wslab, const void* ybn, int ldybn, const float* save_mean, const float* save_invstd,
+                                               int relu, float* slab, void* stream) {
+  return dgrad_wgrad_bnres_impl(dtype, C, stride, dil, N, Hi, Wi, dy, lddy, w, addend, ldadd, dx, lddx, x, ldx, wslab, ybn, ldybn, save_mean, save_invstd,
+                                relu, slab, stream, true);
 }
 
 extern "C" int dc_dwconv_wgrad_reduce(int C, int rows, const float* wslab, float* grad_w, void* stream) {

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "dwtile.h"
 #include "dwtile_common.h"
+#include "bn_fin.h"
 
 namespace dc {
 
@@ -76,6 +77,7 @@ struct DwpArgs {
   const float* invstd2;
   int relu2;
   float* slab2;         // [2][st.rows][C]
+  int sum_row, sum_row2; // the BatchNorm sums (st.slab / slab2) go to a SUM ROW, double[2][C] (bn_fin.h), by fp64 atomics instead of a row per workgroup
 };
 
 #ifdef DWP_STAMPS
@@ -463,7 +465,8 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) s += red[(q * 2 + which) * P_CH + cl];
-        a.st.slab[((size_t)which * a.st.rows + wj) * a.C + c] = s;
+        if (a.sum_row) unsafeAtomicAdd(reinterpret_cast<double*>(a.st.slab) + (size_t)which * a.C + c, (double)s);
+        else a.st.slab[((size_t)which * a.st.rows + wj) * a.C + c] = s;
       }
     }
     __syncthreads();
@@ -483,7 +486,8 @@ __global__ __launch_bounds__(P_THREADS) void dwp_kernel(const DwpArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) s += red[(q * 2 + which) * P_CH + cl];
-        a.slab2[((size_t)which * a.st.rows + wj) * a.C + c] = s;
+        if (a.sum_row2) unsafeAtomicAdd(reinterpret_cast<double*>(a.slab2) + (size_t)which * a.C + c, (double)s);
+        else a.slab2[((size_t)which * a.st.rows + wj) * a.C + c] = s;
       }
     }
     __syncthreads();
@@ -563,6 +567,8 @@ int launch_dw_pipe(int dil, bool flip, const void* in, int ldin, const float* wp
   a.pscale = pscale; a.pshift = pshift; a.prelu = prelu;
   if (bnstats != nullptr) a.st = *bnstats;
   else { a.st.slab = nullptr; a.st.y = nullptr; a.st.ldy = 0; a.st.mean = a.st.invstd = a.st.mscale = a.st.mshift = nullptr; a.st.relu = 0; a.st.rows = 0; a.st.wslab = nullptr; }
+  a.sum_row = bnstats != nullptr && bnstats->rows == SUM_ROW && bnstats->slab != nullptr;
+  a.sum_row2 = res != nullptr && res->sum_row;
   a.st.rows = wc;
   a.y2 = nullptr; a.ldy2 = 0; a.mean2 = a.invstd2 = nullptr; a.relu2 = 0; a.slab2 = nullptr;
   if (res != nullptr) {

@@ -16,6 +16,7 @@ struct DwResStats {
   const float* invstd;
   int relu;
   float* slab;
+  int sum_row;      // slab is a SUM ROW (bn_fin.h): double[2][C], zeroed by the caller, added to by every workgroup
 };
 
 constexpr int DWT_MAX_ROWS = 2048;   // most partial rows the weight-gradient slab may hold

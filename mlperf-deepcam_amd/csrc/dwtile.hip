@@ -65,8 +65,10 @@ __device__ inline void stage_halo(char* smem, const T* __restrict__ in, int ldin
 }
 
 // forward (FLIP = false) and data gradient (FLIP = true: the same stencil with the taps reversed, plus an optional addend)
-// FIN (forward only): an instantiation of its own -- its 2 KiB of coefficients beside the 52 KiB halo tile would take the third workgroup off a CU
-template <typename T, int DIL, bool FLIP, int CG, bool WG = false, bool FIN = false>
+// FIN (forward only): instantiations of their own -- FIN = 1 (a row slab): 2 KiB of coefficients and 16 KiB of partial sums beside the 52 KiB halo
+// tile take the third workgroup off a CU; FIN = 2 (a sum row, bn_fin.h): one channel per thread, no partial sums, and the coefficients go
+// into the bytes the halo's last LDS-DMA instruction leaves unused where there are enough of them (three workgroups per CU stay)
+template <typename T, int DIL, bool FLIP, int CG, bool WG = false, int FIN = 0>
 __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int ldin, const float* __restrict__ wp,
                                                   const T* __restrict__ addend, int ldadd, T* __restrict__ out, int ldout, int H, int W,
                                                   int C, int ncgb, int ntx, int nty, const float* __restrict__ pscale,
@@ -94,7 +96,21 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
   const float* ps = pscale;
   const float* psh = pshift;
   int cbase = 0;
-  if constexpr (FIN) {
+  float fsc = 0.f, fsh = 0.f;
+  if constexpr (FIN == 2) {
+    // dc_dwconv_fwd_fin over a sum row: thread i takes channel i of the workgroup's block while the halo travels
+    constexpr int CW = CG * KPV;
+    if (threadIdx.x < CW) {
+      const int c = cg0 * KPV + threadIdx.x;
+      if (c < C) {
+        double s, q;
+        sum_row_load(fin.slab, C, c, s, q);
+        bn_fin_coefs(fin, c, s, q, tile_id == 0, fsc, fsh);
+      }
+    }
+    if (t == 0 && threadIdx.x == 0 && fin.nbt != nullptr) *fin.nbt += 1;
+  }
+  if constexpr (FIN == 1) {
     // dc_dwconv_fwd_fin: the producer's BatchNorm finalize over a short slab, by every workgroup for its own channels while its halo
     // travels (bn_fin.h: slab_quad_sum2); the workgroup of pixel tile 0 stores the vectors the backward pass reads
     constexpr int CW = CG * KPV;
@@ -117,6 +133,25 @@ __global__ __launch_bounds__(256) void dwt_kernel(const T* __restrict__ in, int 
     }
   }
   __syncthreads();   // vmcnt(0) + barrier: the whole halo tile has landed
+  if constexpr (FIN == 2) {
+    constexpr int CW = CG * KPV;
+    constexpr bool SLACK = K::LDS_BYTES - K::HP * CG * 16 >= 2 * CW * (int)sizeof(float);      // slots past the halo: zero-filled by the DMA, read by nobody
+    float* coef;
+    if constexpr (SLACK) {
+      coef = reinterpret_cast<float*>(smem + K::LDS_BYTES) - 2 * CW;
+    } else {
+      __shared__ float fincoef2[2 * CW];
+      coef = fincoef2;
+    }
+    if (threadIdx.x < CW) {
+      coef[threadIdx.x] = fsc;
+      coef[CW + threadIdx.x] = fsh;
+    }
+    __syncthreads();
+    ps = coef;
+    psh = coef + CW;
+    cbase = cg0 * KPV;
+  }
   if (!FLIP && ps != nullptr) {   // fused BatchNorm(+ReLU) of the producer, applied once per staged element
     bn_transform_tile<T, K::HH, K::HW, CG>(smem, y0 - DIL, x0 - DIL, H, W, ps, psh, prelu, cg0, ngroups, cbase);
     __syncthreads();
@@ -465,9 +500,15 @@ static void launch_fwd1(const TileGrid& t, const void* in, int ldin, const float
   }
   constexpr int LDS = TileCfg<DIL, CG>::LDS_BYTES;
   if constexpr (!FLIP) {
+    if (fin.slab != nullptr && fin.rows == SUM_ROW) {
+      DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, false, CG, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+      hipLaunchKernelGGL((dwt_kernel<T, DIL, false, CG, false, 2>), dim3(t.ntiles * t.ncgb), dim3(256), LDS, st, (const T*)in, ldin, wp,
+                         (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs, fin);
+      return;
+    }
     if (fin.slab != nullptr) {
-      DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, false, CG, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-      hipLaunchKernelGGL((dwt_kernel<T, DIL, false, CG, false, true>), dim3(t.ntiles * t.ncgb), dim3(256), LDS, st, (const T*)in, ldin, wp,
+      DC_ONCE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt_kernel<T, DIL, false, CG, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+      hipLaunchKernelGGL((dwt_kernel<T, DIL, false, CG, false, 1>), dim3(t.ntiles * t.ncgb), dim3(256), LDS, st, (const T*)in, ldin, wp,
                          (const T*)addend, ldadd, (T*)out, ldout, H, W, C, t.ncgb, t.ntx, t.nty, pscale, pshift, prelu, bs, fin);
       return;
     }
@@ -498,6 +539,7 @@ int launch_dw_tile(int dtype, int dil, bool flip, const void* in, int ldin, cons
   // BatchNorm applied on load: its in-place transform pass costs eight waves more than it costs three co-resident workgroups)
   if ((flip || dw_pipe_forward()) && (long)N * H * W < (1L << 31) && dw_pipe_rows(dtype, C, dil, N, H, W) > 0)
     return launch_dw_pipe(dil, flip, in, ldin, wp, addend, ldadd, out, ldout, N, H, W, C, st, pscale, pshift, prelu, bnstats);
+  DC_REQUIRE(bnstats == nullptr || bnstats->rows != SUM_ROW, "dc_dwconv_dgrad_*_sum: a sum row is served by the pipelined kernel only (dc_dwconv_dgrad_sum_row_ok)");
   const TileGrid t = tile_grid(C / kpv, N, H, W);
   DC_REQUIRE((long)t.ntiles * t.ncgb < (1L << 31) && (long)N * H * W < (1L << 31), "dc_dwconv: tensor too large for the tiled path");
   DwBnStats bs;

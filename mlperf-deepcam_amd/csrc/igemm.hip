@@ -635,13 +635,14 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
   p.mtiles = cdiv(M, BM);
   p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
-  if (bst == nullptr && !out32 && p.M <= TINY_M && p.g.ntaps == 1 && p.g.os == 1 && p.g.is == 1 && p.g.taps[0].dy == 0 && p.g.taps[0].dx == 0) {
+  const bool sum_row = slab != nullptr && slab_rows == -1;      // only the 224-pixel tile kernel below serves it
+  if (!sum_row && bst == nullptr && !out32 && p.M <= TINY_M && p.g.ntaps == 1 && p.g.os == 1 && p.g.is == 1 && p.g.taps[0].dy == 0 && p.g.taps[0].dx == 0) {
     if (d->dtype == DC_BF16) hipLaunchKernelGGL(tiny_gemm_kernel<bf16>, dim3(cdiv(p.g.Cout, 4)), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(tiny_gemm_kernel<float>, dim3(cdiv(p.g.Cout, 4)), dim3(256), 0, st, p);
     DC_CHECK_LAUNCH();
     return 0;
   }
-  if (bst == nullptr && g_thin_fwd && thin_fwd_eligible(p.g, d->dtype, bias != nullptr, accumulate, out32))
+  if (!sum_row && bst == nullptr && g_thin_fwd && thin_fwd_eligible(p.g, d->dtype, bias != nullptr, accumulate, out32))
     return launch_thin_fwd(p.g, N, in, ldin, w, p.ldw, out, ldout, slab, p.mtiles * p.g.os * p.g.os, st);
   if (d->dtype == DC_BF16 && !out32 && bst == nullptr) {      // (the BatchNorm-backward epilogue lives in the LDS-epilogue kernels)
     if (const int npb = pw384_plan(p)) {
@@ -652,12 +653,23 @@ static int run_gather(const dc_conv_desc* d, GatherMode mode, int N, int Hi, int
           DC_REQUIRE(slab_rows >= cdiv(p.M, 224), "dc_conv_fwd_kn: slab_rows is smaller than the rows this launch writes (dc_conv_stat_rows_kn)");
           p.mtiles = slab_rows;
         }
+        if (slab != nullptr && slab_rows == -1) {      // a sum row: double[2][Cout], zeroed by the caller; every tile adds its sums (fp64 atomics)
+          DC_REQUIRE(((uintptr_t)slab & 7) == 0, "dc_conv_fwd_kn: a sum row is double[2][Cout]");
+          p.mtiles = -1;
+        }
         return launch_pw224(p, npb == 224 ? 384 : 192, st);
       }
+      if (npb == 192 && sum_row) {      // the 128 x 192 tiles add to a sum row as well
+        DC_REQUIRE(((uintptr_t)slab & 7) == 0, "dc_conv_fwd_kn: a sum row is double[2][Cout]");
+        p.mtiles = -1;
+        return launch_pw192(p, st);
+      }
+      DC_REQUIRE(!sum_row, "dc_conv_fwd_kn: this launch does not add to a sum row (dc_conv_sum_row_kn)");
       DC_REQUIRE(slab == nullptr || slab_rows <= 0 || slab_rows == p.mtiles, "dc_conv_fwd_kn: slab_rows is not what this launch writes now (dc_conv_stat_rows_kn)");
       return npb == 192 ? launch_pw192(p, st) : launch_pw384(p, npb, st);
     }
   }
+  DC_REQUIRE(slab == nullptr || slab_rows != -1, "dc_conv_fwd_kn: this launch does not add to a sum row (dc_conv_sum_row_kn)");
   DC_REQUIRE(slab == nullptr || slab_rows <= 0 || slab_rows == p.mtiles * p.g.os * p.g.os, "dc_conv_fwd_kn: slab_rows is not what this launch writes now (dc_conv_stat_rows_kn)");
   if (d->dtype == DC_BF16 && !out32 && g_igemm256 != 0) {
     if (g_igemm256 == 2 || igemm256_wins(p)) {
@@ -1041,13 +1053,15 @@ extern "C" int dc_conv_fwd_kn(const dc_conv_desc* d, int N, int Hi, int Wi, cons
 // Rows of the slab dc_conv_fwd_kn writes for this layer when it is handed both weight images: one per 224-pixel tile where the planner gives
 // the layer to igemm224.hip (27 648 pixels: 124 rows instead of the 216 of dc_conv_stat_rows; 13 824 pixels: 62, short enough for the kernels
 // that run the BatchNorm finalize themselves), dc_conv_stat_rows everywhere else.  Pass the value as slab_rows.
-extern "C" int dc_conv_stat_rows_kn(const dc_conv_desc* d, int N, int Hi, int Wi) {
+// the pointwise tile a forward launch with both weight images would run on (pw384_plan's code: 224 / 226 / 192 / ...), 0: another kernel
+static int kn_forward_plan(const dc_conv_desc* d, int N, int Hi, int Wi, long* Mout) {
   const int plain = dc_conv_stat_rows(d, N, Hi, Wi);
-  if (plain <= 0 || d->dtype != DC_BF16) return plain;
+  if (plain <= 0 || d->dtype != DC_BF16) return 0;
   IgemmParams p;
-  if (!build_geom(*d, Hi, Wi, kFwd, &p.g)) return plain;
+  if (!build_geom(*d, Hi, Wi, kFwd, &p.g)) return 0;
   const long M = (long)N * p.g.Qh * p.g.Qw;
-  if (M >= (1L << 31) - BM) return plain;
+  if (M >= (1L << 31) - BM) return 0;
+  if (M <= TINY_M || (g_thin_fwd && thin_fwd_eligible(p.g, d->dtype, false, 0, false))) return 0;      // (run_gather asks these first)
   p.x = nullptr; p.w = nullptr; p.y = nullptr; p.bias = nullptr; p.slab = nullptr;
   p.N = N; p.ldx = weight_ld(p.g.Cin); p.ldy = weight_ld(p.g.Cout); p.ldw = weight_ld(p.g.Cin);
   alignas(16) static const char some_image[16] = {0};
@@ -1056,8 +1070,23 @@ extern "C" int dc_conv_stat_rows_kn(const dc_conv_desc* d, int N, int Hi, int Wi
   p.M = (int)M; p.m_beg = 0; p.phase_fast = 0; p.zero_page = nullptr; p.ngroup = 0; p.ksplit = 0; p.kslab = nullptr; p.zfill = 0;
   p.bst = BnBwdEpi{nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
   p.mtiles = cdiv(M, BM); p.accumulate = 0;
-  const int npb = pw384_plan(p);
-  return (npb == 224 || npb == 226) ? cdiv(M, 224) : plain;
+  *Mout = M;
+  return pw384_plan(p);
+}
+extern "C" int dc_conv_stat_rows_kn(const dc_conv_desc* d, int N, int Hi, int Wi) {
+  long M = 0;
+  const int npb = kn_forward_plan(d, N, Hi, Wi, &M);
+  return (npb == 224 || npb == 226) ? cdiv(M, 224) : dc_conv_stat_rows(d, N, Hi, Wi);
+}
+// 1: dc_conv_fwd_kn takes slab_rows = -1 for this layer -- stat_slab is then a SUM ROW, double[2][Cout], that the caller has zeroed and every
+// tile of the launch adds its channel sums to (fp64 atomics; the sum of a few hundred fp32 numbers is exact in fp64, so the row does not
+// depend on the order they arrive in).  dc_bn_finalize, dc_bn_apply_fin and dc_dwconv_fwd_fin take it with rows = -1; reading two numbers
+// per channel, the consumers run the finalize themselves at any tensor size.
+extern "C" int dc_conv_sum_row_kn(const dc_conv_desc* d, int N, int Hi, int Wi) {
+  if (d == nullptr) return 0;
+  long M = 0;
+  const int npb = kn_forward_plan(d, N, Hi, Wi, &M);
+  return npb == 224 || npb == 226 || npb == 192 ? 1 : 0;      // igemm224.hip's tiles and igemm192.hip's
 }
 extern "C" int dc_conv_dgrad_kn(const dc_conv_desc* d, int N, int Hi, int Wi, const void* dy, int lddy, const void* wb, const void* wf,
                                 void* dx, int lddx, int accumulate, void* stream) {

@@ -265,9 +265,10 @@ __global__ __launch_bounds__(512) void pw192_kernel(const IgemmParams p) {
     const int rows = p.mtiles, mt128 = m0 >> 7;
     for (int i = tid; i < 2 * TN; i += 512) {
       const int c = i % TN, which = i / TN;
-      if (n0 + c < g.Cout && mt128 < rows)
-        p.slab[((size_t)which * rows + mt128) * g.Cout + n0 + c] =
-            (red[(0 * 2 + which) * TN + c] + red[(1 * 2 + which) * TN + c]) + (red[(2 * 2 + which) * TN + c] + red[(3 * 2 + which) * TN + c]);
+      if (n0 + c >= g.Cout) continue;
+      const float v = (red[(0 * 2 + which) * TN + c] + red[(1 * 2 + which) * TN + c]) + (red[(2 * 2 + which) * TN + c] + red[(3 * 2 + which) * TN + c]);
+      if (rows < 0) unsafeAtomicAdd(reinterpret_cast<double*>(p.slab) + (size_t)which * g.Cout + n0 + c, (double)v);      // a sum row (bn_fin.h)
+      else if (mt128 < rows) p.slab[((size_t)which * rows + mt128) * g.Cout + n0 + c] = v;
     }
   }
 }

@@ -505,6 +505,10 @@ __global__ __launch_bounds__(512) void pw224_kernel(const IgemmParams p) {
         float v = red[which * TN + c];
 #pragma unroll
         for (int gq = 1; gq < GP; ++gq) v += red[(gq * 2 + which) * TN + c];
+        if (rows < 0) {      // a sum row (bn_fin.h: SUM_ROW): double[2][Cout], zeroed by the caller, added to by every tile
+          unsafeAtomicAdd(reinterpret_cast<double*>(p.slab) + (size_t)which * g.Cout + n0 + c, (double)v);
+          continue;
+        }
         float* col = p.slab + (size_t)which * rows * g.Cout + n0 + c;
         col[(size_t)tm * g.Cout] = v;
         for (int r = tm + ntm; r < rows; r += ntm) col[(size_t)r * g.Cout] = 0.f;

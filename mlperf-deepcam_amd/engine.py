@@ -212,6 +212,12 @@ class Engine:
         self.fuse_pw_bn_bwd = os.environ.get("DC_FUSE_PW_BN_BWD", "1") != "0"
         self.fuse_head_wgrad = os.environ.get("DC_FUSE_HEAD_WGRAD", "1") != "0"
         self.fuse_bn_src_dw = os.environ.get("DC_FUSE_BN_SRC_DW", "1") != "0"       # a stored BatchNorm output's last depthwise reader takes its backward sums
+        # BatchNorm sums as ONE fp64 row per layer that the producing launch adds to (dc_conv_sum_row_kn; include/deepcam_hip.h) instead of a row
+        # per workgroup: the consumer of the coefficients reads two numbers per channel and runs the finalize itself at any tensor size, so the
+        # 6 us finalize launch leaves the dependent chain.  The rows live in one arena that a single memset zeroes at the start of a train step.
+        self.bn_sum_rows = os.environ.get("DC_BN_SUM_ROWS", "1") != "0"
+        self._sum_arena = None
+        self._sum_used = 0
         self.conv_kn = os.environ.get("DC_CONV_KN", "1") != "0"                    # pointwise layers pass both packed weight images (dc_conv_fwd_kn / dc_conv_dgrad_kn)
         self.fuse_sep_fwd = os.environ.get("DC_FUSE_SEP_FWD", "1") != "0"           # depthwise + pointwise forward of the thin layers in one kernel
         # layers per grouped weight-gradient launch (dc_conv_wgrad_group).  Measured with both streams (scripts/ab_step.py): local
@@ -330,10 +336,24 @@ class Engine:
     def _f32(self, n: int) -> torch.Tensor:
         return torch.empty(n, dtype=torch.float32, device=self.device)
 
+    SUM_ARENA_FLOATS = 1 << 21      # 8 MiB: a sum row is double[2][C] = 4 * C floats; the network has some 150 BatchNorms of at most 2048 channels
+
+    def _sum_row(self, channels: int) -> torch.Tensor:
+        """A sum row (double[2][channels], as a float32 view) out of the arena that _run_forward zeroes once per train step."""
+        if self._sum_arena is None:
+            self._sum_arena = torch.zeros(self.SUM_ARENA_FLOATS, dtype=torch.float32, device=self.device)
+        n = (4 * channels + 15) // 16 * 16          # 64-byte granules
+        if self._sum_used + n > self.SUM_ARENA_FLOATS:
+            raise L.DeepcamHipError("the arena of BatchNorm sum rows is full (Engine.SUM_ARENA_FLOATS)")
+        row = self._sum_arena[self._sum_used:self._sum_used + n]
+        self._sum_used += n
+        return row
+
     # ------------------------------------------------------------------------------------------------ op builders
     def _conv(self, x: Act, wname: str, cout: int, k: int = 1, stride: int = 1, pad: int = 0, dil: int = 1,
               transposed: bool = False, out: Act = None, stats: bool = True, bias: str = None, name: str = None,
-              need_dx: bool = True, f32: bool = False, fwd_group: list = None, sole_consumer: bool = False, bn_fuse: bool = False):
+              need_dx: bool = True, f32: bool = False, fwd_group: list = None, sole_consumer: bool = False, bn_fuse: bool = False,
+              sum_row: bool = True):
         """Dense conv (implicit GEMM).  Returns (y, slab, rows).  fwd_group: a list that collects (dilation, wf, y, slab) instead
         of this layer's own forward launch (the caller then launches the members together: _dilated_group_fwd).
         sole_consumer: x is a stored BatchNorm(+ReLU) output that feeds this conv and nothing else; its BatchNorm's backward sums
@@ -357,6 +377,10 @@ class Engine:
         both = self.conv_kn and k == 1 and stride == 1 and not transposed and not f32 and need_dx and dt == L.DC_BF16
         rows = (lib.dc_conv_stat_rows_kn if both else lib.dc_conv_stat_rows)(C.byref(d), x.N, x.H, x.W) if stats else 0
         slab = self._f32(2 * rows * cout) if stats else None
+        if (stats and both and sum_row and self.bn_sum_rows and fwd_group is None and bias is None and out is None
+                and lib.dc_conv_sum_row_kn(C.byref(d), x.N, x.H, x.W) == 1):
+            # the 224-pixel tile kernel adds its sums to ONE fp64 row (rows = -1 from here on: _bn hands it to the consumer of the coefficients)
+            rows, slab = -1, self._sum_row(cout)
         y.pw_fuse = None
         if (bn_fuse and self.fuse_pw_bn_bwd and k == 1 and stride == 1 and not transposed and bias is None and not f32 and need_dx
                 and out is None and x.parent is None):
@@ -567,18 +591,22 @@ class Engine:
             if srows == 0 and self.fuse_dw_wgrad:
                 # stored input (or a lazy one whose statistics are taken elsewhere): data gradient + weight-gradient rows in one kernel
                 wrows = lib.dc_dwconv_dgrad_wgrad_rows(self.dt, Cc, stride, dil, N, H, W)
+            # BatchNorm sums into ONE fp64 row (the persistent kernel's workgroups add to it): the BatchNorm's apply then runs the finalize itself
+            sum_ok = self.bn_sum_rows and lib.dc_dwconv_dgrad_sum_row_ok(self.dt, Cc, stride, dil, N, H, W) == 1
+            stats_sum = False
             if srows > 0:
-                sslab = self._f32(2 * srows * Cc)
-                x.fused_bwd = (sslab, srows)
-                mean_p, invstd_p = L.dptr(x.mean), L.dptr(x.invstd)
                 if self.fuse_dw_wgrad:
                     wrows = lib.dc_dwconv_dgrad_wgrad_rows(self.dt, Cc, stride, dil, N, H, W)
+                stats_sum = sum_ok and wrows > 0
+                sslab = self._sum_row(Cc) if stats_sum else self._f32(2 * srows * Cc)
+                x.fused_bwd = (sslab, -1 if stats_sum else srows)
+                mean_p, invstd_p = L.dptr(x.mean), L.dptr(x.invstd)
             # the stored input is a block output relu(bn(y) + residual) and this data gradient completes d(x): that BatchNorm's sums ride along
             res = getattr(x, "bn_res", None) if (not lazy and wrows > 0 and srows == 0 and self.fuse_bn_res) else None
             if res is not None and getattr(x, "fused_bwd", 1) is None and x.parent is None and \
                     lib.dc_dwconv_dgrad_wgrad_bnres_rows(self.dt, Cc, stride, dil, N, H, W) == wrows:
-                rslab2 = self._f32(2 * wrows * Cc)
-                x.fused_bwd = (rslab2, wrows, x.grad_takes)       # (this layer's take_grad_mode call above was the last one so far)
+                rslab2 = self._sum_row(Cc) if sum_ok else self._f32(2 * wrows * Cc)
+                x.fused_bwd = (rslab2, -1 if sum_ok else wrows, x.grad_takes)       # (this layer's take_grad_mode call above was the last one so far)
             else:
                 res = None
             # the BatchNorm's make_bwd runs after this one: if it finds that ANOTHER consumer wrote the gradient later (this layer was not the
@@ -608,7 +636,7 @@ class Engine:
             def bwd():
                 res = fuse_state["res"]
                 if res is not None:
-                    L.call("dc_dwconv_dgrad_wgrad_bnres", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
+                    L.call("dc_dwconv_dgrad_wgrad_bnres_sum" if sum_ok else "dc_dwconv_dgrad_wgrad_bnres", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr if mode else None, dx.ld,
                            dx.ptr, dx.ld, src.ptr, src.ld, L.dptr(wslab), res["y"].ptr, res["y"].ld, L.dptr(res["mean"]), L.dptr(res["invstd"]),
                            res["relu"], L.dptr(rslab2), self._st())
                     return
@@ -623,7 +651,7 @@ class Engine:
                            dx.ptr, dx.ld, src.ptr, src.ld, ps, psh, prelu, L.dptr(wslab), self._st())
                     return
                 if wrows > 0:
-                    L.call("dc_dwconv_dgrad_bnstats_wgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr, dx.ld, src.ptr, src.ld,
+                    L.call("dc_dwconv_dgrad_bnstats_wgrad_sum" if stats_sum else "dc_dwconv_dgrad_bnstats_wgrad", self.dt, Cc, stride, dil, N, H, W, dy.ptr, dy.ld, pw, dx.ptr, dx.ld, src.ptr, src.ld,
                            mean_p, invstd_p, ps, psh, prelu, L.dptr(sslab), L.dptr(wslab), self._st())
                     return
                 self._on_side(dw_wgrad)
@@ -664,7 +692,8 @@ class Engine:
         # coefficients sums it itself, every workgroup for its own channels (same bits): one launch and one dependent boundary less per
         # BatchNorm.  Lazy: the depthwise layer that reads through this BatchNorm takes it (_dw sets fin["taken"])
         fin = None
-        if self.fuse_bn_fwd_fin and rows <= lib.dc_bn_bwd_apply_fin_max_rows() and M <= self.bn_fin_max_m and not self._debug_skip_finalize:
+        if (self.fuse_bn_fwd_fin and not self._debug_skip_finalize and
+                (rows == -1 or (rows <= lib.dc_bn_bwd_apply_fin_max_rows() and M <= self.bn_fin_max_m))):      # (a sum row: at any size)
             fin = {"taken": False, "args": (M, L.dptr(slab), rows, gam, bet, rm, rv, nbt, BN_MOMENTUM, BN_EPS, L.dptr(scale), L.dptr(shift),
                                             L.dptr(mean), L.dptr(invstd))}
 
@@ -750,7 +779,8 @@ class Engine:
             # flow.  Every 32-row block repeats the sum for its channels, so it pays only while the grid is small: local batch 2 12.47 ->
             # 12.38 ms, batch 4 19.80 -> 19.83, batch 8 33.47 -> 33.88 (2 592 blocks re-reading 86 KB each).  With 64 rows per block in this form
             # (option bn_fin_mul_bwd = 2) batch 4 gains too (19.02 -> 18.93) and batch 8 is level at best: on up to 16 384 pixels (DC_BN_FIN_MAX_M)
-            fin_in_apply = (self.fuse_bn_bwd_fin and apply_by is None and pwf is None and rrows <= lib.dc_bn_bwd_apply_fin_max_rows() and M <= self.bn_fin_max_m
+            fin_in_apply = (self.fuse_bn_bwd_fin and apply_by is None and pwf is None
+                            and (rrows == -1 or (rrows <= lib.dc_bn_bwd_apply_fin_max_rows() and M <= self.bn_fin_max_m))      # (a sum row: at any size)
                             and os.environ.get("DC_DEBUG_SKIP_BN_FINALIZE", "") not in ("bwd", "both"))     # (the timing switch is read later)
 
             def bwd():
@@ -781,8 +811,10 @@ class Engine:
         """depthwise 3x3 -> pointwise 1x1 [-> BN (+residual) (+ReLU)].  lazy: the BN output feeds only the next
         depthwise conv and is fused into it instead of being stored."""
         d = self._dw(x, s.prefix + ".conv1.weight", s.stride, s.dil, s.prefix + ".dw")
+        # (where dc_sepconv_fwd may take the pair below, the statistics stay a row slab: that operator writes rows)
+        sep_cand = self.fuse_sep_fwd and L.load().dc_sepconv_fwd_rows(self.dt, d.C, s.cout, s.stride, s.dil, d.N, d.H, d.W) > 0
         y, slab, rows = self._conv(d, s.prefix + ".pointwise.weight", s.cout, stats=bool(s.bn), name=s.prefix + ".pw",
-                                   bn_fuse=bool(s.bn) and residual is None)
+                                   bn_fuse=bool(s.bn) and residual is None, sum_row=not sep_cand)
         # the entry flow's thin layers: depthwise + pointwise forward as ONE operator (dc_sepconv_fwd: d is written once and not read back);
         # the two forward entries the builders above appended are replaced, everything backward stays as it is
         dwf, cvf = getattr(d, "dw_fwd", None), getattr(y, "conv_fwd", None)
@@ -1207,6 +1239,8 @@ class Engine:
         marks = self.region_marks if train else None      # measurement hook: events at the encoder's boundaries
         if marks is not None:
             marks.append(("fwd_begin", torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))))
+        if train and self._sum_used:
+            L.call("dc_memset_async", L.dptr(self._sum_arena), 0, 4 * self._sum_used, self._st())      # every BatchNorm sum row of the step
         for i, op in enumerate(self.fwd_train if train else self.fwd_eval):
             if marks is not None and i == self._enc_fwd_end:
                 marks.append(("fwd_enc_end", torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))))

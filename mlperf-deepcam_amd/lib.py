@@ -67,6 +67,7 @@ _SIGS = {
     "dc_conv_fwd": (I, [CD, I, I, I, P, I, P, P, P, I, P, I, P]),
     "dc_conv_fwd_kn": (I, [CD, I, I, I, P, I, P, P, P, P, I, P, I, I, P]),
     "dc_conv_stat_rows_kn": (I, [CD, I, I, I]),
+    "dc_conv_sum_row_kn": (I, [CD, I, I, I]),
     "dc_conv_dgrad_kn": (I, [CD, I, I, I, P, I, P, P, P, I, I, P]),
     "dc_conv_fwd_f32out": (I, [CD, I, I, I, P, I, P, P, I, P]),
     "dc_conv_fwd_dilated_group": (I, [CD, I, I, I, I, P, P, I, P, P, I, P, P]),
@@ -97,6 +98,9 @@ _SIGS = {
     "dc_dwconv_dgrad_wgrad": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P, I, P, P, I, P, P]),
     "dc_dwconv_dgrad_wgrad_bnres_rows": (I, [I, I, I, I, I, I, I]),
     "dc_dwconv_dgrad_wgrad_bnres": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P, I, P, P, I, P, P, I, P, P]),
+    "dc_dwconv_dgrad_sum_row_ok": (I, [I, I, I, I, I, I, I]),
+    "dc_dwconv_dgrad_bnstats_wgrad_sum": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P, P, P, P, I, P, P, P]),
+    "dc_dwconv_dgrad_wgrad_bnres_sum": (I, [I, I, I, I, I, I, I, P, I, P, P, I, P, I, P, I, P, P, I, P, P, I, P, P]),
     "dc_dwconv_wgrad_reduce": (I, [I, I, P, P, P]),
     "dc_dwconv_wgrad_workspace": (SZ, [I, I, I, I, I]),
     "dc_dwconv_wgrad": (I, [I, I, I, I, I, I, I, P, I, P, I, P, P, P, P, I, P]),

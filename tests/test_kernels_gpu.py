@@ -1114,6 +1114,116 @@ def test_batchnorm_finalize_inside_its_consumer(case):
         L.call("dc_bn_apply_fin", dt, M, Cc, M, vptr(yv), ld, vptr(slab), 65, *fin_args(state())[2:], None, 0, 0, vptr(o_got), Cc + 16, S())
 
 
+@pytest.mark.parametrize("shape", [(728, 728, 8, 48, 72, 1, 2), (728, 728, 4, 48, 72, 1, 2), (1536, 1536, 3, 20, 24, 2, 2), (256, 728, 2, 33, 21, 1, 2),
+                                   (728, 728, 2, 48, 72, 1, 1)],
+                         ids=["middle_flow_b8", "middle_flow_b4", "exit_flow_d2", "ragged", "middle_flow_b2_128x192_tiles"])
+def test_batchnorm_sum_row(shape):
+    """BatchNorm sums as ONE fp64 row (dc_conv_sum_row_kn): dc_conv_fwd_kn with slab_rows = -1 adds every tile's channel sums to a zeroed
+    double[2][Cout] -- exactly the fp64 column sums of the row slab the same launch writes with slab_rows = dc_conv_stat_rows_kn, in whatever order
+    the atomics arrive, and twice that after a second launch -- and dc_bn_finalize, dc_dwconv_fwd_fin and dc_bn_apply_fin take the row with
+    rows = -1: coefficients, stored vectors, running statistics and outputs bit for bit those of the row-slab path
+    (nn.BatchNorm2d in training mode behind SeparableConv2d_same.pointwise, deeplab_xception.py:62-66,104-119)."""
+    cin, cout, N, H, W, dil, force = shape      # force = 2: the 224-pixel tiles wherever eligible; 1: the planner (here: igemm192.hip's 128 x 192 tiles)
+    dtype = torch.bfloat16
+    dt = L.dtype_code(dtype)
+    lib = L.load()
+    d = desc(dtype, 1, 1, 0, 1, 0, cin, cout)
+    M = N * H * W
+    x = q(rnd(N, cin, H, W, seed=31) + 0.3, dtype)
+    w = rnd(cout, cin, 1, 1, seed=32, scale=cin ** -0.5)
+    nwf, nwb = C.c_size_t(), C.c_size_t()
+    L.call("dc_conv_packed_elems", C.byref(d), C.byref(nwf), C.byref(nwb))
+    wf = torch.empty(nwf.value, dtype=dtype, device=dev())
+    wb = torch.empty(nwb.value, dtype=dtype, device=dev())
+    L.call("dc_conv_pack_weights", C.byref(d), vptr(w.to(dev())), vptr(wf), vptr(wb), S())
+    _, xv = to_nhwc(x, dtype)
+    ld = (cout + 63) // 64 * 64
+    L.call("dc_set_option", b"pw224", force)
+    try:
+        assert lib.dc_conv_sum_row_kn(C.byref(d), N, H, W) == 1
+        rows = lib.dc_conv_stat_rows_kn(C.byref(d), N, H, W)
+        assert rows == ((M + 223) // 224 if force == 2 else (M + 127) // 128)
+        _, yv = empty_nhwc(N, H, W, cout, dtype, ld=ld)
+        slab = torch.full((2, rows, cout), float("nan"), device=dev())
+        L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin, vptr(wf), vptr(wb), None, vptr(yv), ld, vptr(slab), rows, 0, S())
+        y_rows = yv.clone()
+        srow = torch.zeros(2 * cout + 8, dtype=torch.float64, device=dev())
+        srow[2 * cout:] = float("nan")                          # a neighbour's row: must stay as it is
+        L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin, vptr(wf), vptr(wb), None, vptr(yv), ld, vptr(srow), -1, 0, S())
+        torch.cuda.synchronize()
+        assert torch.equal(yv, y_rows)
+        want = slab.double().sum(1).reshape(-1)
+        assert torch.equal(srow[:2 * cout], want) and torch.isnan(srow[2 * cout:]).all()
+        twice = srow.clone()
+        L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin, vptr(wf), vptr(wb), None, vptr(yv), ld, vptr(twice), -1, 0, S())
+        torch.cuda.synchronize()
+        assert torch.equal(twice[:2 * cout], 2 * want)
+        # a launch the 224-pixel tiles do not serve refuses the sum row instead of writing rows into it
+        L.call("dc_set_option", b"pw224", 0)
+        L.call("dc_set_option", b"pw192", 0)
+        assert lib.dc_conv_sum_row_kn(C.byref(d), N, H, W) == 0
+        with pytest.raises(L.DeepcamHipError):
+            L.call("dc_conv_fwd_kn", C.byref(d), N, H, W, vptr(xv), cin, vptr(wf), vptr(wb), None, vptr(yv), ld, vptr(srow), -1, 0, S())
+    finally:
+        L.call("dc_set_option", b"pw224", 1)
+        L.call("dc_set_option", b"pw192", 1)
+    gamma, beta = (torch.rand(cout) + 0.5).to(dev()), rnd(cout, seed=33, scale=0.3).to(dev())
+    wm = rnd(cout, 1, 3, 3, seed=34, scale=1 / 3).to(dev())
+    wd = torch.empty(9 * cout, device=dev())
+    L.call("dc_dwconv_pack_weights", cout, vptr(wm), vptr(wd), S())
+    res = q(rnd(N, cout, H, W, seed=35), dtype)
+    _, rv_ = to_nhwc(res, dtype)
+
+    def state():
+        st = {"rm": rnd(cout, seed=36).to(dev()), "rv": (torch.rand(cout, generator=torch.Generator().manual_seed(37)) + 0.5).to(dev()),
+              "nbt": torch.full((1,), 5, dtype=torch.int64, device=dev())}
+        for k in ("scale", "shift", "mean", "invstd"):
+            st[k] = torch.full((cout,), float("nan"), device=dev())
+        return st
+
+    def fin_args(st, sl, r):
+        return (vptr(sl), r, vptr(gamma), vptr(beta), vptr(st["rm"]), vptr(st["rv"]), vptr(st["nbt"]), 0.1, 1e-5, vptr(st["scale"]),
+                vptr(st["shift"]), vptr(st["mean"]), vptr(st["invstd"]))
+
+    def same_state(a, b):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+        assert int(a["nbt"]) == 6
+
+    ref, got = state(), state()
+    L.call("dc_bn_finalize", cout, M, *fin_args(ref, slab, rows), S())
+    L.call("dc_bn_finalize", cout, M, *fin_args(got, srow, -1), S())
+    torch.cuda.synchronize()
+    same_state(ref, got)
+    assert lib.dc_dwconv_fwd_fin_ok(dt, cout, 1, dil, N, H, W) == 1
+    for prelu in (1, 0):
+        got = state()
+        _, d_ref = empty_nhwc(N, H, W, cout, dtype)
+        L.call("dc_dwconv_fwd", dt, cout, 1, dil, N, H, W, vptr(yv), ld, vptr(wd), vptr(d_ref), cout, vptr(ref["scale"]), vptr(ref["shift"]), prelu, S())
+        db, d_got = empty_nhwc(N, H, W, cout, dtype, ld=cout + 16, off=8)
+        L.call("dc_dwconv_fwd_fin", dt, cout, 1, dil, N, H, W, vptr(yv), ld, vptr(wd), vptr(d_got), cout + 16, prelu, M, *fin_args(got, srow, -1), S())
+        torch.cuda.synchronize()
+        assert torch.equal(d_got.float(), d_ref.float()) and torch.isnan(db[..., :8].float()).all() and torch.isnan(db[..., 8 + cout:].float()).all()
+        same_state(ref, got)
+        for use_res in (True, False):
+            got = state()
+            _, o_ref = empty_nhwc(N, H, W, cout, dtype)
+            L.call("dc_bn_apply", dt, M, cout, vptr(yv), ld, vptr(ref["scale"]), vptr(ref["shift"]), vptr(rv_) if use_res else None, cout, prelu,
+                   vptr(o_ref), cout, S())
+            ob, o_got = empty_nhwc(N, H, W, cout, dtype, ld=cout + 16, off=8)
+            L.call("dc_bn_apply_fin", dt, M, cout, M, vptr(yv), ld, *fin_args(got, srow, -1), vptr(rv_) if use_res else None, cout, prelu, vptr(o_got),
+                   cout + 16, S())
+            torch.cuda.synchronize()
+            assert torch.equal(o_got.float(), o_ref.float()) and torch.isnan(ob[..., :8].float()).all() and torch.isnan(ob[..., 8 + cout:].float()).all()
+            same_state(ref, got)
+    # the statistics are the tensor's (against torch)
+    o = F.batch_norm(from_nhwc(yv).float().cpu(), None, None, gamma.cpu(), beta.cpu(), True, 0.1, 1e-5)
+    o = (o + res.float()).clamp_min(0) if False else o
+    _, o_plain = empty_nhwc(N, H, W, cout, dtype)
+    L.call("dc_bn_apply", dt, M, cout, vptr(yv), ld, vptr(ref["scale"]), vptr(ref["shift"]), None, 0, 0, vptr(o_plain), cout, S())
+    assert_close(from_nhwc(o_plain), o, dtype, bf16=2e-2)
+
+
 @pytest.mark.parametrize("tpb", [3, 50])
 def test_depthwise_wgrad_several_tiles_per_workgroup(tpb):
     """The weight-gradient planner gives a workgroup several tiles only on large layers; force it on a small one."""
@@ -1293,6 +1403,85 @@ def test_depthwise_dgrad_takes_the_residual_batchnorm_sums(case, with_addend, re
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     for u, v in zip(res[0][2:], res[1][2:]):
         np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=3e-5, atol=3e-5 * float(v.abs().max()))
+
+
+@pytest.mark.parametrize("case", [c for c in PIPE_CASES if c[0] in ("728", "728_b8", "1024d2", "64_half_block")], ids=lambda c: c[0])
+def test_depthwise_dgrad_batchnorm_sums_into_a_sum_row(case):
+    """The BatchNorm-backward sums of the persistent depthwise data gradient as ONE fp64 row (dc_dwconv_dgrad_sum_row_ok):
+    dc_dwconv_dgrad_bnstats_wgrad_sum and dc_dwconv_dgrad_wgrad_bnres_sum leave dx and the weight-gradient rows of the row-slab forms, bit for bit,
+    and a sum row that IS the fp64 column sum of their slab rows; dc_bn_bwd_finalize and dc_bn_bwd_apply_fin take it with rows = -1 and
+    return the bits of the row-slab path (the BatchNorm backward inside a Block, deeplab_xception.py:104-119 under train_hdf5_ddp.py:363)."""
+    _, Cc, dil, N, H, W = case
+    dt, lib, dtype = L.DC_BF16, L.load(), torch.bfloat16
+    assert lib.dc_dwconv_dgrad_sum_row_ok(dt, Cc, 1, dil, N, H, W) == 1
+    rows = lib.dc_dwconv_dgrad_wgrad_rows(dt, Cc, 1, dil, N, H, W)
+    assert rows > 0 and rows == lib.dc_dwconv_dgrad_bnstats_rows(dt, Cc, 1, dil, N, H, W)
+    M = N * H * W
+    ybn = q(rnd(N, Cc, H, W, seed=7), dtype)
+    gy = q(rnd(N, Cc, H, W, seed=3), dtype)
+    wm = rnd(Cc, 1, 3, 3, seed=2, scale=1 / 3).to(dev())
+    wd = torch.empty(9 * Cc, device=dev())
+    L.call("dc_dwconv_pack_weights", Cc, vptr(wm), vptr(wd), S())
+    mean, invstd = rnd(Cc, seed=8, scale=0.2).to(dev()), (torch.rand(Cc) + 0.5).to(dev())
+    msc, msh = (torch.rand(Cc) + 0.5).to(dev()), rnd(Cc, seed=9, scale=0.2).to(dev())
+    gamma = (torch.rand(Cc) + 0.5).to(dev())
+    ld = (Cc + 31) // 32 * 32
+    _, yv = to_nhwc(ybn, dtype, ld=ld)
+    _, gyv = to_nhwc(gy, dtype)
+
+    def run(sum_row):
+        _, dx = empty_nhwc(N, H, W, Cc, dtype)
+        wslab = torch.full((rows, 9, Cc), float("nan"), device=dev())
+        if sum_row:
+            slab = torch.zeros(2 * Cc + 4, dtype=torch.float64, device=dev())
+            slab[2 * Cc:] = float("nan")
+        else:
+            slab = torch.full((2, rows, Cc), float("nan"), device=dev())
+        L.call("dc_dwconv_dgrad_bnstats_wgrad_sum" if sum_row else "dc_dwconv_dgrad_bnstats_wgrad", dt, Cc, 1, dil, N, H, W, vptr(gyv), Cc, vptr(wd),
+               vptr(dx), Cc, vptr(yv), ld, vptr(mean), vptr(invstd), vptr(msc), vptr(msh), 1, vptr(slab), vptr(wslab), S())
+        torch.cuda.synchronize()
+        return dx, wslab, slab
+
+    dx_r, ws_r, slab_r = run(False)
+    dx_s, ws_s, slab_s = run(True)
+    assert torch.equal(dx_r, dx_s) and torch.equal(ws_r, ws_s)
+    assert torch.equal(slab_s[:2 * Cc], slab_r.double().sum(1).reshape(-1)) and torch.isnan(slab_s[2 * Cc:]).all()
+    # the consumers: finalize alone, and the apply that runs it itself
+    outs = []
+    for slab, r in ((slab_r, rows), (slab_s, -1)):
+        dgam, dbet = torch.full((Cc,), float("nan"), device=dev()), torch.full((Cc,), float("nan"), device=dev())
+        L.call("dc_bn_bwd_finalize", Cc, vptr(slab), r, vptr(dgam), vptr(dbet), S())
+        _, dyv = empty_nhwc(N, H, W, Cc, dtype)
+        L.call("dc_bn_bwd_apply", dt, M, Cc, M, vptr(dx_r), Cc, vptr(yv), ld, None, 0, 2, vptr(gamma), vptr(mean), vptr(invstd), vptr(dgam), vptr(dbet),
+               vptr(dyv), Cc, None, 0, vptr(msc), vptr(msh), S())
+        dgam2, dbet2 = torch.full((Cc,), float("nan"), device=dev()), torch.full((Cc,), float("nan"), device=dev())
+        _, dyv2 = empty_nhwc(N, H, W, Cc, dtype)
+        if r == -1 or r <= lib.dc_bn_bwd_apply_fin_max_rows():
+            L.call("dc_bn_bwd_apply_fin", dt, M, Cc, M, vptr(dx_r), Cc, vptr(yv), ld, None, 0, 2, vptr(gamma), vptr(mean), vptr(invstd), vptr(slab), r,
+                   vptr(dgam2), vptr(dbet2), vptr(dyv2), Cc, None, 0, vptr(msc), vptr(msh), S())
+            torch.cuda.synchronize()
+            assert torch.equal(dgam2, dgam) and torch.equal(dbet2, dbet) and torch.equal(dyv2.float(), dyv.float())
+        torch.cuda.synchronize()
+        outs.append((dgam, dbet, dyv))
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u.float(), v.float())
+    if dil != 1:
+        return
+    # the residual form: sums of the BatchNorm whose output (plus a residual, through a ReLU) is this layer's stored input
+    xo = q(rnd(N, Cc, H, W, seed=1), dtype)
+    add = q(rnd(N, Cc, H, W, seed=4), dtype)
+    _, xv = to_nhwc(xo, dtype, ld=ld)
+    res = []
+    for sum_row in (False, True):
+        _, dx = to_nhwc(add, dtype)
+        wslab = torch.full((rows, 9, Cc), float("nan"), device=dev())
+        slab = torch.zeros(2 * Cc, dtype=torch.float64, device=dev()) if sum_row else torch.full((2, rows, Cc), float("nan"), device=dev())
+        L.call("dc_dwconv_dgrad_wgrad_bnres_sum" if sum_row else "dc_dwconv_dgrad_wgrad_bnres", dt, Cc, 1, dil, N, H, W, vptr(gyv), Cc, vptr(wd),
+               vptr(dx), Cc, vptr(dx), Cc, vptr(xv), ld, vptr(wslab), vptr(yv), ld, vptr(mean), vptr(invstd), 1, vptr(slab), S())
+        torch.cuda.synchronize()
+        res.append((dx, wslab, slab))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[1][2], res[0][2].double().sum(1).reshape(-1))
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
