@@ -333,6 +333,12 @@ int dc_bn_apply_fin(int dtype, long M, int C, long count, const void* y, int ldy
 int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int lddo, const void* y, int ldy,
                      const void* out, int ldout, int relu, const float* save_mean, const float* save_invstd,
                      float* slab, const float* mscale, const float* mshift, void* stream);
+/* dc_bn_bwd_reduce with the two sums added to a SUM ROW (see dc_conv_sum_row_kn): `slab` is double[2][C], zeroed by the caller; every block of the
+ * pass adds its share with fp64 atomics (at most 2 048 per channel).  dc_bn_bwd_finalize / dc_bn_bwd_apply_fin take it with rows = -1: the
+ * two-stage fold of a long slab and the finalize launch leave the chain. */
+int dc_bn_bwd_reduce_sum(int dtype, long M, int C, const void* dout, int lddo, const void* y, int ldy,
+                     const void* out, int ldout, int relu, const float* save_mean, const float* save_invstd,
+                     float* slab, const float* mscale, const float* mshift, void* stream);
 /* step 2: dgamma, dbeta (fp32, written to the gradient arena) */
 int dc_bn_bwd_finalize(int C, float* slab, int rows, float* dgamma, float* dbeta, void* stream);
 /* step 3: dy = gamma*invstd*(g - dbeta/count - xhat*dgamma/count);  g is also stored when g_out != NULL */

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void colred_kernel(long M, int C, int RED_ROWS
                                                      const T* __restrict__ p1, int ld1, const T* __restrict__ p2,
                                                      int ld2, int relu, const float* __restrict__ mean,
                                                      const float* __restrict__ invstd, float* __restrict__ slab,
-                                                     const float* __restrict__ mscale, const float* __restrict__ mshift) {
+                                                     const float* __restrict__ mscale, const float* __restrict__ mshift, int sum_row) {
   // MODE 0: stats of p0            -> (sum x, sum x^2)
   // MODE 1: BN backward, p0 = dout, p1 = y (pre-BN), p2 = out (post activation; only read when relu)
   //                                -> (sum g, sum g*xhat),  g = dout * (out > 0)
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void colred_kernel(long M, int C, int RED_ROWS
       float s = 0.f;
 #pragma unroll
       for (int r = 0; r < RED_RL; ++r) s += red[which][r][cl];
-      slab[((size_t)which * gridDim.y + blockIdx.y) * C + c] = s;
+      if (sum_row) unsafeAtomicAdd(reinterpret_cast<double*>(slab) + (size_t)which * C + c, (double)s);      // bn_fin.h: SUM_ROW
+      else slab[((size_t)which * gridDim.y + blockIdx.y) * C + c] = s;
     }
   }
 }
@@ -426,11 +427,11 @@ static int ew_blocks(long total) {
 template <typename T, int MODE>
 static int launch_colred(long M, int C, const void* p0, int ld0, const void* p1, int ld1, const void* p2, int ld2,
                          int relu, const float* mean, const float* invstd, float* slab, hipStream_t st,
-                         const float* mscale = nullptr, const float* mshift = nullptr) {
+                         const float* mscale = nullptr, const float* mshift = nullptr, int sum_row = 0) {
   const int RED_ROWS = red_rows(M);
   const int ngroups = C / Elem<T>::kPerVec, cg = narrow_cg(ngroups, RED_CG_MAX);
   dim3 grid(cdiv(ngroups, cg), cdiv(M, red_rows(M)));
-#define DC_COLRED(W) hipLaunchKernelGGL((colred_kernel<T, MODE, W>), grid, dim3(256), 0, st, M, C, RED_ROWS, (const T*)p0, ld0, (const T*)p1, ld1, (const T*)p2, ld2, relu, mean, invstd, slab, mscale, mshift)
+#define DC_COLRED(W) hipLaunchKernelGGL((colred_kernel<T, MODE, W>), grid, dim3(256), 0, st, M, C, RED_ROWS, (const T*)p0, ld0, (const T*)p1, ld1, (const T*)p2, ld2, relu, mean, invstd, slab, mscale, mshift, sum_row)
   if (cg == 32) DC_COLRED(32); else if (cg == 16) DC_COLRED(16); else if (cg == 8) DC_COLRED(8); else DC_COLRED(4);
 #undef DC_COLRED
   DC_CHECK_LAUNCH();
@@ -571,9 +572,9 @@ extern "C" int dc_bn_apply_fin(int dtype, long M, int C, long count, const void*
   return bn_apply_impl(dtype, M, C, y, ldy, scale, shift, residual, ldr, relu, out, ldo, stream, &a, (rows == SUM_ROW ? 1 : g_bn_fin_mul_f) * g_bn_rows);
 }
 
-extern "C" int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int lddo, const void* y, int ldy,
-                                const void* out, int ldout, int relu, const float* save_mean, const float* save_invstd,
-                                float* slab, const float* mscale, const float* mshift, void* stream) {
+static int bn_bwd_reduce_impl(int dtype, long M, int C, const void* dout, int lddo, const void* y, int ldy,
+                              const void* out, int ldout, int relu, const float* save_mean, const float* save_invstd,
+                              float* slab, const float* mscale, const float* mshift, void* stream, int sum_row) {
   if (int e = dc_check_view(dout, lddo, C, dtype, "dc_bn_bwd_reduce dout")) return e;
   if (int e = dc_check_view(y, ldy, C, dtype, "dc_bn_bwd_reduce y")) return e;
   if (relu == 1)
@@ -581,8 +582,21 @@ extern "C" int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int 
   DC_REQUIRE(relu != 2 || (mscale && mshift), "dc_bn_bwd_reduce: relu == 2 needs the forward scale / shift vectors");
   DC_REQUIRE(save_mean && save_invstd && slab && M > 0, "dc_bn_bwd_reduce: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  return dtype == DC_BF16 ? launch_colred<bf16, 1>(M, C, dout, lddo, y, ldy, out, ldout, relu, save_mean, save_invstd, slab, st, mscale, mshift)
-                          : launch_colred<float, 1>(M, C, dout, lddo, y, ldy, out, ldout, relu, save_mean, save_invstd, slab, st, mscale, mshift);
+  DC_REQUIRE(!sum_row || ((uintptr_t)slab & 7) == 0, "dc_bn_bwd_reduce_sum: a sum row is double[2][C]");
+  return dtype == DC_BF16 ? launch_colred<bf16, 1>(M, C, dout, lddo, y, ldy, out, ldout, relu, save_mean, save_invstd, slab, st, mscale, mshift, sum_row)
+                          : launch_colred<float, 1>(M, C, dout, lddo, y, ldy, out, ldout, relu, save_mean, save_invstd, slab, st, mscale, mshift, sum_row);
+}
+extern "C" int dc_bn_bwd_reduce(int dtype, long M, int C, const void* dout, int lddo, const void* y, int ldy,
+                                const void* out, int ldout, int relu, const float* save_mean, const float* save_invstd,
+                                float* slab, const float* mscale, const float* mshift, void* stream) {
+  return bn_bwd_reduce_impl(dtype, M, C, dout, lddo, y, ldy, out, ldout, relu, save_mean, save_invstd, slab, mscale, mshift, stream, 0);
+}
+// ... with the two sums added to a SUM ROW (bn_fin.h): slab is double[2][C], zeroed by the caller; every block adds its share (fp64 atomics, at
+// most 2 048 per channel).  dc_bn_bwd_finalize / dc_bn_bwd_apply_fin take it with rows = -1: no slab fold, no finalize launch.
+extern "C" int dc_bn_bwd_reduce_sum(int dtype, long M, int C, const void* dout, int lddo, const void* y, int ldy,
+                                    const void* out, int ldout, int relu, const float* save_mean, const float* save_invstd,
+                                    float* slab, const float* mscale, const float* mshift, void* stream) {
+  return bn_bwd_reduce_impl(dtype, M, C, dout, lddo, y, ldy, out, ldout, relu, save_mean, save_invstd, slab, mscale, mshift, stream, 1);
 }
 
 extern "C" int dc_bn_bwd_finalize(int C, float* slab, int rows, float* dgamma, float* dbeta, void* stream) {

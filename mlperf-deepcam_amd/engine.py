@@ -739,7 +739,11 @@ class Engine:
         self.fwd_train.append(fwd_train)
         self.fwd_eval.append(fwd_eval)
         brows = lib.dc_bn_stat_rows(M)
-        bslab = self._f32(2 * brows * Cc)
+        bsum = self.bn_sum_rows            # the reduce pass (where no producer takes the sums on its way) adds to a sum row as well
+        if bsum:
+            brows, bslab = -1, self._sum_row(Cc)
+        else:
+            bslab = self._f32(2 * brows * Cc)
 
         def make_bwd():
             apply_by = getattr(lz, "apply_by", None) if lazy else None      # the consumer writes dy itself (the head, two passes)
@@ -785,7 +789,7 @@ class Engine:
 
             def bwd():
                 if fused is None:
-                    L.call("dc_bn_bwd_reduce", bdt, M, Cc, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, L.dptr(mean),
+                    L.call("dc_bn_bwd_reduce_sum" if bsum else "dc_bn_bwd_reduce", bdt, M, Cc, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, L.dptr(mean),
                            L.dptr(invstd), L.dptr(bslab), L.dptr(scale), L.dptr(shift), self._st())
                 if fin_in_apply:
                     L.call("dc_bn_bwd_apply_fin", bdt, M, Cc, M, do.ptr, do.ld, y.ptr, y.ld, optr(), old_, mrelu, gam, L.dptr(mean),

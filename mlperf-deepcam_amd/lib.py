@@ -111,6 +111,7 @@ _SIGS = {
     "dc_bn_apply": (I, [I, L, I, P, I, P, P, P, I, I, P, I, P]),
     "dc_bn_apply_fin": (I, [I, L, I, L, P, I, P, I, P, P, P, P, P, F, F, P, P, P, P, P, I, I, P, I, P]),
     "dc_bn_bwd_reduce": (I, [I, L, I, P, I, P, I, P, I, I, P, P, P, P, P, P]),
+    "dc_bn_bwd_reduce_sum": (I, [I, L, I, P, I, P, I, P, I, I, P, P, P, P, P, P]),
     "dc_bn_bwd_finalize": (I, [I, P, I, P, P, P]),
     "dc_bn_bwd_apply": (I, [I, L, I, L, P, I, P, I, P, I, I, P, P, P, P, P, P, I, P, I, P, P, P]),
     "dc_bn_bwd_apply_fin_max_rows": (I, []),
