@@ -137,7 +137,7 @@ class KernelTimer:
     """HIP-event timing of every launch of the two MFMA kernel families on the stream they run on:
        igemm  dc::igemm256_kernel / dc::igemm256p_kernel / dc::pw224_kernel / dc::pw384_kernel / dc::pw192_kernel / dc::igemm_kernel<T> / dc::tiny_gemm_kernel<T>
               (dc_conv_fwd + dc_conv_dgrad: dense conv forward and data gradient; the library's planner picks the tile shape per layer)
-       wgrad  dc::wgrad384_kernel / dc::wgrad256_kernel / dc::wgrad_dma_kernel<T>  (dc_conv_wgrad_partial: dense conv weight gradient, split-K
+       wgrad  dc::wgrad384_kernel / dc::wgrad_dma_kernel<T>  (dc_conv_wgrad_partial: dense conv weight gradient, split-K
               partial sums; a grouped call is ONE launch of the kernel for up to sixteen layers and counts as one) + dc::fold_kernel (dc_fold_slabs: the
               fixed-order sum of those slabs, which also folds the depthwise layers' rows; its time counts, it adds no launch or flop)
        Not in either family (neither its time nor its flop): dc::pw_bn_bwd_kernel (dc_pw_bn_bwd), the HBM-bound pass that does the BatchNorm backward
@@ -457,9 +457,9 @@ def main():
         names = {"igemm": f"dc::igemm256_kernel + dc::igemm256p_kernel + dc::pw224_kernel + dc::pw384_kernel + dc::pw192_kernel + dc::igemm_kernel<{a.dtype}> (dense conv "
                           "forward + data gradient: gather-form implicit GEMM; 256x256 (one tile per workgroup or persistent) / 224x384 / 256x384 / 128x192 "
                           "eight-wave or 128x128 four-wave tile per layer)",
-                 "wgrad": f"dc::wgrad384_kernel + dc::wgrad256_kernel + dc::wgrad_dma_kernel<{a.dtype}> + dc::fold_kernel (dense conv weight gradient: "
-                          "split-K partial sums on 256x384 tiles of the [tap][ci] axis (pointwise and stride-1 3x3 layers), 256x256 or 128x128 tiles "
-                          "(the rest), then the fixed-order fold of the slabs)"}
+                 "wgrad": f"dc::wgrad384_kernel + dc::wgrad_dma_kernel<{a.dtype}> + dc::fold_kernel (dense conv weight gradient: "
+                          "split-K partial sums on 256x384 tiles of the [tap][ci] axis (pointwise and stride-1 3x3 layers), 128x128 tiles (the rest), "
+                          "then the fixed-order fold of the slabs)"}
         dom = max(fams, key=lambda f: fams[f][1])
         def entry(f, src=None):
             fl, secs, n, nbytes = (src or fams)[f]

@@ -1651,6 +1651,13 @@ def test_batchnorm_train_fwd_bwd(shape, dtype, relu, use_res):
     L.call("dc_bn_bwd_reduce", dt, M, Cc, vptr(gov), Cc, vptr(yv), Cc + 8, vptr(ov), Cc + 16, relu, vptr(smean), vptr(sinv), vptr(slab2), None, None, S())
     dgamma, dbeta = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
     L.call("dc_bn_bwd_finalize", Cc, vptr(slab2), rows, vptr(dgamma), vptr(dbeta), S())
+    # the same pass into a sum row (dc_bn_bwd_reduce_sum): the fp64 column sums of those rows, and the same parameter gradients from it
+    srow = torch.zeros(2 * Cc, dtype=torch.float64, device=dev())
+    L.call("dc_bn_bwd_reduce_sum", dt, M, Cc, vptr(gov), Cc, vptr(yv), Cc + 8, vptr(ov), Cc + 16, relu, vptr(smean), vptr(sinv), vptr(srow), None, None, S())
+    dgamma_s, dbeta_s = torch.empty(Cc, device=dev()), torch.empty(Cc, device=dev())
+    L.call("dc_bn_bwd_finalize", Cc, vptr(srow), -1, vptr(dgamma_s), vptr(dbeta_s), S())
+    torch.cuda.synchronize()
+    assert torch.equal(srow, slab2.double().sum(1).reshape(-1)) and torch.equal(dgamma_s, dgamma) and torch.equal(dbeta_s, dbeta)
     _, dyv = empty_nhwc(N, H, W, Cc, dtype)
     _, gv = empty_nhwc(N, H, W, Cc, dtype)
     L.call("dc_bn_bwd_apply", dt, M, Cc, M, vptr(gov), Cc, vptr(yv), Cc + 8, vptr(ov), Cc + 16, relu, vptr(g_d), vptr(smean),
