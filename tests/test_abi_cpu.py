@@ -58,6 +58,16 @@ def test_host_side_geometry_without_gpu():
     assert lib.dc_conv_stat_rows_kn(C.byref(d), 2, 48, 72) == 54
     d32 = L.ConvDesc(L.DC_F32, 1, 1, 0, 1, 0, 728, 728)
     assert lib.dc_conv_stat_rows_kn(C.byref(d32), 8, 48, 72) == 216
+    # where a launch adds its BatchNorm sums to ONE fp64 row (a host-side plan as well): the pointwise tile kernels igemm224.hip / igemm192.hip
+    # (the middle flow at every local batch), not fp32, not a layer another kernel serves (2048 -> 256 fills a third of a 384-wide tile), not the
+    # stem; the depthwise data gradient: where the persistent kernel runs (stride 1, at least 64 channels, extents multiples of 8)
+    assert [lib.dc_conv_sum_row_kn(C.byref(d), n, 48, 72) for n in (8, 4, 2)] == [1, 1, 1]
+    assert lib.dc_conv_sum_row_kn(C.byref(d32), 8, 48, 72) == 0
+    assert lib.dc_conv_sum_row_kn(C.byref(L.ConvDesc(L.DC_BF16, 1, 1, 0, 1, 0, 2048, 256)), 8, 48, 72) == 0
+    assert lib.dc_conv_sum_row_kn(C.byref(L.ConvDesc(L.DC_BF16, 3, 2, 1, 1, 0, 16, 32)), 8, 768, 1152) == 0
+    assert lib.dc_dwconv_dgrad_sum_row_ok(L.DC_BF16, 728, 1, 1, 8, 48, 72) == 1 and lib.dc_dwconv_dgrad_sum_row_ok(L.DC_BF16, 1536, 1, 2, 2, 48, 72) == 1
+    assert lib.dc_dwconv_dgrad_sum_row_ok(L.DC_BF16, 728, 2, 1, 8, 96, 144) == 0 and lib.dc_dwconv_dgrad_sum_row_ok(L.DC_F32, 728, 1, 1, 8, 48, 72) == 0
+    assert lib.dc_dwconv_dgrad_sum_row_ok(L.DC_BF16, 32, 1, 1, 8, 48, 72) == 0 and lib.dc_dwconv_dgrad_sum_row_ok(L.DC_BF16, 728, 1, 1, 8, 50, 72) == 0
     # a failed call leaves a message behind
     d = L.ConvDesc(L.DC_BF16, 1, 2, 0, 1, 0, 64, 64)
     assert lib.dc_conv_stat_rows(C.byref(d), 1, 5, 5) == 1
