@@ -18,6 +18,14 @@ inline int red_rows(long M) {
   r = (r + 31) / 32 * 32;
   return (int)(r < RED_ROWS_MIN ? RED_ROWS_MIN : r);
 }
+// ... when the blocks add to a sum row: fp64 atomics onto ONE address go at about one per 17 ns (scripts/sum_row_contention.py: 1 728 blocks per
+// channel block took 12 -> 42 us), so the pass is cut into at most 256 row blocks -- 4 us of adds, hidden behind the loads
+constexpr int RED_SUM_MAX = 256;
+inline int red_rows_sum(long M) {
+  long r = (M + RED_SUM_MAX - 1) / RED_SUM_MAX;
+  r = (r + 31) / 32 * 32;
+  return (int)(r < RED_ROWS_MIN ? RED_ROWS_MIN : r);
+}
 // channel groups per block: 32 = 512 contiguous bytes per row (256-byte runs measured 25 % slower); tensors with fewer channel groups
 // (the 32 / 64 / 128-channel layers) get a block as narrow as the tensor, so that no lane idles on channels that do not exist
 constexpr int RED_CG_MAX = 32;
@@ -428,9 +436,9 @@ template <typename T, int MODE>
 static int launch_colred(long M, int C, const void* p0, int ld0, const void* p1, int ld1, const void* p2, int ld2,
                          int relu, const float* mean, const float* invstd, float* slab, hipStream_t st,
                          const float* mscale = nullptr, const float* mshift = nullptr, int sum_row = 0) {
-  const int RED_ROWS = red_rows(M);
+  const int RED_ROWS = sum_row ? red_rows_sum(M) : red_rows(M);
   const int ngroups = C / Elem<T>::kPerVec, cg = narrow_cg(ngroups, RED_CG_MAX);
-  dim3 grid(cdiv(ngroups, cg), cdiv(M, red_rows(M)));
+  dim3 grid(cdiv(ngroups, cg), cdiv(M, RED_ROWS));
 #define DC_COLRED(W) hipLaunchKernelGGL((colred_kernel<T, MODE, W>), grid, dim3(256), 0, st, M, C, RED_ROWS, (const T*)p0, ld0, (const T*)p1, ld1, (const T*)p2, ld2, relu, mean, invstd, slab, mscale, mshift, sum_row)
   if (cg == 32) DC_COLRED(32); else if (cg == 16) DC_COLRED(16); else if (cg == 8) DC_COLRED(8); else DC_COLRED(4);
 #undef DC_COLRED

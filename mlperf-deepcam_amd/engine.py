@@ -739,7 +739,10 @@ class Engine:
         self.fwd_train.append(fwd_train)
         self.fwd_eval.append(fwd_eval)
         brows = lib.dc_bn_stat_rows(M)
-        bsum = self.bn_sum_rows            # the reduce pass (where no producer takes the sums on its way) adds to a sum row as well
+        # the reduce pass (where no producer takes the sums on its way) adds to a sum row as well -- on tensors of 256 channels and more: same-address
+        # atomics go at one per 17 ns, so the pass is cut into 256 row blocks in that form, too few workgroups for a narrow tensor to stream at rate
+        # (128 channels x 1.77 M pixels: 151 -> 175 us, more than the fold and the finalize launch it saves; scripts/sum_row_contention.py)
+        bsum = self.bn_sum_rows and Cc >= 256
         if bsum:
             brows, bslab = -1, self._sum_row(Cc)
         else:
