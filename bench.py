@@ -267,6 +267,7 @@ def also_config(dnn, B, H, W, dtype_name, optimizer, steps, warmup, dev):
                               "achieved": round(enc_flop / ((t_fwd + t_bwd) * 1e-3) / 1e12, 2),
                               "frac": round(enc_flop / ((t_fwd + t_bwd) * 1e-3) / peak, 4)}}
     del step, net, opt, eng
+    gc.collect()                  # (an engine sits in reference cycles: its launch closures point back at it)
     torch.cuda.empty_cache()
     return out
 
@@ -516,6 +517,7 @@ def main():
             out["comm"] = comm
         if world == 1:
             del step, net, opt, eng       # the engine's arenas go back to the allocator before the other configurations / baselines
+            gc.collect()
             torch.cuda.empty_cache()
         if world == 1 and not a.no_also and (B, a.dtype) == (8, "bf16"):
             # BASELINE.json configs[1] and configs[2]: the other two single-GPU configurations, timed the same way in this process
